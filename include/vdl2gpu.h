@@ -1,0 +1,178 @@
+/*
+ * vdl2gpu.h -- C ABI of libvdl2gpu.so: the MI355X-native VDL Mode 2 front end.
+ *
+ * Drop-in boundary.  The reference has no plugin API; its
+ * seam is the translation-unit pair d8psk.c + viterbi.c, entered through
+ *
+ *     void *rcv_thread(void *arg)            d8psk.c:335   (one pthread per channel)
+ *     int   initD8psk(channel_t *ch)         d8psk.c:28
+ *     unsigned reversebits(unsigned, int)    d8psk.c:39    (also used by out.c:429-432)
+ *
+ * consuming the shared sample block `Cbuff` (rtl.c:273 / air.c:190, 32768 samples
+ * per hand-off, vdlm2.h:35) with per-channel `thread_param_t{chn,Fr,Fo}`
+ * (vdlm2.h:49-52) and producing `msgblk_t` records (vdlm2.h:39-47) through
+ * `decodeVdlm2(channel_t*)` (vdlm2.c:189).  This library replaces exactly that:
+ * raw sample blocks in, burst records out, everything between on the GPU.
+ *
+ *     reference interface                      replaced by
+ *     ---------------------------------------  -----------------------------------
+ *     rcv_thread() x nbch + Bar1/Bar2           vdl2gpu_create() + vdl2gpu_push()
+ *     in_callback() cu8->float, rtl.c:285-292   fused into the channeliser kernel
+ *     rx_callback() real f32,  air.c:206-208    VDL2GPU_FMT_F32R
+ *     thread_param_t            vdlm2.h:49-52   vdl2gpu_chan_t (same three ints)
+ *     decodeVdlm2(ch)           vdlm2.c:189     vdl2gpu_poll() -> vdl2gpu_burst_t,
+ *                                               vdl2gpu_burst_to_msgblk() fills the
+ *                                               reference's msgblk_t byte layout
+ *     initD8psk / viterbi_*     d8psk.c:28,     internal to the kernels
+ *                               viterbi.c:37-96
+ *     reversebits               d8psk.c:39      reversebits() still exported
+ *
+ * Plain C types only; no torch / HIP types cross this boundary.  `iq` may be a
+ * host pointer (copied with hipMemcpyAsync) or a device pointer (used in place).
+ * All functions return 0 on success or a negative VDL2GPU_E* code; none aborts.
+ */
+#ifndef VDL2GPU_H
+#define VDL2GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDL2GPU_ABI_VERSION 1
+#define VDL2GPU_MAXCH 8		/* MAXNBCHANNELS vdlm2.h:26 */
+#define VDL2GPU_MAXROWS 8	/* bursts with more rows are rejected, d8psk.c:103 */
+#define VDL2GPU_ROWLEN 255
+
+enum {
+	VDL2GPU_OK = 0,
+	VDL2GPU_EINVAL = -1,	/* bad argument / configuration */
+	VDL2GPU_EHIP = -2,	/* a HIP runtime call failed (see vdl2gpu_last_error) */
+	VDL2GPU_ENOMEM = -3,
+	VDL2GPU_EOVERFLOW = -4,	/* more bursts than the record ring holds; oldest kept */
+	VDL2GPU_ENODEV = -5	/* no usable GPU: the library never falls back to the CPU */
+};
+
+/* sample formats of the wideband stream */
+enum {
+	VDL2GPU_FMT_CU8 = 0,	/* interleaved u8 I,Q; x = (float)b - 127.37f  (rtl.c:287-289) */
+	VDL2GPU_FMT_CS16 = 1,	/* interleaved s16 I,Q; x = (float)v              */
+	VDL2GPU_FMT_CF32 = 2,	/* interleaved f32 I,Q  (what Cbuff holds with WITH_RTL)     */
+	VDL2GPU_FMT_F32R = 3	/* real f32 (Cbuff with WITH_AIR, air.c:190)                 */
+};
+
+enum { VDL2GPU_MEM_HOST = 0, VDL2GPU_MEM_DEVICE = 1 };
+
+/* == thread_param_t, vdlm2.h:49-52 */
+typedef struct {
+	int32_t chn;		/* channel number reported back in every burst */
+	int32_t Fr;		/* channel frequency, Hz (only used for ppm, d8psk.c:302) */
+	int32_t Fo;		/* offset from the tuner centre, Hz (d8psk.c:354) */
+} vdl2gpu_chan_t;
+
+typedef struct {
+	uint32_t struct_size;	/* sizeof(vdl2gpu_config_t), for ABI growth */
+	uint32_t sdrinrate;	/* SDRINRATE: 2000000 (rtl.c:36), 5/6 MS/s (air.c:134), 10 MS/s */
+	uint32_t sdrclk;	/* SDRCLK; 0 = sdrinrate/4000 (rtl.c:37, air.c:138) */
+	int32_t fmt;		/* VDL2GPU_FMT_* */
+	int32_t nbch;		/* channels per wideband stream, 1..8 */
+	int32_t nstreams;	/* independent wideband streams decoded side by side (>=1) */
+	const vdl2gpu_chan_t *chan;	/* nstreams*nbch entries, stream-major */
+	uint64_t max_push;	/* largest nsamples a single vdl2gpu_push() will carry */
+	int32_t device;		/* HIP device ordinal */
+	uint32_t max_bursts;	/* burst-record ring capacity (0 = default 65536) */
+	uint32_t flags;		/* VDL2GPU_F_* */
+} vdl2gpu_config_t;
+
+#define VDL2GPU_F_KEEP_DEC 1u	/* keep each push's decimated stream for vdl2gpu_debug_dec() */
+
+/* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */
+typedef struct {
+	int32_t stream;
+	int32_t chn;		/* msgblk_t.chn */
+	int32_t Fr;		/* msgblk_t.Fr */
+	int32_t nbrow;		/* msgblk_t.nbrow  (header value, d8psk.c:94) */
+	int32_t nlbyte;		/* msgblk_t.nlbyte (header value, d8psk.c:95) */
+	float df;		/* carrier estimate at sync, rad/symbol (channel_t.df) */
+	float ppm;		/* msgblk_t.ppm, d8psk.c:302 */
+	int64_t trig_dec;	/* 84 kS/s sample index of the sync trigger (stream time) */
+	int64_t end_dec;	/* 84 kS/s sample index of the last symbol of the burst */
+	int64_t trig_sample;	/* the same instants in input samples */
+	int64_t end_sample;
+	uint8_t data[VDL2GPU_MAXROWS][VDL2GPU_ROWLEN];	/* msgblk_t.data rows 0..7 */
+} vdl2gpu_burst_t;
+
+typedef struct {
+	uint64_t samples_in;	/* per stream */
+	uint64_t dec_samples;	/* 84 kS/s samples produced per channel */
+	uint64_t sync_evals;	/* WSYNC evaluations, all channels */
+	uint64_t triggers;	/* sync triggers */
+	uint64_t header_rejects;	/* d8psk.c:97-107 */
+	uint64_t bursts;	/* records handed out */
+	uint64_t deferrals;	/* bursts that waited for a later push to complete */
+	uint64_t overflowed;	/* records dropped because the ring was full */
+} vdl2gpu_stats_t;
+
+typedef struct {
+	double channelise_ms;	/* sum over pushes of the channeliser kernel, HIP events */
+	double demod_ms;	/* sum of the demodulator kernel(s) */
+	double other_ms;	/* compaction / bookkeeping kernels */
+	uint64_t pushes;
+	uint64_t samples;	/* input samples per stream covered by the sums */
+} vdl2gpu_timing_t;
+
+typedef struct vdl2gpu vdl2gpu_t;
+
+int vdl2gpu_abi_version(void);
+int vdl2gpu_create(const vdl2gpu_config_t *cfg, vdl2gpu_t **out);
+void vdl2gpu_destroy(vdl2gpu_t *h);
+
+/* Feed `nsamples` samples of every stream.  Stream s starts at
+ * (const char*)iq + s*stream_stride_bytes.  Asynchronous: returns once the
+ * work is enqueued on the handle's HIP stream.  Replaces one Bar2/Bar1
+ * hand-off of Cbuff (d8psk.c:360-383) for all channels at once, with any
+ * block length instead of the fixed 32768. */
+int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind);
+/* Wait until everything pushed so far has been demodulated. */
+int vdl2gpu_sync(vdl2gpu_t *h);
+/* Collect finished bursts (implies vdl2gpu_sync).  Bursts come out ordered by
+ * (end_sample, stream, chn).  Returns the count (>=0) or a negative error. */
+int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
+/* Number of bursts a poll would currently return (implies vdl2gpu_sync). */
+int vdl2gpu_pending(vdl2gpu_t *h);
+
+int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out);
+int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset);
+const char *vdl2gpu_last_error(vdl2gpu_t *h);
+const char *vdl2gpu_strerror(int code);
+
+/* Fill a reference msgblk_t (vdlm2.h:39-47, LP64 layout: prev@0 chn@8 Fr@12
+ * tv@16 ppm@32 nbrow@36 nlbyte@40 data@44, sizeof 16624) from a burst record.
+ * `msgblk` must point at sizeof(msgblk_t) zeroed bytes (calloc, as vdlm2.c:201). */
+int vdl2gpu_burst_to_msgblk(const vdl2gpu_burst_t *b, void *msgblk, size_t msgblk_size);
+
+/* d8psk.c:39-52; the host path keeps calling it (out.c:429-432, outxid.c:122). */
+unsigned int reversebits(const unsigned int bits, const int n);
+
+/* ---- pure host helpers (usable without a GPU) ---- */
+/* Local-oscillator table of one channel, d8psk.c:353-357 (libm sincosf of the
+ * float-narrowed phase step).  Returns the table length SDRINRATE/25000. */
+int vdl2gpu_lo_table(unsigned sdrinrate, int fo_hz, float *out_re_im, int max_complex);
+/* Integrate-and-dump schedule of one push (d8psk.c:374-381 in closed form). */
+int vdl2gpu_plan(uint64_t total_in, uint64_t n, unsigned sdrclk, unsigned lo_len,
+		 int *c0, int *no0, int *nf0, int64_t *nout);
+
+/* ---- diagnostics (P3 taps, tests only) ---- */
+/* Decimated samples of the LAST push of (stream, channel index), interleaved
+ * re,im; needs VDL2GPU_F_KEEP_DEC.  Returns the number of complex samples. */
+int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t max_complex);
+/* Local-oscillator table of (stream, channel index): len complex values. */
+int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, int max_complex);
+/* Device build of the fixed-sequence atan2f, elementwise (host arrays). */
+int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x, float *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

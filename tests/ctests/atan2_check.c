@@ -1,0 +1,75 @@
+/* CPU check: vdl2_atan2f (fixed-sequence restatement) == glibc atan2f, bit for bit.
+ * usage: atan2_check <npoints> <seed>   -> prints mismatches, exit 1 on any */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include "../../vdlm2dec_amd/csrc/vdl2_math.h"
+
+static uint64_t s[2];
+static uint64_t rnd(void)
+{
+	uint64_t a = s[0], b = s[1];
+	s[0] = b;
+	a ^= a << 23;
+	s[1] = a ^ b ^ (a >> 17) ^ (b >> 26);
+	return s[1] + b;
+}
+
+static int check(float y, float x, long *bad)
+{
+	float a = atan2f(y, x), b = vdl2_atan2f(y, x);
+	if (vdl2_f2u(a) != vdl2_f2u(b)) {
+		if (*bad < 10)
+			printf("MISMATCH y=%a x=%a libm=%a (%08x) ours=%a (%08x)\n", y, x, a, vdl2_f2u(a), b, vdl2_f2u(b));
+		(*bad)++;
+		return 1;
+	}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	long n = argc > 1 ? atol(argv[1]) : 10000000, bad = 0;
+	s[0] = argc > 2 ? (uint64_t) atoll(argv[2]) : 12345;
+	s[1] = 0x9E3779B97F4A7C15ull;
+	/* specials */
+	float sp[] = { 0.0f, -0.0f, 1.0f, -1.0f, 0.5f, 1.5f, 2.4375f, 0.4375f, 0.6875f, 1.1875f, 1e-30f, -1e-30f, 1e30f, -1e30f,
+		INFINITY, -INFINITY, 1e-40f, -1e-40f, 3.0f, 127.63f, -127.37f, 32767.f, -32768.f
+	};
+	int ns = sizeof sp / sizeof sp[0];
+	for (int i = 0; i < ns; i++)
+		for (int j = 0; j < ns; j++)
+			check(sp[i], sp[j], &bad);
+	for (long i = 0; i < n; i++) {
+		uint64_t r = rnd(), q = rnd();
+		float y, x;
+		switch (i & 3) {
+		case 0:	/* arbitrary finite bit patterns */
+			y = vdl2_u2f((uint32_t) r);
+			x = vdl2_u2f((uint32_t) (r >> 32));
+			if (!isfinite(y) || !isfinite(x))
+				continue;
+			break;
+		case 1:	/* moderate magnitudes like FIR outputs */
+			y = ((float)(int32_t) (r & 0xffffff) - 8388608.0f) * (1.0f / 1024.0f);
+			x = ((float)(int32_t) (q & 0xffffff) - 8388608.0f) * (1.0f / 1024.0f);
+			break;
+		case 2:	/* ratio near the reduction breakpoints */
+			x = vdl2_u2f(0x3f800000u | (uint32_t) (r & 0x7fffff)) * ((r >> 40) & 1 ? -1.f : 1.f);
+			{
+				float bp[] = { 0.4375f, 0.6875f, 1.1875f, 2.4375f, 1.0f, 0.0002441f };
+				float t = bp[(q >> 8) % 6];
+				y = x * t * (1.0f + ((float)(int)(q & 0xff) - 128.0f) * 1.1920929e-7f);
+			}
+			break;
+		default:	/* wide exponent spread */
+			y = ldexpf((float)(int32_t) (r & 0xffffff) - 8388608.0f, (int)((r >> 32) % 80) - 50);
+			x = ldexpf((float)(int32_t) (q & 0xffffff) - 8388608.0f, (int)((q >> 32) % 80) - 50);
+			break;
+		}
+		check(y, x, &bad);
+	}
+	printf("checked %ld points, %ld mismatches\n", n, bad);
+	return bad ? 1 : 0;
+}

@@ -1,0 +1,623 @@
+/*
+ * vdl2gpu.hip -- host side of libvdl2gpu.so: the C ABI of include/vdl2gpu.h.
+ *
+ * One handle = one HIP stream on one MI355X.  vdl2gpu_push() enqueues
+ *   [H2D copy] -> K1 channelise -> K2 demod -> K3 compact
+ * and returns; vdl2gpu_poll() synchronises and hands burst records back in
+ * stream-time order.  There is no CPU fallback: without a HIP device
+ * vdl2gpu_create() fails with VDL2GPU_ENODEV.
+ *
+ * Build (see __graft_entry__.build()):
+ *   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
+ *         vdl2gpu.hip -o libvdl2gpu.so
+ */
+#include "vdl2gpu_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+extern "C" void sincosf(float, float *, float *);
+
+#define HIPCHK(h, expr)                                                                         \
+	do {                                                                                    \
+		hipError_t e__ = (expr);                                                        \
+		if (e__ != hipSuccess) {                                                        \
+			(h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);          \
+			return VDL2GPU_EHIP;                                                    \
+		}                                                                               \
+	} while (0)
+
+struct PushTiming {
+	hipEvent_t e[4];	/* before K1, after K1, after K2, after K3 */
+	uint64_t samples;
+};
+
+struct vdl2gpu {
+	vdl2gpu_config_t cfg;
+	std::vector<vdl2gpu_chan_t> chans;
+	int S, C, L, maxwin, sdrclk;
+	size_t sample_bytes;
+	long long cap;		/* frames per stream per ping-pong buffer */
+	hipStream_t stream = nullptr;
+	void *d_raw = nullptr;
+	size_t raw_bytes = 0;
+	float2 *d_lo = nullptr;
+	float2 *d_dec[2] = { nullptr, nullptr };
+	StreamState *d_ss = nullptr;
+	ChanState *d_cs = nullptr;
+	ChanCfg *d_cfg = nullptr;
+	uint8_t *d_pn = nullptr;
+	vdl2gpu_burst_t *d_recs = nullptr;
+	unsigned *d_cnt = nullptr;	/* [0] = record count, [1] = overflow count */
+	unsigned rec_cap = 0;
+	uint64_t total_in = 0;		/* samples per stream pushed so far */
+	uint64_t pushes = 0;
+	uint64_t overflowed = 0;
+	std::vector<PushTiming> pending;
+	std::vector<PushTiming> free_ev;
+	vdl2gpu_timing_t tm{};
+	std::vector<vdl2gpu_burst_t> ready;	/* fetched, sorted, not yet handed out */
+	std::string err;
+};
+
+/* ------------------------------------------------------------ pure host helpers */
+extern "C" unsigned int reversebits(const unsigned int bits, const int n)
+{
+	unsigned int r = 0;
+	for (int i = 0; i < n; ++i)
+		r |= ((bits >> i) & 1u) << (n - 1 - i);
+	return r;
+}
+
+/* d8psk.c:353-357: wf[n] = cexpf(-n*Fo*I) with Fo narrowed to float.  cexpf of a
+ * purely imaginary argument is (cos, sin) from libm's sincosf. */
+extern "C" int vdl2gpu_lo_table(unsigned sdrinrate, int fo_hz, float *out_re_im, int max_complex)
+{
+	const int L = (int)(sdrinrate / 25000u);
+	if (L <= 0 || L > max_complex)
+		return VDL2GPU_EINVAL;
+	const float w = (float)((double)((float)fo_hz / (float)sdrinrate) * 2.0 * M_PI);
+	for (int n = 0; n < L; ++n) {
+		const float y = (float)(-n) * w;
+		float sn, cs;
+		sincosf(y, &sn, &cs);
+		out_re_im[2 * n] = cs;
+		out_re_im[2 * n + 1] = sn;
+	}
+	return L;
+}
+
+/* Decimation schedule of one push, pure integer arithmetic:
+ * given the number of samples already consumed, where does the push start in
+ * the 21/SDRCLK clock, the LO period and the current integrate-and-dump window,
+ * and how many 84 kS/s outputs complete inside it. */
+extern "C" int vdl2gpu_plan(uint64_t total_in, uint64_t n, unsigned sdrclk, unsigned lo_len,
+			    int *c0, int *no0, int *nf0, int64_t *nout)
+{
+	if (!sdrclk || !lo_len || sdrclk <= 21)
+		return VDL2GPU_EINVAL;
+	const unsigned __int128 t21 = (unsigned __int128)total_in * 21u;
+	const uint64_t done = (uint64_t)(t21 / sdrclk);	/* outputs completed before this push */
+	*c0 = (int)(uint64_t)(t21 % sdrclk);
+	*no0 = (int)(total_in % lo_len);
+	/* first input index after output (done-1): ceil(done*sdrclk/21) */
+	const unsigned __int128 num = (unsigned __int128)done * sdrclk;
+	const uint64_t first = (uint64_t)((num + 20) / 21);
+	*nf0 = (int)(total_in - first);
+	*nout = (int64_t)(((uint64_t)*c0 + 21ull * n) / sdrclk);
+	return VDL2GPU_OK;
+}
+
+/* stream time (84 kS/s index) -> index of the input sample that completed it */
+static int64_t dec_to_sample(int64_t m, unsigned sdrclk)
+{
+	if (m < 0)
+		return m;
+	return (int64_t)((((unsigned __int128)(uint64_t)(m + 1)) * sdrclk + 20) / 21) - 1;
+}
+
+extern "C" int vdl2gpu_abi_version(void)
+{
+	return VDL2GPU_ABI_VERSION;
+}
+
+extern "C" const char *vdl2gpu_strerror(int code)
+{
+	switch (code) {
+	case VDL2GPU_OK: return "ok";
+	case VDL2GPU_EINVAL: return "invalid argument";
+	case VDL2GPU_EHIP: return "HIP runtime error";
+	case VDL2GPU_ENOMEM: return "out of memory";
+	case VDL2GPU_EOVERFLOW: return "burst record ring overflow";
+	case VDL2GPU_ENODEV: return "no HIP device (there is no CPU fallback)";
+	default: return "unknown error";
+	}
+}
+
+extern "C" const char *vdl2gpu_last_error(vdl2gpu_t *h)
+{
+	return h ? h->err.c_str() : "null handle";
+}
+
+/* msgblk_t, vdlm2.h:39-47, LP64: prev@0(8) chn@8 Fr@12 tv@16(16) ppm@32 nbrow@36 nlbyte@40 data@44 */
+extern "C" int vdl2gpu_burst_to_msgblk(const vdl2gpu_burst_t *b, void *msgblk, size_t msgblk_size)
+{
+	if (!b || !msgblk || msgblk_size < 16624)
+		return VDL2GPU_EINVAL;
+	char *m = (char *)msgblk;
+	memcpy(m + 8, &b->chn, 4);
+	memcpy(m + 12, &b->Fr, 4);
+	memcpy(m + 32, &b->ppm, 4);
+	memcpy(m + 36, &b->nbrow, 4);
+	memcpy(m + 40, &b->nlbyte, 4);
+	memcpy(m + 44, b->data, VDL2GPU_MAXROWS * VDL2GPU_ROWLEN);
+	return VDL2GPU_OK;
+}
+
+/* ------------------------------------------------------------------- lifecycle */
+static size_t fmt_bytes(int fmt)
+{
+	switch (fmt) {
+	case VDL2GPU_FMT_CU8: return 2;
+	case VDL2GPU_FMT_CS16: return 4;
+	case VDL2GPU_FMT_CF32: return 8;
+	case VDL2GPU_FMT_F32R: return 4;
+	default: return 0;
+	}
+}
+
+extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
+{
+	if (!h)
+		return;
+	(void)hipSetDevice(h->cfg.device);
+	if (h->stream)
+		(void)hipStreamSynchronize(h->stream);
+	for (auto &pt : h->pending)
+		for (auto &e : pt.e)
+			(void)hipEventDestroy(e);
+	for (auto &pt : h->free_ev)
+		for (auto &e : pt.e)
+			(void)hipEventDestroy(e);
+	(void)hipFree(h->d_raw);
+	(void)hipFree(h->d_lo);
+	(void)hipFree(h->d_dec[0]);
+	(void)hipFree(h->d_dec[1]);
+	(void)hipFree(h->d_ss);
+	(void)hipFree(h->d_cs);
+	(void)hipFree(h->d_cfg);
+	(void)hipFree(h->d_pn);
+	(void)hipFree(h->d_recs);
+	(void)hipFree(h->d_cnt);
+	if (h->stream)
+		(void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+static int create_impl(vdl2gpu_t *h)
+{
+	const vdl2gpu_config_t &cfg = h->cfg;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg.device >= ndev) {
+		h->err = "no HIP device";
+		return VDL2GPU_ENODEV;
+	}
+	HIPCHK(h, hipSetDevice(cfg.device));
+	HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	const int S = h->S, L = h->L;
+	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
+	h->cap = VDL2_CARRY_FRAMES + jmax + 64;
+	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
+	HIPCHK(h, hipMalloc(&h->d_dec[0], dec_bytes));
+	HIPCHK(h, hipMalloc(&h->d_dec[1], dec_bytes));
+	HIPCHK(h, hipMemsetAsync(h->d_dec[0], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
+	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
+	HIPCHK(h, hipMalloc(&h->d_ss, (size_t)S * sizeof(StreamState)));
+	HIPCHK(h, hipMalloc(&h->d_cs, (size_t)S * VDL2_CS * sizeof(ChanState)));
+	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
+	HIPCHK(h, hipMalloc(&h->d_pn, VDL2_PN_BITS));
+	HIPCHK(h, hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
+	HIPCHK(h, hipMalloc(&h->d_cnt, 2 * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 2 * sizeof(unsigned), h->stream));
+
+	std::vector<float2> lo((size_t)S * VDL2_CS * L, make_float2(0.f, 0.f));
+	std::vector<ChanCfg> cc((size_t)S * VDL2_CS, ChanCfg{ 0, 0, 0, 0 });
+	std::vector<float> tmp(2 * (size_t)L);
+	for (int s = 0; s < S; ++s)
+		for (int c = 0; c < h->C; ++c) {
+			const vdl2gpu_chan_t &ch = h->chans[(size_t)s * h->C + c];
+			vdl2gpu_lo_table(cfg.sdrinrate, ch.Fo, tmp.data(), L);
+			for (int n = 0; n < L; ++n)
+				lo[((size_t)s * VDL2_CS + c) * L + n] = make_float2(tmp[2 * n], tmp[2 * n + 1]);
+			cc[(size_t)s * VDL2_CS + c] = ChanCfg{ ch.chn, ch.Fr, ch.Fo, 0 };
+		}
+	HIPCHK(h, hipMemcpyAsync(h->d_lo, lo.data(), lo.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipMemcpyAsync(h->d_cfg, cc.data(), cc.size() * sizeof(ChanCfg), hipMemcpyHostToDevice, h->stream));
+
+	/* scrambler sequence from seed 0x4D4B (d8psk.c:54-65, 299): identical for every burst */
+	std::vector<uint8_t> pn(VDL2_PN_BITS);
+	unsigned sc = 0x4D4B;
+	for (size_t i = 0; i < pn.size(); ++i) {
+		const unsigned b = (sc ^ (sc >> 14)) & 1u;
+		sc = (sc << 1) | b;
+		pn[i] = (uint8_t)b;
+	}
+	HIPCHK(h, hipMemcpyAsync(h->d_pn, pn.data(), pn.size(), hipMemcpyHostToDevice, h->stream));
+
+	/* canonical start state: everything zero except initD8psk's perr=100 (d8psk.c:28-37);
+	 * 16 zero frames stand for the empty Inbuff ring */
+	std::vector<StreamState> ss(S);
+	memset(ss.data(), 0, ss.size() * sizeof(StreamState));
+	for (auto &x : ss) {
+		x.dec_base = -VDL2_HIST;
+		x.dec_fill = VDL2_HIST;
+	}
+	std::vector<ChanState> cs((size_t)S * VDL2_CS);
+	memset(cs.data(), 0, cs.size() * sizeof(ChanState));
+	for (auto &x : cs) {
+		x.pos = 1;	/* clk: 0 -> 4 (sample 0, idle) -> 8 (sample 1, evaluate) */
+		x.r = 0;
+		x.perr = 100.0f;
+	}
+	HIPCHK(h, hipMemcpyAsync(h->d_ss, ss.data(), ss.size() * sizeof(StreamState), hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipMemcpyAsync(h->d_cs, cs.data(), cs.size() * sizeof(ChanState), hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return VDL2GPU_OK;
+}
+
+extern "C" int vdl2gpu_create(const vdl2gpu_config_t *cfg, vdl2gpu_t **out)
+{
+	if (!cfg || !out || cfg->struct_size != sizeof(vdl2gpu_config_t))
+		return VDL2GPU_EINVAL;
+	if (cfg->nbch < 1 || cfg->nbch > VDL2GPU_MAXCH || cfg->nstreams < 1 || !cfg->chan || !cfg->max_push)
+		return VDL2GPU_EINVAL;
+	if (fmt_bytes(cfg->fmt) == 0 || cfg->sdrinrate < 100000 || cfg->sdrinrate % 25000)
+		return VDL2GPU_EINVAL;
+	const unsigned sdrclk = cfg->sdrclk ? cfg->sdrclk : cfg->sdrinrate / 4000;
+	if (sdrclk <= 21 || sdrclk > 1000000)
+		return VDL2GPU_EINVAL;
+	vdl2gpu_t *h = new(std::nothrow) vdl2gpu;
+	if (!h)
+		return VDL2GPU_ENOMEM;
+	h->cfg = *cfg;
+	h->S = cfg->nstreams;
+	h->C = cfg->nbch;
+	h->L = (int)(cfg->sdrinrate / 25000);	/* SDRINRATE/STEPRATE, d8psk.c:348 */
+	h->sdrclk = (int)sdrclk;
+	h->maxwin = (h->sdrclk + 20) / 21;
+	h->sample_bytes = fmt_bytes(cfg->fmt);
+	h->rec_cap = cfg->max_bursts ? cfg->max_bursts : 65536u;
+	h->chans.assign(cfg->chan, cfg->chan + (size_t)cfg->nstreams * cfg->nbch);
+	h->cfg.chan = h->chans.data();
+	const int rc = create_impl(h);
+	if (rc != VDL2GPU_OK) {
+		std::string e = h->err;
+		vdl2gpu_destroy(h);
+		*out = nullptr;
+		return rc;
+	}
+	*out = h;
+	return VDL2GPU_OK;
+}
+
+/* ------------------------------------------------------------------------ push */
+static int get_events(vdl2gpu_t *h, PushTiming &pt)
+{
+	if (!h->free_ev.empty()) {
+		pt = h->free_ev.back();
+		h->free_ev.pop_back();
+		return VDL2GPU_OK;
+	}
+	for (auto &e : pt.e)
+		HIPCHK(h, hipEventCreate(&e));
+	return VDL2GPU_OK;
+}
+
+static int harvest_timing(vdl2gpu_t *h)
+{
+	for (auto &pt : h->pending) {
+		float a = 0, b = 0, c = 0;
+		HIPCHK(h, hipEventElapsedTime(&a, pt.e[0], pt.e[1]));
+		HIPCHK(h, hipEventElapsedTime(&b, pt.e[1], pt.e[2]));
+		HIPCHK(h, hipEventElapsedTime(&c, pt.e[2], pt.e[3]));
+		h->tm.channelise_ms += a;
+		h->tm.demod_ms += b;
+		h->tm.other_ms += c;
+		h->tm.pushes++;
+		h->tm.samples += pt.samples;
+		h->free_ev.push_back(pt);
+	}
+	h->pending.clear();
+	return VDL2GPU_OK;
+}
+
+template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
+{
+	hipLaunchKernelGGL(k1_channelise<FMT>, grid, dim3(K1_THREADS), smem, st, p);
+}
+
+extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind)
+{
+	if (!h || (!iq && nsamples))
+		return VDL2GPU_EINVAL;
+	if (nsamples == 0)
+		return VDL2GPU_OK;
+	if (nsamples > h->cfg.max_push)
+		return VDL2GPU_EINVAL;
+	if (h->S > 1 && stream_stride_bytes < nsamples * h->sample_bytes)
+		return VDL2GPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	if (h->pending.size() >= 256) {	/* bound the event backlog */
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		int rc = harvest_timing(h);
+		if (rc)
+			return rc;
+	}
+	const void *src = iq;
+	size_t stride = stream_stride_bytes;
+	if (memkind == VDL2GPU_MEM_HOST) {
+		const size_t per = nsamples * h->sample_bytes;
+		const size_t need = per * (size_t)h->S;
+		if (need > h->raw_bytes) {
+			HIPCHK(h, hipStreamSynchronize(h->stream));
+			(void)hipFree(h->d_raw);
+			h->d_raw = nullptr;
+			h->raw_bytes = 0;
+			HIPCHK(h, hipMalloc(&h->d_raw, need));
+			h->raw_bytes = need;
+		}
+		for (int s = 0; s < h->S; ++s)
+			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw + (size_t)s * per,
+						 (const char *)iq + (size_t)s * stream_stride_bytes, per,
+						 hipMemcpyHostToDevice, h->stream));
+		src = h->d_raw;
+		stride = per;
+	} else if (memkind != VDL2GPU_MEM_DEVICE)
+		return VDL2GPU_EINVAL;
+
+	K1Params k1{};
+	int64_t J = 0;
+	vdl2gpu_plan(h->total_in, nsamples, (unsigned)h->sdrclk, (unsigned)h->L, &k1.c0, &k1.no0, &k1.nf0, &J);
+	const int par = (int)(h->pushes & 1);
+	k1.raw = src;
+	k1.stream_stride = stride;
+	k1.fmt = h->cfg.fmt;
+	k1.nbch = h->C;
+	k1.sdrclk = h->sdrclk;
+	k1.L = h->L;
+	k1.maxwin = h->maxwin;
+	k1.parity = par;
+	k1.N = (long long)nsamples;
+	k1.J = J;
+	k1.lo = h->d_lo;
+	k1.dec = h->d_dec[par];
+	k1.cap = h->cap;
+	k1.ss = h->d_ss;
+
+	PushTiming pt{};
+	int rc = get_events(h, pt);
+	if (rc)
+		return rc;
+	pt.samples = nsamples;
+	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
+	{
+		const long long per_block = K1_OPB * K1_PASSES;
+		const unsigned gx = (unsigned)((J + 1 + per_block - 1) / per_block);
+		const dim3 grid(gx, (unsigned)h->S);
+		const size_t smem = ((size_t)(h->L + h->maxwin) * VDL2_CS + (size_t)K1_OPB * h->maxwin) * sizeof(float2);
+		switch (h->cfg.fmt) {
+		case VDL2GPU_FMT_CU8: launch_k1<VDL2GPU_FMT_CU8>(k1, grid, smem, h->stream); break;
+		case VDL2GPU_FMT_CS16: launch_k1<VDL2GPU_FMT_CS16>(k1, grid, smem, h->stream); break;
+		case VDL2GPU_FMT_CF32: launch_k1<VDL2GPU_FMT_CF32>(k1, grid, smem, h->stream); break;
+		default: launch_k1<VDL2GPU_FMT_F32R>(k1, grid, smem, h->stream); break;
+		}
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipEventRecord(pt.e[1], h->stream));
+	{
+		K2Params k2{};
+		k2.dec = h->d_dec[par];
+		k2.cap = h->cap;
+		k2.nbch = h->C;
+		k2.J = J;
+		k2.ss = h->d_ss;
+		k2.cs = h->d_cs;
+		k2.cfg = h->d_cfg;
+		k2.pn = h->d_pn;
+		k2.recs = h->d_recs;
+		k2.rec_count = h->d_cnt;
+		k2.rec_cap = h->rec_cap;
+		k2.overflow = h->d_cnt + 1;
+		hipLaunchKernelGGL(k2_demod, dim3((unsigned)h->C, (unsigned)h->S), dim3(K2_THREADS), 0, h->stream, k2);
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
+	{
+		K3Params k3{};
+		k3.src = h->d_dec[par];
+		k3.dst = h->d_dec[par ^ 1];
+		k3.cap = h->cap;
+		k3.nbch = h->C;
+		k3.J = J;
+		k3.ss = h->d_ss;
+		k3.cs = h->d_cs;
+		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
+	h->pending.push_back(pt);
+	h->total_in += nsamples;
+	h->pushes++;
+	return VDL2GPU_OK;
+}
+
+extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
+{
+	if (!h)
+		return VDL2GPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return harvest_timing(h);
+}
+
+static int fetch_records(vdl2gpu_t *h)
+{
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	unsigned cnt[2] = { 0, 0 };
+	HIPCHK(h, hipMemcpy(cnt, h->d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+	unsigned n = std::min(cnt[0], h->rec_cap);
+	h->overflowed += cnt[1];
+	if (n) {
+		const size_t old = h->ready.size();
+		h->ready.resize(old + n);
+		HIPCHK(h, hipMemcpy(h->ready.data() + old, h->d_recs, (size_t)n * sizeof(vdl2gpu_burst_t), hipMemcpyDeviceToHost));
+		for (size_t i = old; i < h->ready.size(); ++i) {
+			vdl2gpu_burst_t &b = h->ready[i];
+			b.trig_sample = dec_to_sample(b.trig_dec, (unsigned)h->sdrclk);
+			b.end_sample = dec_to_sample(b.end_dec, (unsigned)h->sdrclk);
+			/* d8psk.c:302, same mixed float/double expression */
+			b.ppm = (float)((double)(10500.0f * b.df) / (2.0 * M_PI * (double)b.Fr) * 1e6);
+		}
+		std::sort(h->ready.begin() + old, h->ready.end(), [](const vdl2gpu_burst_t &a, const vdl2gpu_burst_t &b) {
+			if (a.end_dec != b.end_dec)
+				return a.end_dec < b.end_dec;
+			if (a.stream != b.stream)
+				return a.stream < b.stream;
+			return a.chn < b.chn;
+		});
+	}
+	if (cnt[0] || cnt[1])
+		HIPCHK(h, hipMemset(h->d_cnt, 0, sizeof cnt));
+	return VDL2GPU_OK;
+}
+
+extern "C" int vdl2gpu_pending(vdl2gpu_t *h)
+{
+	if (!h)
+		return VDL2GPU_EINVAL;
+	int rc = fetch_records(h);
+	if (rc)
+		return rc;
+	return (int)h->ready.size();
+}
+
+extern "C" int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
+{
+	if (!h || (max > 0 && !out) || max < 0)
+		return VDL2GPU_EINVAL;
+	int rc = fetch_records(h);
+	if (rc)
+		return rc;
+	const int n = std::min<int>(max, (int)h->ready.size());
+	if (n) {
+		memcpy(out, h->ready.data(), (size_t)n * sizeof(vdl2gpu_burst_t));
+		h->ready.erase(h->ready.begin(), h->ready.begin() + n);
+	}
+	return n;
+}
+
+extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
+{
+	if (!h || !out)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	std::vector<ChanState> cs((size_t)h->S * VDL2_CS);
+	HIPCHK(h, hipMemcpy(cs.data(), h->d_cs, cs.size() * sizeof(ChanState), hipMemcpyDeviceToHost));
+	memset(out, 0, sizeof *out);
+	out->samples_in = h->total_in;
+	out->dec_samples = (uint64_t)(((unsigned __int128)h->total_in * 21u) / (unsigned)h->sdrclk);
+	for (int s = 0; s < h->S; ++s)
+		for (int c = 0; c < h->C; ++c) {
+			const ChanState &x = cs[(size_t)s * VDL2_CS + c];
+			out->sync_evals += x.n_eval;
+			out->triggers += x.n_trig;
+			out->header_rejects += x.n_reject;
+			out->bursts += x.n_burst;
+			out->deferrals += x.n_defer;
+		}
+	out->overflowed = h->overflowed;
+	return VDL2GPU_OK;
+}
+
+extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset)
+{
+	if (!h || !out)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	*out = h->tm;
+	if (reset)
+		h->tm = vdl2gpu_timing_t{};
+	return VDL2GPU_OK;
+}
+
+/* ----------------------------------------------------------------- diagnostics */
+extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t max_complex)
+{
+	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out || !h->pushes)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	StreamState ss;
+	HIPCHK(h, hipMemcpy(&ss, h->d_ss + stream, sizeof ss, hipMemcpyDeviceToHost));
+	const int par = (int)((h->pushes - 1) & 1);
+	const int64_t n = std::min<int64_t>(ss.last_J, max_complex);
+	if (n <= 0)
+		return 0;
+	std::vector<float2> frames((size_t)n * VDL2_CS);
+	HIPCHK(h, hipMemcpy(frames.data(), h->d_dec[par] + ((size_t)stream * h->cap + ss.last_fill) * VDL2_CS,
+			    frames.size() * sizeof(float2), hipMemcpyDeviceToHost));
+	for (int64_t i = 0; i < n; ++i) {
+		out[2 * i] = frames[(size_t)i * VDL2_CS + ch].x;
+		out[2 * i + 1] = frames[(size_t)i * VDL2_CS + ch].y;
+	}
+	return n;
+}
+
+extern "C" int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, int max_complex)
+{
+	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out || max_complex < h->L)
+		return VDL2GPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	HIPCHK(h, hipMemcpy(out, h->d_lo + ((size_t)stream * VDL2_CS + ch) * h->L, (size_t)h->L * sizeof(float2), hipMemcpyDeviceToHost));
+	return h->L;
+}
+
+extern "C" int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x, float *out, size_t n)
+{
+	if (!h || !y || !x || !out)
+		return VDL2GPU_EINVAL;
+	if (!n)
+		return VDL2GPU_OK;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	float *d = nullptr;
+	HIPCHK(h, hipMalloc(&d, 3 * n * sizeof(float)));
+	hipError_t e = hipMemcpy(d, y, n * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+		e = hipMemcpy(d + n, x, n * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_atan2f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, d + n, d + 2 * n, n);
+		e = hipStreamSynchronize(h->stream);
+	}
+	if (e == hipSuccess)
+		e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) {
+		h->err = hipGetErrorString(e);
+		return VDL2GPU_EHIP;
+	}
+	return VDL2GPU_OK;
+}

@@ -1,0 +1,209 @@
+"""Host-side mirror of the reference's receive interface, over the C ABI.
+
+The reference starts one ``rcv_thread(thread_param_t*)`` per channel (main.c:228-231)
+and each hands ``msgblk_t`` bursts to ``decodeVdlm2`` (d8psk.c:201).  ``Receiver`` keeps
+those names and meanings: it is configured with the same ``(chn, Fr, Fo)`` triples and
+``SDRINRATE``; ``push()`` plays the producer's Bar1/Bar2 hand-off of one sample block
+(rtl.c:283-294) for *all* channels; ``poll()`` yields ``Burst`` objects carrying exactly the
+``msgblk_t`` fields.  All DSP happens in libvdl2gpu.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as _lib
+
+STEPRATE = 25000           # vdlm2.h:33
+RTLINBUFSZ = 16 * 4096     # vdlm2.h:35 (bytes per RTL hand-off = 32768 complex samples)
+
+
+@dataclass(frozen=True)
+class ThreadParam:
+    """thread_param_t, vdlm2.h:49-52."""
+    chn: int
+    Fr: int
+    Fo: int
+
+
+@dataclass
+class Burst:
+    """The msgblk_t fields the DSP fills (vdlm2.h:39-47) plus stream-time stamps."""
+    stream: int
+    chn: int
+    Fr: int
+    nbrow: int
+    nlbyte: int
+    df: float
+    ppm: float
+    trig_dec: int
+    end_dec: int
+    trig_sample: int
+    end_sample: int
+    data: bytes            # 8 rows x 255 bytes, row-major
+
+    def key(self):
+        return (self.stream, self.chn, self.nbrow, self.nlbyte, self.data)
+
+
+def plan_channels(fc: int, offsets: Sequence[int]) -> List[ThreadParam]:
+    """thread_param_t list the way rtl.c:245-247 fills it: Fo = Fr - Fc."""
+    return [ThreadParam(chn=i, Fr=fc + fo, Fo=fo) for i, fo in enumerate(offsets)]
+
+
+class Receiver:
+    def __init__(self, sdrinrate: int, channels: Sequence[ThreadParam] | Sequence[Sequence[ThreadParam]],
+                 fmt: str = "cu8", max_push: int = 1 << 22, device: int = 0, sdrclk: int = 0,
+                 max_bursts: int = 0, keep_dec: bool = False):
+        self.L = _lib.load()
+        if channels and isinstance(channels[0], ThreadParam):
+            channels = [list(channels)]
+        self.nstreams = len(channels)
+        self.nbch = len(channels[0])
+        if any(len(c) != self.nbch for c in channels):
+            raise ValueError("every stream needs the same number of channels")
+        self.fmt = fmt
+        self.rate = sdrinrate
+        self.sample_bytes = _lib.SAMPLE_BYTES[fmt]
+        self._chan = (_lib.ChanT * (self.nstreams * self.nbch))()
+        for s, plan in enumerate(channels):
+            for c, tp in enumerate(plan):
+                self._chan[s * self.nbch + c] = _lib.ChanT(tp.chn, tp.Fr, tp.Fo)
+        cfg = _lib.ConfigT()
+        cfg.struct_size = C.sizeof(_lib.ConfigT)
+        cfg.sdrinrate = sdrinrate
+        cfg.sdrclk = sdrclk
+        cfg.fmt = _lib.FMT[fmt]
+        cfg.nbch = self.nbch
+        cfg.nstreams = self.nstreams
+        cfg.chan = self._chan
+        cfg.max_push = max_push
+        cfg.device = device
+        cfg.max_bursts = max_bursts
+        cfg.flags = _lib.F_KEEP_DEC if keep_dec else 0
+        self.max_push = max_push
+        self.h = C.c_void_p()
+        rc = self.L.vdl2gpu_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise _lib.Vdl2GpuError(f"vdl2gpu_create failed: {self.L.vdl2gpu_strerror(rc).decode()}")
+
+    # -------------------------------------------------------------------- data path
+    def _check(self, rc: int):
+        if rc < 0:
+            msg = self.L.vdl2gpu_last_error(self.h).decode()
+            raise _lib.Vdl2GpuError(f"{self.L.vdl2gpu_strerror(rc).decode()}: {msg}")
+        return rc
+
+    def push(self, raw: np.ndarray):
+        """One hand-off of host samples. ``raw``: 1-D (single stream) or [nstreams, n] raw array."""
+        a = np.ascontiguousarray(raw)
+        if a.ndim == 1:
+            a = a[None, :]
+        if a.shape[0] != self.nstreams:
+            raise ValueError("first dimension must be nstreams")
+        nbytes = a.shape[1] * a.itemsize
+        n = nbytes // self.sample_bytes
+        self._check(self.L.vdl2gpu_push(self.h, a.ctypes.data_as(C.c_void_p), n, nbytes, _lib.MEM_HOST))
+        return n
+
+    def push_device(self, ptr: int, nsamples: int, stream_stride_bytes: int = 0):
+        """Samples already resident in HBM (e.g. ``tensor.data_ptr()``)."""
+        self._check(self.L.vdl2gpu_push(self.h, C.c_void_p(ptr), nsamples, stream_stride_bytes, _lib.MEM_DEVICE))
+
+    def sync(self):
+        self._check(self.L.vdl2gpu_sync(self.h))
+
+    def poll(self, max_bursts: int = 4096) -> List[Burst]:
+        out: List[Burst] = []
+        buf = (_lib.BurstT * max_bursts)()
+        while True:
+            n = self._check(self.L.vdl2gpu_poll(self.h, buf, max_bursts))
+            for i in range(n):
+                b = buf[i]
+                out.append(Burst(b.stream, b.chn, b.Fr, b.nbrow, b.nlbyte, b.df, b.ppm, b.trig_dec, b.end_dec,
+                                 b.trig_sample, b.end_sample, bytes(b.data)))
+            if n < max_bursts:
+                return out
+
+    def run(self, raw: np.ndarray, block: Optional[int] = None) -> List[Burst]:
+        """Feed a whole recording in ``block``-sample hand-offs and return every burst."""
+        a = np.ascontiguousarray(raw)
+        if a.ndim == 1:
+            a = a[None, :]
+        per = self.sample_bytes // a.itemsize
+        n = a.shape[1] // per
+        block = block or self.max_push
+        out: List[Burst] = []
+        for s in range(0, n, block):
+            e = min(n, s + block)
+            self.push(a[:, s * per:e * per])
+            out += self.poll()
+        return out
+
+    # ------------------------------------------------------------------ bookkeeping
+    def stats(self) -> dict:
+        st = _lib.StatsT()
+        self._check(self.L.vdl2gpu_get_stats(self.h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in _lib.StatsT._fields_}
+
+    def timing(self, reset: bool = False) -> dict:
+        t = _lib.TimingT()
+        self._check(self.L.vdl2gpu_get_timing(self.h, C.byref(t), int(reset)))
+        return {n: getattr(t, n) for n, _ in _lib.TimingT._fields_}
+
+    # ------------------------------------------------------------------ diagnostics
+    def debug_dec(self, stream: int, ch: int, max_complex: int = 1 << 24) -> np.ndarray:
+        buf = np.empty(2 * max_complex, np.float32)
+        n = self.L.vdl2gpu_debug_dec(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_complex)
+        self._check(int(n))
+        return buf[:2 * n].view(np.complex64).copy()
+
+    def debug_atan2f(self, y: np.ndarray, x: np.ndarray) -> np.ndarray:
+        y = np.ascontiguousarray(y, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(y)
+        self._check(self.L.vdl2gpu_debug_atan2f(self.h, y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                                                out.ctypes.data_as(C.c_void_p), y.size))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vdl2gpu_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def lo_table(sdrinrate: int, fo: int) -> np.ndarray:
+    """Host LO table exactly as the library uploads it (d8psk.c:353-357)."""
+    L = _lib.load()
+    n = sdrinrate // STEPRATE
+    buf = np.empty(2 * n, np.float32)
+    rc = L.vdl2gpu_lo_table(sdrinrate, fo, buf.ctypes.data_as(C.c_void_p), n)
+    if rc < 0:
+        raise _lib.Vdl2GpuError("vdl2gpu_lo_table failed")
+    return buf.view(np.complex64).copy()
+
+
+def plan(total_in: int, n: int, sdrclk: int, lo_len: int) -> Tuple[int, int, int, int]:
+    """(c0, no0, nf0, nout): decimation schedule of one push (d8psk.c:374-381 closed form)."""
+    L = _lib.load()
+    c0, no0, nf0, nout = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    rc = L.vdl2gpu_plan(total_in, n, sdrclk, lo_len, C.byref(c0), C.byref(no0), C.byref(nf0), C.byref(nout))
+    if rc < 0:
+        raise _lib.Vdl2GpuError("vdl2gpu_plan failed")
+    return c0.value, no0.value, nf0.value, nout.value

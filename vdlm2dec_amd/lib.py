@@ -1,0 +1,111 @@
+"""ctypes binding of libvdl2gpu.so (the C ABI in include/vdl2gpu.h).
+
+The library is the product; this module only loads it.  There is no Python or
+CPU fallback: if the shared object is missing, or no HIP device is present when a
+handle is created, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdl2gpu.so")
+
+FMT = {"cu8": 0, "cs16": 1, "cf32": 2, "f32": 3}
+SAMPLE_BYTES = {"cu8": 2, "cs16": 4, "cf32": 8, "f32": 4}
+MEM_HOST, MEM_DEVICE = 0, 1
+F_KEEP_DEC = 1
+
+# every symbol include/vdl2gpu.h declares
+EXPORTS = (
+    "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
+    "vdl2gpu_poll", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
+    "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
+    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f",
+)
+
+
+class ChanT(C.Structure):
+    _fields_ = [("chn", C.c_int32), ("Fr", C.c_int32), ("Fo", C.c_int32)]
+
+
+class ConfigT(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("sdrinrate", C.c_uint32), ("sdrclk", C.c_uint32),
+                ("fmt", C.c_int32), ("nbch", C.c_int32), ("nstreams", C.c_int32),
+                ("chan", C.POINTER(ChanT)), ("max_push", C.c_uint64), ("device", C.c_int32),
+                ("max_bursts", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class BurstT(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("chn", C.c_int32), ("Fr", C.c_int32), ("nbrow", C.c_int32),
+                ("nlbyte", C.c_int32), ("df", C.c_float), ("ppm", C.c_float),
+                ("trig_dec", C.c_int64), ("end_dec", C.c_int64), ("trig_sample", C.c_int64),
+                ("end_sample", C.c_int64), ("data", (C.c_uint8 * 255) * 8)]
+
+
+class StatsT(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples_in", "dec_samples", "sync_evals", "triggers",
+                                          "header_rejects", "bursts", "deferrals", "overflowed")]
+
+
+class TimingT(C.Structure):
+    _fields_ = [("channelise_ms", C.c_double), ("demod_ms", C.c_double), ("other_ms", C.c_double),
+                ("pushes", C.c_uint64), ("samples", C.c_uint64)]
+
+
+class Vdl2GpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libvdl2gpu.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Vdl2GpuError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.vdl2gpu_abi_version.restype = C.c_int
+    L.vdl2gpu_create.restype = C.c_int
+    L.vdl2gpu_create.argtypes = [C.POINTER(ConfigT), C.POINTER(C.c_void_p)]
+    L.vdl2gpu_destroy.restype = None
+    L.vdl2gpu_destroy.argtypes = [C.c_void_p]
+    L.vdl2gpu_push.restype = C.c_int
+    L.vdl2gpu_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+    L.vdl2gpu_sync.restype = C.c_int
+    L.vdl2gpu_sync.argtypes = [C.c_void_p]
+    L.vdl2gpu_poll.restype = C.c_int
+    L.vdl2gpu_poll.argtypes = [C.c_void_p, C.POINTER(BurstT), C.c_int]
+    L.vdl2gpu_pending.restype = C.c_int
+    L.vdl2gpu_pending.argtypes = [C.c_void_p]
+    L.vdl2gpu_get_stats.restype = C.c_int
+    L.vdl2gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(StatsT)]
+    L.vdl2gpu_get_timing.restype = C.c_int
+    L.vdl2gpu_get_timing.argtypes = [C.c_void_p, C.POINTER(TimingT), C.c_int]
+    L.vdl2gpu_last_error.restype = C.c_char_p
+    L.vdl2gpu_last_error.argtypes = [C.c_void_p]
+    L.vdl2gpu_strerror.restype = C.c_char_p
+    L.vdl2gpu_strerror.argtypes = [C.c_int]
+    L.vdl2gpu_burst_to_msgblk.restype = C.c_int
+    L.vdl2gpu_burst_to_msgblk.argtypes = [C.POINTER(BurstT), C.c_void_p, C.c_size_t]
+    L.reversebits.restype = C.c_uint
+    L.reversebits.argtypes = [C.c_uint, C.c_int]
+    L.vdl2gpu_lo_table.restype = C.c_int
+    L.vdl2gpu_lo_table.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_int]
+    L.vdl2gpu_plan.restype = C.c_int
+    L.vdl2gpu_plan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.POINTER(C.c_int),
+                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.vdl2gpu_debug_dec.restype = C.c_int64
+    L.vdl2gpu_debug_dec.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    L.vdl2gpu_debug_lo.restype = C.c_int
+    L.vdl2gpu_debug_lo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.vdl2gpu_debug_atan2f.restype = C.c_int
+    L.vdl2gpu_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    _lib = L
+    return L
