@@ -1,0 +1,96 @@
+"""The C-ABI shared library: loads, exports everything include/vdl2gpu.h declares, host-only helpers
+agree with the oracle, and it refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol(built):
+    from vdlm2dec_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "vdl2gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vdl2gpu_[a-z0-9_]+|reversebits)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared == set(lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.vdl2gpu_abi_version() == 1
+
+
+def test_struct_layouts_match_header(built):
+    from vdlm2dec_amd import lib
+    assert C.sizeof(lib.BurstT) == 64 + 8 * 255          # data at offset 64, see vdl2gpu_kernels.h
+    assert lib.BurstT.data.offset == 64
+    assert C.sizeof(lib.ChanT) == 12                      # == thread_param_t, vdlm2.h:49-52
+    assert C.sizeof(lib.ConfigT) == 56
+
+
+def test_reversebits_exported_for_host_path(built, oracle):
+    from vdlm2dec_amd import lib
+    L, O = lib.load(), oracle.lib()
+    for v, n in ((0x2A, 6), (0x55, 7), (0x12345, 17), (1, 1)):
+        assert L.reversebits(v, n) == O.vo_reversebits(v, n)
+
+
+def test_burst_to_msgblk_layout(built):
+    """msgblk_t on LP64 (vdlm2.h:39-47): chn@8 Fr@12 ppm@32 nbrow@36 nlbyte@40 data@44, 16624 bytes."""
+    from vdlm2dec_amd import lib
+    L = lib.load()
+    b = lib.BurstT()
+    b.chn, b.Fr, b.nbrow, b.nlbyte, b.ppm = 3, 136975000, 2, 17, -4.75
+    for r in range(8):
+        for i in range(255):
+            b.data[r][i] = (r * 255 + i) & 0xFF
+    blk = (C.c_uint8 * 16624)()
+    assert L.vdl2gpu_burst_to_msgblk(C.byref(b), blk, 16624) == 0
+    raw = bytes(blk)
+    assert np.frombuffer(raw[8:16], "<i4").tolist() == [3, 136975000]
+    assert np.frombuffer(raw[32:36], "<f4")[0] == np.float32(-4.75)
+    assert np.frombuffer(raw[36:44], "<i4").tolist() == [2, 17]
+    assert raw[44:44 + 8 * 255] == bytes(b.data)
+    assert raw[:8] == b"\0" * 8 and raw[16:32] == b"\0" * 16 and set(raw[44 + 2040:]) == {0}
+    assert L.vdl2gpu_burst_to_msgblk(C.byref(b), blk, 100) == -1
+
+
+@pytest.mark.parametrize("rate", [2_000_000, 5_000_000, 6_000_000, 10_000_000])
+def test_lo_table_equals_reference_formula(built, oracle, rate):
+    """Host LO table (sincosf) == the oracle's cexpf table (d8psk.c:353-357), bit for bit."""
+    from vdlm2dec_amd.demod import lo_table
+    rng = np.random.default_rng(rate)
+    fos = [-450000, -50000, 100000, 25000, 975000, -123457, 1] + [int(v) for v in rng.integers(-rate // 2, rate // 2, 40)]
+    for fo in fos:
+        ch = oracle.OracleChannel(rate, fo, 136_000_000 + fo)
+        assert np.array_equal(ch.lo_table().view(np.uint32), lo_table(rate, fo).view(np.uint32)), fo
+        ch.close()
+
+
+def test_create_rejects_bad_config_and_missing_gpu(built):
+    import torch
+    from vdlm2dec_amd import lib
+    from vdlm2dec_amd.demod import Receiver, ThreadParam
+    L = lib.load()
+    assert L.vdl2gpu_create(None, None) == -1
+    with pytest.raises(lib.Vdl2GpuError):
+        Receiver(2_000_000, [ThreadParam(0, 1, 1)], fmt="cu8", max_push=0)
+    with pytest.raises(lib.Vdl2GpuError):
+        Receiver(2_000_001, [ThreadParam(0, 1, 1)], fmt="cu8")
+    if not torch.cuda.is_available():
+        # the product must fail loudly, never fall back to a CPU path
+        with pytest.raises(lib.Vdl2GpuError, match="no HIP device"):
+            Receiver(2_000_000, [ThreadParam(0, 136975000, -50000)], fmt="cu8")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vdlm2dec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("oracle's", "") or f in ("vdl2_math.h",), \
+                    f"{f} mentions the oracle"

@@ -1,0 +1,115 @@
+"""Pin the oracle: the CPU restatement against the real reference built from its own sources
+(oracle/_ref, only where /root/reference exists).  Skipped on the GPU box; tests/test_golden.py
+carries the same evidence there as committed vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios as S
+from vdlm2dec_amd import synth
+
+
+def _compare(O, spec, fmt, tmp_path, quirk=0):
+    raw = synth.synth_stream(spec, fmt)
+    p = str(tmp_path / "iq.raw")
+    raw.tofile(p)
+    total_blocks = 0
+    for c, fo in enumerate(spec.fo):
+        rb, rf, taps = O.run_ref(p, fmt, spec.rate, fo, S.FC + fo, str(tmp_path / "o.txt"), quirk, str(tmp_path / "t.bin"))
+        ch = O.OracleChannel(spec.rate, fo, S.FC + fo, chn=c, tap_phase=True)
+        ch.feed(raw, fmt + ("_quirk" if quirk else ""))
+        ob = ch.blocks()
+        assert len(ob) == len(rb)
+        fr = []
+        for a, b in zip(rb, ob):
+            assert (a["nbrow"], a["nlbyte"], a["data"]) == (b.nbrow, b.nlbyte, b.data)
+            assert a["df_bits"] == int(np.float32(b.df).view(np.uint32))
+            fr += O.frames_of_block(b.nbrow, b.nlbyte, b.data)
+        assert [f["frame"] for f in rf] == fr
+        at = taps[taps["t"] == 1]
+        assert np.array_equal(at["c"].view(np.uint32), ch.phases().view(np.uint32))
+        # header soft bits handed to viterbi_add, in order
+        total_blocks += len(ob)
+        # trigger timing decisions: every roundf() argument at a trigger equals `of`
+        rr = taps[taps["t"] == 2]
+        tr = ch.triggers()
+        ofs = {np.float32(t["of"]).view(np.uint32).item() for t in tr}
+        assert ofs <= set(rr["a"].view(np.uint32).tolist())
+        ch.close()
+    return total_blocks
+
+
+@pytest.fixture
+def O(oracle, have_ref):
+    if not have_ref:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    return oracle
+
+
+def test_regimes_cu8(O, tmp_path):
+    assert _compare(O, S.regimes(seed=101), "cu8", tmp_path) >= 12
+
+
+def test_regimes_cu8_quirk(O, tmp_path):
+    assert _compare(O, S.regimes(seed=102, infos=(5, 40, 70, 250)), "cu8", tmp_path, quirk=1) >= 3
+
+
+def test_eight_channels_cs16(O, tmp_path):
+    assert _compare(O, S.eight_channels(seed=103), "cs16", tmp_path) >= 12
+
+
+def test_back_to_back_stale_ring(O, tmp_path):
+    assert _compare(O, S.back_to_back(), "cu8", tmp_path) >= 3
+
+
+def test_odd_headers(O, tmp_path):
+    _compare(O, S.odd_headers(), "cs16", tmp_path)
+
+
+def test_corrupted_rows_frames(O, tmp_path):
+    assert _compare(O, S.corrupted(), "cu8", tmp_path) == 5
+
+
+def test_ten_ms_cs16(O, tmp_path):
+    assert _compare(O, S.single_short(10_000_000, 2_400_000, seed=104, info_len=33, blocks=6), "cs16", tmp_path) == 1
+
+
+def test_airspy_real_f32(O, tmp_path):
+    assert _compare(O, S.single_short(6_000_000, 1_200_000, seed=105, info_len=14, blocks=5), "f32", tmp_path) == 1
+
+
+def test_weak_noisy(O, tmp_path):
+    # low SNR: sync decisions near threshold, header Viterbi actually corrects, false triggers possible
+    spec = S.regimes(seed=106, infos=(20, 50, 90, 30, 10, 77), noise=6.0)
+    _compare(O, spec, "cu8", tmp_path)
+
+
+def test_rs_decoder_against_reference_rs(O):
+    """vo_rs_decode vs the reference's rs() (rs.c:81) compiled as oracle/_ref/librefrs.so,
+    on random codewords with errors + erasures, correctable and not."""
+    import ctypes as C
+    ref = C.CDLL(os.path.join(O.REF_DIR, "librefrs.so"))
+    ref.rs.restype = C.c_int
+    ref.rs.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L = O.lib()
+    rng = np.random.default_rng(7)
+    for it in range(4000):
+        row = rng.integers(0, 256, 249, dtype=np.uint8)
+        cw = np.concatenate([row, np.array(synth.rs_parity(row.tolist()), dtype=np.uint8)])
+        nera = int(rng.choice([0, 0, 2, 4]))
+        eras = [253, 254] if nera == 2 else ([251, 252, 253, 254] if nera == 4 else [])
+        for e in eras:
+            cw[e] = 0
+        nerr = int(rng.integers(0, 6))
+        for pos in rng.choice(251, size=nerr, replace=False):
+            cw[pos] ^= int(rng.integers(1, 256))
+        a, b = cw.copy(), cw.copy()
+        ea = (C.c_int * 6)(*(eras + [0] * (6 - len(eras))))
+        eb = (C.c_int * 6)(*(eras + [0] * (6 - len(eras))))
+        ra = ref.rs(a.ctypes.data_as(C.c_void_p), ea, nera)
+        rb = L.vo_rs_decode(b.ctypes.data_as(C.c_void_p), eb, nera)
+        assert ra == rb, (it, nerr, nera)
+        assert np.array_equal(a, b), (it, nerr, nera)
+        if ra > 0:
+            assert list(ea)[:ra] == list(eb)[:rb]

@@ -70,6 +70,14 @@ def load():
         raise Vdl2GpuError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    if not os.environ.get("VDL2GPU_NO_TORCH"):
+        # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HSA runtimes in
+        # one process cannot both own the GPU.  Importing torch first makes its runtime the one this
+        # library binds to (same SONAME), so tensors' device pointers can be pushed directly.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     L.vdl2gpu_abi_version.restype = C.c_int
     L.vdl2gpu_create.restype = C.c_int
