@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the IQ->bursts hot path on MI355X (BASELINE.json metric).
+
+Workload (configs[1] of BASELINE.json): one wideband stream, 8 VDL2 channels on the 25 kHz
+grid, SDRINRATE 2 MS/s, cs16 interleaved IQ, synthetic D8PSK bursts (Poisson arrivals per
+channel, 8..60 LSB amplitude, +-400 Hz carrier offset, AWGN) from vdlm2dec_amd.synth.
+A "step" is one vdl2gpu_push() of `--batch` samples (default 16 x 4.2 MS = 67.2 MS = 33.6 s
+of air time) that is already resident in HBM, plus vdl2gpu_poll() of the decoded bursts.
+`value` = input samples consumed per second with all 8 channels demodulated, whole job.
+
+N > 1 (weak scaling): the path shards by independent wideband stream, so every
+rank decodes its own stream of the same size; there is no data-path collective.  RCCL is used
+only for the timing barrier / max-reduce and a gather of per-rank burst counts.
+
+Extra objects on the JSON line:
+  roofline      channeliser kernel (the only kernel that touches the full-rate stream):
+                algorithmic bytes = 4 B per cs16 sample, read once for all 8 channels
+                (SURVEY.md 8d), divided by its mean launch time from HIP events recorded on
+                the library's stream (vdl2gpu_get_timing).
+  kernels_ms    mean per-step device time of each kernel, same events.
+  cpu_baseline  the oracle (CPU restatement, verified bit-equal to the reference) timed on
+                this host on a bounded sample of the same recording, one thread per channel.
+  parity        GPU bursts of the first tile compared with the oracle's, msgblk_t level.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+RATE = 2_000_000
+FC = 136_975_000
+TILE = 4_200_000          # samples per generated tile (multiple of the 2000-sample LO/decimator period)
+HBM_PEAK_GBS = 8000.0     # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_tile(seed: int, fmt: str):
+    from vdlm2dec_amd import synth
+    spec = synth.random_scenario(RATE, synth.DEFAULT_FO_8CH, TILE, seed=seed, bursts_per_s=4.0, info_max=240)
+    return spec, synth.synth_stream(spec, fmt)
+
+
+def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0):
+    """Oracle ("port" of the reference path) on host cores: one thread per channel, like the
+    reference's one rcv_thread per channel (main.c:228-231)."""
+    from oracle import oracle as O
+    O.lib()
+    per = O.PER_SAMPLE[fmt]
+    n_total = raw.size // per
+    # size the sample so the run takes roughly budget_s: probe one channel on 1 MS first
+    probe = min(n_total, 1_000_000)
+    ch = O.OracleChannel(RATE, fos[0], FC + fos[0])
+    t0 = time.perf_counter()
+    ch.feed(raw[:probe * per], fmt)
+    one = (time.perf_counter() - t0) / probe
+    ch.close()
+    ncores = os.cpu_count() or 1
+    nthreads = min(len(fos), ncores)
+    passes = int(np.ceil(len(fos) / nthreads))
+    # the recording is one tile; feed it repeatedly (the stream simply continues) until ~budget_s
+    reps = max(1, int(budget_s / (one * n_total * passes)))
+    n = n_total * reps
+    chans = [O.OracleChannel(RATE, fo, FC + fo, chn=i) for i, fo in enumerate(fos)]
+
+    def work(idx):
+        for c in range(idx, len(chans), nthreads):
+            for _ in range(reps):
+                chans[c].feed(raw, fmt)       # ctypes releases the GIL
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    nb = sum(len(c.blocks()) for c in chans)
+    for c in chans:
+        c.close()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n / dt / 1e6, "unit": "MS/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} samples ({reps} x the 4.2 MS tile of the same recording), 8 channels, {nthreads} threads "
+                      f"(1 thread/channel), {dt:.1f} s wall, {nb} bursts; single-thread single-channel "
+                      f"{1.0 / one / 1e6:.1f} MS/s; host CPU: {model} x{ncores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tiles", type=int, default=16, help="tiles of 4.2 MS per step (batch = tiles*4.2 MS)")
+    ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vdlm2dec_amd import synth
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local)
+
+    fos = synth.DEFAULT_FO_8CH
+    spec, tile = make_tile(seed=1234 + rank, fmt=args.fmt)
+    batch = args.tiles * TILE
+    dtile = torch.from_numpy(tile).to(dev)
+    dbatch = dtile.repeat(args.tiles).contiguous()          # [batch * 2] raw values, resident in HBM
+    del dtile
+    sample_bytes = 4 if args.fmt == "cs16" else 2
+
+    rx = Receiver(RATE, plan_channels(FC, fos), fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18)
+    first = []
+    nbursts = 0
+
+    def step(collect=None):
+        nonlocal nbursts
+        rx.push_device(dbatch.data_ptr(), batch)
+        b = rx.poll(8192)
+        nbursts += len(b)
+        if collect is not None:
+            collect += b
+
+    for i in range(args.warmup):
+        step(first if i == 0 else None)
+    if args.warmup == 0:
+        pass
+    rx.timing(reset=True)
+    nbursts = 0
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(first if (args.warmup == 0 and i == 0) else None)
+    rx.sync()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = rx.timing()
+    st = rx.stats()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([nbursts], device=dev, dtype=torch.int64)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        total_bursts = int(sum(int(c.item()) for c in allc))
+    else:
+        total_bursts = nbursts
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        from oracle import oracle as O     # checker only
+        want = sorted(b.key() for b in O.run_oracle(tile, args.fmt, RATE, fos, FC))
+        got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in first if b.end_sample < TILE)
+        # oracle bursts still open at the tile end have no counterpart; both lists hold completed ones
+        parity = {"level": "msgblk_t (pre-RS) bit-exact, first tile", "oracle_bursts": len(want),
+                  "gpu_bursts": len(got), "equal": want == got}
+
+    if rank == 0:
+        k1_ms = tm["channelise_ms"] / max(1, tm["pushes"])
+        k2_ms = tm["demod_ms"] / max(1, tm["pushes"])
+        k3_ms = tm["other_ms"] / max(1, tm["pushes"])
+        alg_bytes = float(batch) * sample_bytes
+        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        value = world * batch * args.steps / dt / 1e6
+        out = {
+            "metric": "IQ MS/s demodulated (8 ch, 2 MS/s cs16) + CRC-pass frame parity vs ref",
+            "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 8 channels @ 2 MS/s on 1xMI355X, synthetic D8PSK bursts",
+                       "fmt": args.fmt, "samples_per_step": batch, "air_time_s_per_step": batch / RATE,
+                       "channels": 8, "streams_per_gpu": 1, "bursts_per_step": total_bursts / max(1, args.steps * world),
+                       "x_real_time": value * 1e6 / RATE, "parallelism": f"stream-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k1_channelise", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
+            "kernels_ms": {"k1_channelise": k1_ms, "k2_demod": k2_ms, "k3_compact": k3_ms},
+            "whole_path_GBps": alg_bytes / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9,
+            "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals", "overflowed")},
+            "parity": parity,
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos)
+        print(json.dumps(out))
+    rx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
