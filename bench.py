@@ -190,6 +190,9 @@ def main():
     if rank == 0:
         k1_ms = tm["channelise_ms"] / max(1, tm["pushes"])
         k2_ms = tm["demod_ms"] / max(1, tm["pushes"])
+        k2a_ms = tm["scan_ms"] / max(1, tm["pushes"])
+        k2b_ms = tm["cluster_ms"] / max(1, tm["pushes"])
+        k2c_ms = tm["resolve_ms"] / max(1, tm["pushes"])
         k3_ms = tm["other_ms"] / max(1, tm["pushes"])
         alg_bytes = float(batch) * sample_bytes
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
@@ -206,10 +209,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_channelise", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
-            "kernels_ms": {"k1_channelise": k1_ms, "k2_demod": k2_ms, "k3_compact": k3_ms},
+            "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
+                           "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms},
             "whole_path_GBps": alg_bytes / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9,
-            "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals", "overflowed")},
+            "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
+                                           "candidates", "serial_samples", "overflowed")},
             "parity": parity,
+            "dbg": rx.debug_counters(),
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos)

@@ -86,6 +86,7 @@ typedef struct {
 } vdl2gpu_config_t;
 
 #define VDL2GPU_F_KEEP_DEC 1u	/* keep each push's decimated stream for vdl2gpu_debug_dec() */
+#define VDL2GPU_F_SERIAL 2u	/* diagnostics: skip the parallel sync tables, one serial machine per channel */
 
 /* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */
 typedef struct {
@@ -111,12 +112,17 @@ typedef struct {
 	uint64_t header_rejects;	/* d8psk.c:97-107 */
 	uint64_t bursts;	/* records handed out */
 	uint64_t deferrals;	/* bursts that waited for a later push to complete */
+	uint64_t candidates;	/* sync-trigger candidates found by the parallel scan (all timing hypotheses) */
+	uint64_t serial_samples;	/* 84 kS/s samples handled by the serial machine (history-dependent stretches) */
 	uint64_t overflowed;	/* records dropped because the ring was full */
 } vdl2gpu_stats_t;
 
 typedef struct {
 	double channelise_ms;	/* sum over pushes of the channeliser kernel, HIP events */
-	double demod_ms;	/* sum of the demodulator kernel(s) */
+	double demod_ms;	/* sum of the demodulator kernels (scan + cluster + resolve) */
+	double scan_ms;		/* K2a sync scan */
+	double cluster_ms;	/* K2b burst clusters */
+	double resolve_ms;	/* K2c resolver + K2d gather */
 	double other_ms;	/* compaction / bookkeeping kernels */
 	uint64_t pushes;
 	uint64_t samples;	/* input samples per stream covered by the sums */
@@ -169,6 +175,8 @@ int vdl2gpu_plan(uint64_t total_in, uint64_t n, unsigned sdrclk, unsigned lo_len
 int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t max_complex);
 /* Local-oscillator table of (stream, channel index): len complex values. */
 int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, int max_complex);
+/* Development cycle counters of the demodulator kernels (meaning is internal). */
+int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int n, int reset);
 /* Device build of the fixed-sequence atan2f, elementwise (host arrays). */
 int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x, float *out, size_t n);
 

@@ -33,8 +33,9 @@ extern "C" void sincosf(float, float *, float *);
 		}                                                                               \
 	} while (0)
 
+#define NEV 6
 struct PushTiming {
-	hipEvent_t e[4];	/* before K1, after K1, after K2, after K3 */
+	hipEvent_t e[NEV];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
 };
 
@@ -54,8 +55,16 @@ struct vdl2gpu {
 	ChanCfg *d_cfg = nullptr;
 	uint8_t *d_pn = nullptr;
 	vdl2gpu_burst_t *d_recs = nullptr;
-	unsigned *d_cnt = nullptr;	/* [0] = record count, [1] = overflow count */
+	unsigned *d_ctl = nullptr;	/* control words, see CTL_* in vdl2gpu_kernels.h */
+	size_t ctl_words = 0;
 	unsigned rec_cap = 0;
+	Cand *d_cands = nullptr;
+	Cluster *d_clusters = nullptr;
+	BurstDesc *d_stage = nullptr;
+	uint8_t *d_stage_sel = nullptr;
+	unsigned stage_cap = 0;
+	int force_serial = 0;
+	unsigned long long *d_dbg = nullptr;
 	uint64_t total_in = 0;		/* samples per stream pushed so far */
 	uint64_t pushes = 0;
 	uint64_t overflowed = 0;
@@ -194,7 +203,12 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_cfg);
 	(void)hipFree(h->d_pn);
 	(void)hipFree(h->d_recs);
-	(void)hipFree(h->d_cnt);
+	(void)hipFree(h->d_ctl);
+	(void)hipFree(h->d_cands);
+	(void)hipFree(h->d_clusters);
+	(void)hipFree(h->d_stage);
+	(void)hipFree(h->d_stage_sel);
+	(void)hipFree(h->d_dbg);
 	if (h->stream)
 		(void)hipStreamDestroy(h->stream);
 	delete h;
@@ -223,8 +237,18 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
 	HIPCHK(h, hipMalloc(&h->d_pn, VDL2_PN_BITS));
 	HIPCHK(h, hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
-	HIPCHK(h, hipMalloc(&h->d_cnt, 2 * sizeof(unsigned)));
-	HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 2 * sizeof(unsigned), h->stream));
+	h->ctl_words = CTL_CAND0 + 2 * (size_t)S * VDL2_CS;
+	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
+	HIPCHK(h, hipMalloc(&h->d_clusters, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
+	h->stage_cap = 131072u * (unsigned)S;
+	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
+	HIPCHK(h, hipMalloc(&h->d_stage_sel, h->stage_cap));
+	HIPCHK(h, hipMemsetAsync(h->d_stage_sel, 0, h->stage_cap, h->stream));
+	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
+	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
+	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
 
 	std::vector<float2> lo((size_t)S * VDL2_CS * L, make_float2(0.f, 0.f));
 	std::vector<ChanCfg> cc((size_t)S * VDL2_CS, ChanCfg{ 0, 0, 0, 0 });
@@ -263,6 +287,7 @@ static int create_impl(vdl2gpu_t *h)
 	for (auto &x : cs) {
 		x.pos = 1;	/* clk: 0 -> 4 (sample 0, idle) -> 8 (sample 1, evaluate) */
 		x.r = 0;
+		x.fresh = 0;	/* the all-zero start ring counts as history */
 		x.perr = 100.0f;
 	}
 	HIPCHK(h, hipMemcpyAsync(h->d_ss, ss.data(), ss.size() * sizeof(StreamState), hipMemcpyHostToDevice, h->stream));
@@ -322,13 +347,15 @@ static int get_events(vdl2gpu_t *h, PushTiming &pt)
 static int harvest_timing(vdl2gpu_t *h)
 {
 	for (auto &pt : h->pending) {
-		float a = 0, b = 0, c = 0;
-		HIPCHK(h, hipEventElapsedTime(&a, pt.e[0], pt.e[1]));
-		HIPCHK(h, hipEventElapsedTime(&b, pt.e[1], pt.e[2]));
-		HIPCHK(h, hipEventElapsedTime(&c, pt.e[2], pt.e[3]));
-		h->tm.channelise_ms += a;
-		h->tm.demod_ms += b;
-		h->tm.other_ms += c;
+		float d[NEV - 1];
+		for (int i = 0; i + 1 < NEV; ++i)
+			HIPCHK(h, hipEventElapsedTime(&d[i], pt.e[i], pt.e[i + 1]));
+		h->tm.channelise_ms += d[0];
+		h->tm.scan_ms += d[1];
+		h->tm.cluster_ms += d[2];
+		h->tm.resolve_ms += d[3];
+		h->tm.demod_ms += d[1] + d[2] + d[3];
+		h->tm.other_ms += d[4];
 		h->tm.pushes++;
 		h->tm.samples += pt.samples;
 		h->free_ev.push_back(pt);
@@ -405,6 +432,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	if (rc)
 		return rc;
 	pt.samples = nsamples;
+	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
@@ -425,19 +453,35 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.dec = h->d_dec[par];
 		k2.cap = h->cap;
 		k2.nbch = h->C;
+		k2.nstreams = h->S;
 		k2.J = J;
 		k2.ss = h->d_ss;
 		k2.cs = h->d_cs;
 		k2.cfg = h->d_cfg;
 		k2.pn = h->d_pn;
+		k2.cands = h->d_cands;
+		k2.clusters = h->d_clusters;
+		k2.ctl = h->d_ctl;
+		k2.stage = h->d_stage;
+		k2.stage_sel = h->d_stage_sel;
+		k2.stage_cap = h->stage_cap;
 		k2.recs = h->d_recs;
-		k2.rec_count = h->d_cnt;
 		k2.rec_cap = h->rec_cap;
-		k2.overflow = h->d_cnt + 1;
-		hipLaunchKernelGGL(k2_demod, dim3((unsigned)h->C, (unsigned)h->S), dim3(K2_THREADS), 0, h->stream, k2);
+		k2.force_serial = h->force_serial;
+		k2.dbg = h->d_dbg;
+		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
+		hipLaunchKernelGGL(k2a_scan, dim3(tiles, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
+		hipLaunchKernelGGL(k2b_clusters, dim3(2048), dim3(K2B_NT), 0, h->stream, k2);
+		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
+		hipLaunchKernelGGL(k2c_resolve, dim3((unsigned)h->C, (unsigned)h->S), dim3(K2_NT), 0, h->stream, k2);
+		HIPCHK(h, hipGetLastError());
+		hipLaunchKernelGGL(k2d_payload, dim3(2048), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
+	HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
 	{
 		K3Params k3{};
 		k3.src = h->d_dec[par];
@@ -447,10 +491,12 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k3.J = J;
 		k3.ss = h->d_ss;
 		k3.cs = h->d_cs;
-		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
+		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
+		HIPCHK(h, hipGetLastError());
+		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
+	HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
 	h->pending.push_back(pt);
 	h->total_in += nsamples;
 	h->pushes++;
@@ -472,7 +518,7 @@ static int fetch_records(vdl2gpu_t *h)
 	if (rc)
 		return rc;
 	unsigned cnt[2] = { 0, 0 };
-	HIPCHK(h, hipMemcpy(cnt, h->d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(cnt, h->d_ctl, sizeof cnt, hipMemcpyDeviceToHost));
 	unsigned n = std::min(cnt[0], h->rec_cap);
 	h->overflowed += cnt[1];
 	if (n) {
@@ -495,7 +541,7 @@ static int fetch_records(vdl2gpu_t *h)
 		});
 	}
 	if (cnt[0] || cnt[1])
-		HIPCHK(h, hipMemset(h->d_cnt, 0, sizeof cnt));
+		HIPCHK(h, hipMemset(h->d_ctl, 0, sizeof cnt));
 	return VDL2GPU_OK;
 }
 
@@ -544,6 +590,8 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 			out->header_rejects += x.n_reject;
 			out->bursts += x.n_burst;
 			out->deferrals += x.n_defer;
+			out->serial_samples += x.n_slow;
+			out->candidates += x.n_cand;
 		}
 	out->overflowed = h->overflowed;
 	return VDL2GPU_OK;
@@ -576,13 +624,8 @@ extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *ou
 	const int64_t n = std::min<int64_t>(ss.last_J, max_complex);
 	if (n <= 0)
 		return 0;
-	std::vector<float2> frames((size_t)n * VDL2_CS);
-	HIPCHK(h, hipMemcpy(frames.data(), h->d_dec[par] + ((size_t)stream * h->cap + ss.last_fill) * VDL2_CS,
-			    frames.size() * sizeof(float2), hipMemcpyDeviceToHost));
-	for (int64_t i = 0; i < n; ++i) {
-		out[2 * i] = frames[(size_t)i * VDL2_CS + ch].x;
-		out[2 * i + 1] = frames[(size_t)i * VDL2_CS + ch].y;
-	}
+	HIPCHK(h, hipMemcpy(out, h->d_dec[par] + ((size_t)stream * VDL2_CS + ch) * h->cap + ss.last_fill,
+			    (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
 	return n;
 }
 
@@ -619,5 +662,18 @@ extern "C" int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x
 		h->err = hipGetErrorString(e);
 		return VDL2GPU_EHIP;
 	}
+	return VDL2GPU_OK;
+}
+
+extern "C" int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int n, int reset)
+{
+	if (!h || !out || n < 0 || n > 64)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	HIPCHK(h, hipMemcpy(out, h->d_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	if (reset)
+		HIPCHK(h, hipMemset(h->d_dbg, 0, 64 * sizeof(unsigned long long)));
 	return VDL2GPU_OK;
 }

@@ -6,15 +6,37 @@
  *            real f32), one contiguous run per stream; read ONCE by K1.
  *   lo       per (stream, channel) local-oscillator table, L = SDRINRATE/25000
  *            complex floats, computed on the host with libm (d8psk.c:353-357).
- *   dec      channel-interleaved 84 kS/s frames: frame m = 8 x float2, channel
- *            fastest (64 B per frame), two ping-pong buffers per stream.  K1
- *            appends, K2 reads, K3 moves the unconsumed tail to the other
- *            buffer.  Frame 0 of a buffer is stream time `dec_base`.
+ *   dec      84 kS/s channel planes: plane (stream, channel) = `cap` float2,
+ *            two ping-pong sets.  K1 appends, K2* read, K3 moves the
+ *            unconsumed tail to the other set.  Frame 0 of a plane is stream
+ *            time `dec_base`; VDL2_HIST frames of history are always kept.
  *   state    StreamState (decimator carry) + ChanState (sync detector state:
  *            next evaluation instant, FIR sub-phase, last 68 phases, last two
  *            fit errors) -- the explicit, persistent form of the reference's
  *            stack-resident channel_t (vdlm2.h:56-79).
- *   bursts   ring of vdl2gpu_burst_t records + atomic counter.
+ *   cands    per channel: sync-trigger candidates of the free-running detector
+ *            under all 8 timing hypotheses (K2a) + what happens after each (K2b).
+ *   bursts   staging pool (K2b) and output ring (K2c/K2d) of vdl2gpu_burst_t.
+ *
+ * Pipeline of one push
+ *   K1  channelise     time-parallel over the whole GPU, the only full-rate kernel
+ *   K2a sync scan      time-parallel: fit error of EVERY (sample, sub-phase) pair
+ *   K2b burst clusters one workgroup per candidate: exact state machine from the
+ *                      trigger until the detector is history-free again
+ *   K2c resolve        one workgroup per VDL channel: walks the real chain of
+ *                      bursts through the tables (sequential but O(bursts))
+ *   K2d gather         copies the bursts on the real chain to the output ring
+ *   K3  compact
+ *
+ * Why the tables are exact: between bursts the reference detector evaluates
+ * every 2nd 84 kS/s sample with a sticky FIR sub-phase r = clk%4 and sample
+ * parity, both of which only change at a sync trigger (d8psk.c:248-250,
+ * 305, 317-319).  68 evaluations after a burst the phase ring Ph[] holds only
+ * new values and perr/p2err are the two previous errors, so the detector's
+ * decision at sample n is a pure function of (n, r): the "free-running" fit
+ * error E_r(n).  K2a computes E_r(n) for all n and r with the same float
+ * sequence the serial code uses; K2b/K2c replay the short history-dependent
+ * stretches (stale ring after a burst) with the serial machine.
  *
  * Arithmetic contract: every float/double operation below is written in the
  * order and width of the reference C expression it replaces and this file is
@@ -30,19 +52,22 @@
 #include "vdl2_math.h"
 #include "../../include/vdl2gpu.h"
 
-#define VDL2_CS 8		/* channel slots per decimated frame */
-#define VDL2_HIST 16		/* frames of history the 17-tap FIR needs */
+#define VDL2_CS 8		/* channel planes per stream */
+#define VDL2_HIST 160		/* frames of history kept: 17-tap FIR + 17 symbols x 8 + slack */
 #define VDL2_NPH 68		/* NBPH*D8DWN, vdlm2.h:54-55 */
+#define VDL2_STEADY 68		/* evaluations after which the detector forgot the last burst */
 #define VDL2_MAXSYM 5456	/* >= ceil((25 + 8*8*255)/3) symbols of the longest burst */
 #define VDL2_CARRY_FRAMES 49152	/* >= longest burst (43592 frames) + history + slack */
-#define VDL2_PN_BITS 16384 + 64
+#define VDL2_PN_BITS (16384 + 64)
+#define VDL2_CAND_CAP 4096	/* trigger candidates per channel per push */
+#define VDL2_CL_MAXB 4		/* bursts per cluster before the resolver takes over */
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
 
 struct StreamState {
-	long long dec_base;	/* stream time (84 kS/s index) of frame 0 of the current buffer */
+	long long dec_base;	/* stream time (84 kS/s index) of frame 0 of the current planes */
 	long long dec_fill;	/* frames present before this push's K1 output */
 	long long last_fill;	/* diagnostics: where the last push's output starts */
 	long long last_J;
@@ -52,13 +77,36 @@ struct StreamState {
 struct ChanState {
 	long long pos;		/* stream time of the next WSYNC evaluation */
 	int r;			/* FIR sub-phase (channel_t.clk after the -=8), 0..3 */
+	int fresh;		/* evaluations since the last trigger/reset, saturating */
 	float perr, p2err, pfr;	/* channel_t.perr/p2err/pfr */
 	float ring[VDL2_NPH];	/* channel_t.Ph in time order, ring[67] newest */
-	unsigned long long n_eval, n_trig, n_reject, n_burst, n_defer;
+	unsigned long long n_eval, n_trig, n_reject, n_burst, n_defer, n_slow, n_cand;
 };
 
 struct ChanCfg {
 	int chn, Fr, Fo, pad;
+};
+
+struct Cand {			/* free-running detector fires at dec_base + nrel with sub-phase r */
+	int nrel, r;
+	float p2err, perr, err, pfr;
+};
+
+enum { CL_STEADY = 0, CL_DEFER_FIRST = 1, CL_NONSTEADY = 2, CL_INVALID = 3 };
+struct Cluster {
+	int status, r_s;
+	long long n_s;		/* CL_STEADY: detector is history-free again at (n_s, r_s) */
+	int nslots, slots[VDL2_CL_MAXB];	/* staged bursts of this cluster */
+	int ntrig, nrej, nburst;
+	ChanState saved;	/* CL_NONSTEADY: explicit state to continue from */
+};
+
+struct BurstDesc {		/* a burst found by a cluster; payload decoded later if it is on the real chain */
+	long long nstar;	/* stream time of the sync trigger */
+	int sc;			/* stream*8 + channel */
+	int clk0;		/* (int)roundf(of), d8psk.c:305 */
+	float df;
+	int nbrow, nlbyte, pad;
 };
 
 struct K1Params {
@@ -69,7 +117,7 @@ struct K1Params {
 	int c0, no0, nf0, parity;
 	long long N, J;
 	const float2 *lo;	/* [S][8][L] */
-	float2 *dec;		/* this push's buffer, [S][cap][8] */
+	float2 *dec;		/* this push's planes, [S][8][cap] */
 	long long cap;
 	StreamState *ss;
 };
@@ -77,17 +125,30 @@ struct K1Params {
 struct K2Params {
 	const float2 *dec;
 	long long cap;
-	int nbch;
+	int nbch, nstreams;
 	long long J;
 	StreamState *ss;
 	ChanState *cs;
 	const ChanCfg *cfg;
 	const uint8_t *pn;
+	Cand *cands;		/* [S*8][CAND_CAP] */
+	Cluster *clusters;	/* [S*8][CAND_CAP] */
+	unsigned *ctl;		/* [0]=out count [1]=out overflow [2]=stage count [3]=k2b ticket [4]=stage overflow
+				 * [8 + S*8 ...] cand counts, then cand overflow flags */
+	BurstDesc *stage;	/* burst descriptors of all clusters */
+	uint8_t *stage_sel;
+	unsigned stage_cap;
 	vdl2gpu_burst_t *recs;
-	unsigned *rec_count;
 	unsigned rec_cap;
-	unsigned *overflow;
+	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
+	unsigned long long *dbg;	/* diagnostics: cycle counters */
 };
+#define CTL_OUT 0
+#define CTL_OUT_OVF 1
+#define CTL_STAGE 2
+#define CTL_TICKET 3
+#define CTL_STAGE_OVF 4
+#define CTL_CAND0 8
 
 struct K3Params {
 	const float2 *src;
@@ -167,13 +228,15 @@ void k1_channelise(K1Params p)
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
 	StreamState *ss = p.ss + s;
 	const long long fill = ss->dec_fill;
-	float2 *dec = p.dec + ((size_t)s * p.cap + fill) * VDL2_CS;
 	const long long jb = (long long)blockIdx.x * (K1_OPB * K1_PASSES);
 	if (blockIdx.x == 0 && tid == 0) {
 		ss->last_fill = fill;
 		ss->last_J = p.J;
 	}
-	const int o = tid >> 3, c = tid & 7;
+	/* lane = (channel, output): 32 consecutive outputs of one channel per half-wave,
+	 * so a plane store is a 256-byte run */
+	const int o = tid & 31, c = tid >> 5;
+	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill;
 	for (int pass = 0; pass < K1_PASSES; ++pass) {
 		const long long jp = jb + (long long)pass * K1_OPB;
 		if (jp > p.J)
@@ -222,49 +285,69 @@ void k1_channelise(K1Params p)
 				ss->acc[p.parity ^ 1][c] = make_float2(dre, dim);
 			} else {
 				const float fn = (float)nf;
-				dec[j * VDL2_CS + c] = make_float2(dre / fn, dim / fn);
+				dec[j] = make_float2(dre / fn, dim / fn);
 			}
 		}
 	}
 }
 
-/* ======================================================================= K2
- * Demodulator: one workgroup per VDL channel.
- *   search  (time-parallel): for the next <=K2_THREADS evaluation instants of
- *           the idle detector compute the filtered phase (d8psk.c:219-230),
- *           then the 17-point sync-word fit error (d8psk.c:257-289), then find
- *           the first instant where `perr < 4 && err > perr` (d8psk.c:292).
- *   burst   (parallel over symbols): one-shot timing estimate (d8psk.c:303-306),
- *           header symbols -> soft bits -> (25,20) Viterbi in one wavefront
- *           (viterbi.c), then every payload symbol's phase, differential
- *           slice + Grey soft tables + descramble (d8psk.c:54-65, 211-217,
- *           321-331) and the column-major de-interleave (d8psk.c:117-206)
- *           as a closed-form scatter.
- */
-#ifndef K2_THREADS
-#define K2_THREADS 512
-#endif
-
+/* ============================================================ shared DSP pieces */
 __device__ __forceinline__ float d_tab(const uint32_t *t, int i)
 {
 	return __uint_as_float(t[i]);
 }
 
-/* filteredphase(), d8psk.c:219-230: x points at frame n-16 (channel column) */
-__device__ __forceinline__ float k2_fir_phase(const float2 *x, int tap0)
+/* filteredphase(), d8psk.c:219-230: x points at sample n-16.  All 17 samples of the
+ * ring are fetched up front (independent loads, one memory latency); the taps
+ * mflt[tap0], mflt[tap0+4], .. < 65 are then applied oldest sample first, exactly the
+ * reference's accumulation order. */
+template <int R> __device__ __forceinline__ float k2_fir_phase_r(const float2 *x)
 {
+	float2 v[17];
+#pragma unroll
+	for (int j = 0; j < 17; ++j)
+		v[j] = x[j];
 	float sr = 0.0f, si = 0.0f;
-	for (int i = tap0, j = 0; i < 65; i += 4, ++j) {
-		const float m = d_tab(c_mflt, i);
-		const float2 v = x[(size_t)j * VDL2_CS];
-		sr += v.x * m;
-		si += v.y * m;
+#pragma unroll
+	for (int j = 0; j < 17; ++j) {
+		if (R + 4 * j < 65) {
+			const float m = d_tab(c_mflt, R + 4 * j);
+			sr += v[j].x * m;
+			si += v[j].y * m;
+		}
 	}
 	return vdl2_atan2f(si, sr);
 }
 
-/* d8psk.c:257-289: ph[0], ph[4], ... ph[64] are the 17 phases one symbol apart */
-__device__ __forceinline__ float k2_sync_metric(const float *ph, float *slope)
+__device__ __forceinline__ float k2_fir_phase(const float2 *x, int tap0)
+{
+	switch (tap0) {
+	case 0: return k2_fir_phase_r<0>(x);
+	case 1: return k2_fir_phase_r<1>(x);
+	case 2: return k2_fir_phase_r<2>(x);
+	case 3: return k2_fir_phase_r<3>(x);
+	default: break;
+	}
+	/* trigger instant: clk = (int)roundf(of) in [4,12] -> 16..14 taps (d8psk.c:305-306) */
+	float2 v[17];
+#pragma unroll
+	for (int j = 0; j < 17; ++j)
+		v[j] = x[j];
+	float sr = 0.0f, si = 0.0f;
+#pragma unroll
+	for (int j = 0; j < 17; ++j) {
+		const int i = tap0 + 4 * j;
+		if (i < 65) {
+			const float m = d_tab(c_mflt, i);
+			sr += v[j].x * m;
+			si += v[j].y * m;
+		}
+	}
+	return vdl2_atan2f(si, sr);
+}
+
+/* d8psk.c:257-289: ph[0], ph[STRIDE], ... ph[16*STRIDE] are the 17 phases one symbol apart */
+template <int STRIDE> __device__ __forceinline__ float k2_sync_metric(const float *ph, float *slope)
 {
 	float pr[17];
 	float pu = 0.0f;
@@ -273,13 +356,13 @@ __device__ __forceinline__ float k2_sync_metric(const float *ph, float *slope)
 	pr[0] = pv;
 #pragma unroll
 	for (int l = 1; l < 17; ++l) {
-		const float pc = ph[4 * l] - d_tab(c_sw, l);
+		const float pc = ph[STRIDE * l] - d_tab(c_sw, l);
 		const float pd = pc - pv;
 		pv = pc;
-		if ((double)pd > M_PI)
-			pu = (float)((double)pu - 2 * M_PI);
-		else if ((double)pd < -M_PI)
-			pu = (float)((double)pu + 2 * M_PI);
+		/* (double)pd > M_PI etc.; -1/0/+1 turns of 2*pi accumulated through double like
+		 * the reference's `Pu -= 2 * M_PI` (the product k*2pi is exact) */
+		const double k = ((double)pd > M_PI) ? -1.0 : (((double)pd < -M_PI) ? 1.0 : 0.0);
+		pu = (float)((double)pu + k * (2 * M_PI));
 		pr[l] = pc + pu;
 		mean += pr[l];
 	}
@@ -319,61 +402,285 @@ __device__ __forceinline__ float k2_soft_bit(int idx, int which, int pnbit)
 	return pnbit ? (float)(1.0 - (double)v) : v;	/* descrambler, d8psk.c:60-63 */
 }
 
-struct K2Shared {
-	float pbuf[VDL2_NPH + K2_THREADS];	/* phases: [0,68) = history ring */
-	float errs[K2_THREADS + 2];		/* errs[t+2] = err of eval t; [0],[1] = p2err, perr */
-	float frs[K2_THREADS + 1];		/* frs[t+1] = slope of eval t; [0] = pfr */
-	float psym[VDL2_MAXSYM];		/* burst symbol phases */
-	uint8_t hbits[VDL2_MAXSYM];		/* 3 descrambled hard bits per symbol */
-	float hsoft[25];			/* descrambled header soft bits */
+/* ====================================================== the serial state machine
+ * Exact replay of demodD8psk()/putbit() for one channel by one workgroup:
+ *   search  for the next <=NT evaluation instants compute the filtered phase
+ *           (d8psk.c:219-230), the 17-point sync-word fit (d8psk.c:257-289) and
+ *           find the first instant where `perr < 4 && err > perr` (d8psk.c:292);
+ *   burst   one-shot timing estimate (d8psk.c:303-306), header symbols -> soft
+ *           bits -> (25,20) Viterbi in one wavefront (viterbi.c), then every
+ *           payload symbol in parallel: differential slice + Grey soft tables +
+ *           descramble (d8psk.c:54-65, 211-217, 321-331) and the column-major
+ *           de-interleave (d8psk.c:117-206) as a closed-form scatter.
+ * Used three ways: K2b (from a trigger candidate until history-free), K2c (from
+ * a carried non-steady state), and as the whole demodulator when the candidate
+ * tables overflow or force_serial is set.
+ */
+#define K2_NT 256		/* workgroup size of the serial machine in the resolver */
+#define K2B_NT 64		/* one wavefront per burst cluster */
+
+/* receiver's byte schedule for a burst of nbrow rows / nlbyte bytes in the last row
+ * (d8psk.c:117-206): ND data bytes then NF FEC bytes, column-major over the rows,
+ * short last row */
+struct BurstGeom {
+	int nd_rows, nd_last, nf_rows, nf_last, ND, NF, nsym;
+};
+
+__device__ __forceinline__ BurstGeom burst_geom(int nbrow, int nlbyte)
+{
+	BurstGeom g;
+	g.nd_rows = nbrow;
+	g.nd_last = nlbyte ? nlbyte : 249;	/* nlbyte==0: the zero-fill loop is skipped */
+	g.ND = (nbrow - 1) * 249 + g.nd_last;
+	if (nlbyte <= 2) {			/* FEC shortening of the last row, d8psk.c:153-161 */
+		g.nf_rows = nbrow - 1;
+		g.nf_last = 6;
+	} else {
+		g.nf_rows = nbrow;
+		g.nf_last = (nlbyte <= 30) ? 2 : (nlbyte <= 67 ? 4 : 6);
+	}
+	g.NF = (g.nf_rows > 0) ? (g.nf_rows - 1) * 6 + g.nf_last : 0;
+	g.nsym = (25 + 8 * (g.ND + g.NF) + 2) / 3;
+	return g;
+}
+
+__device__ __forceinline__ void burst_timing(int clk0, int *j0, int *rb)
+{
+	int j = (32 - clk0 + 3) / 4;	/* samples until clk0 + 4j >= 32 (d8psk.c:239, 317-319) */
+	if (j < 1)
+		j = 1;
+	*j0 = j;
+	*rb = clk0 + 4 * j - 32;	/* sub-phase during and after the burst */
+}
+
+/* Payload of one accepted burst -> output record (all NT threads of the workgroup).
+ * One lane per transmitted byte: its 8 bits sit in 3 or 4 consecutive symbols; the lane takes
+ * their phases itself (and the one before, for the differential slice): differential slice +
+ * Grey soft tables + descramble + hard decision (d8psk.c:54-65, 119, 168, 211-217, 321-331),
+ * then the column-major de-interleave as a closed-form scatter (d8psk.c:127-147, 176-197). */
+template <int NT> __device__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
+						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg)
+{
+	const int tid = threadIdx.x;
+	int j0, rb;
+	burst_timing(clk0, &j0, &rb);
+	const BurstGeom g = burst_geom(nbrow, nlbyte);
+	const long long nsym0 = nstar + j0;
+	uint32_t *w = reinterpret_cast<uint32_t *>(&rec->data[0][0]);
+	for (int i = tid; i < VDL2GPU_MAXROWS * VDL2GPU_ROWLEN / 4; i += NT)
+		w[i] = 0u;
+	__syncthreads();
+	const float2 *xs0 = x0 + (nsym0 - 16);
+	for (int b = tid; b < g.ND + g.NF; b += NT) {
+		const int q0 = 25 + 8 * b;
+		const int k0 = q0 / 3;	/* >= 8: never needs P1 */
+		int q = q0;
+		unsigned byte = 0;
+		float pprev = k2_fir_phase(xs0 + 8LL * (k0 - 1), rb);
+		for (int k = k0; q < q0 + 8; ++k) {
+			const float pk = k2_fir_phase(xs0 + 8LL * k, rb);
+			const int idx = k2_grey_index(pk, pprev, df);
+			pprev = pk;
+			for (int i = q - 3 * k; i < 3 && q < q0 + 8; ++i, ++q) {
+				const float v = k2_soft_bit(idx, i, pn[q]);
+				if ((double)v > 0.5)
+					byte |= 1u << (q - q0);
+			}
+		}
+		int row, col;
+		if (b < g.ND) {
+			const int full = g.nd_last * g.nd_rows;
+			if (b < full) {
+				col = b / g.nd_rows;
+				row = b % g.nd_rows;
+			} else {
+				const int bb = b - full;
+				col = g.nd_last + bb / (g.nd_rows - 1);
+				row = bb % (g.nd_rows - 1);
+			}
+		} else {
+			const int bf = b - g.ND;
+			const int full = g.nf_last * g.nf_rows;
+			if (bf < full) {
+				col = bf / g.nf_rows;
+				row = bf % g.nf_rows;
+			} else {
+				const int bb = bf - full;
+				col = g.nf_last + bb / (g.nf_rows - 1);
+				row = bb % (g.nf_rows - 1);
+			}
+			col += 249;
+		}
+		rec->data[row][col] = (uint8_t)byte;
+	}
+	if (tid == 0) {
+		rec->stream = stream;
+		rec->chn = cfg.chn;
+		rec->Fr = cfg.Fr;
+		rec->nbrow = nbrow;
+		rec->nlbyte = nlbyte;
+		rec->df = df;
+		rec->ppm = 0.0f;	/* host: d8psk.c:302 needs libm double math */
+		rec->trig_dec = nstar;
+		rec->end_dec = nsym0 + 8LL * (g.nsym - 1);
+		rec->trig_sample = 0;
+		rec->end_sample = 0;
+	}
+}
+
+template <int NT> struct MachSharedT {
+	float pbuf[VDL2_NPH + NT];	/* phases: [0,68) = history ring */
+	float errs[NT + 2];		/* errs[t+2] = err of eval t; [0],[1] = p2err, perr */
+	float frs[NT + 1];		/* frs[t+1] = slope of eval t; [0] = pfr */
+	float psym[12];			/* header symbol phases */
+	float hsoft[25];		/* descrambled header soft bits */
 	uint8_t vbk[26][32], vbv[26][32];	/* Viterbi back pointers / decided bits */
 	int first;
 	int ctl[16];
 	float fctl[8];
 };
 
-__global__ __launch_bounds__(K2_THREADS)
-void k2_demod(K2Params p)
-{
-	__shared__ K2Shared sh;
-	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
-	if (c >= p.nbch)
-		return;
-	ChanState *cs = p.cs + (size_t)s * VDL2_CS + c;
-	const StreamState *ss = p.ss + s;
-	const long long dec_base = ss->dec_base;
-	const long long avail_end = dec_base + ss->dec_fill + p.J;
-	const float2 *x0 = p.dec + (size_t)s * p.cap * VDL2_CS + c;	/* frame f, channel c: x0[f*8] */
+struct MachCtx {
+	const float2 *x;	/* channel plane, frame 0 = stream time dec_base */
+	long long dec_base, avail_end;
+	const uint8_t *pn;
+	vdl2gpu_burst_t *recs;	/* sink: output ring, payload decoded at once (K2c serial stretches) ... */
+	BurstDesc *desc;	/* ... or descriptor pool, payload decoded by K2d if selected (K2b) */
+	int sc;
+	unsigned *rec_count, *rec_ovf;
+	unsigned rec_cap;
+	int stream;
+	ChanCfg cfg;
+};
 
-	long long pos = cs->pos;
-	int r = cs->r;
-	unsigned long long n_eval = 0, n_trig = 0, n_reject = 0, n_burst = 0, n_defer = 0;
-	if (tid < VDL2_NPH)
-		sh.pbuf[tid] = cs->ring[tid];
+struct MachState {
+	long long pos;
+	int r, fresh;
+};
+
+struct MachOut {
+	int nslots, slots[VDL2_CL_MAXB];
+	int ntrig, nrej, nburst, ndefer;
+	long long neval;
+};
+
+enum { MR_END = 0, MR_DEFER = 1, MR_STEADY = 2, MR_LIMIT = 3 };
+
+template <int NT> __device__ __forceinline__ void mach_load(MachSharedT<NT> &sh, const ChanState *cs)
+{
+	const int tid = threadIdx.x;
+	for (int i = tid; i < VDL2_NPH; i += NT)
+		sh.pbuf[i] = cs->ring[i];
 	if (tid == 0) {
 		sh.errs[0] = cs->p2err;
 		sh.errs[1] = cs->perr;
 		sh.frs[0] = cs->pfr;
 	}
 	__syncthreads();
+}
 
+template <int NT> __device__ __forceinline__ void mach_store(const MachSharedT<NT> &sh, const MachState &st, ChanState *cs)
+{
+	const int tid = threadIdx.x;
+	for (int i = tid; i < VDL2_NPH; i += NT)
+		cs->ring[i] = sh.pbuf[i];
+	if (tid == 0) {
+		cs->pos = st.pos;
+		cs->r = st.r;
+		cs->fresh = st.fresh;
+		cs->p2err = sh.errs[0];
+		cs->perr = sh.errs[1];
+		cs->pfr = sh.frs[0];
+	}
+}
+
+/* shift the phase ring: new ring = pbuf[from .. from+67] (all threads call) */
+template <int NT> __device__ __forceinline__ void mach_shift_ring(MachSharedT<NT> &sh, int from, float e0, float e1, float f0)
+{
+	const int tid = threadIdx.x;
+	float keep[(VDL2_NPH + NT - 1) / NT];
+#pragma unroll
+	for (int k = 0; k < (VDL2_NPH + NT - 1) / NT; ++k) {
+		const int i = tid + k * NT;
+		keep[k] = (i < VDL2_NPH) ? sh.pbuf[from + i] : 0.0f;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < (VDL2_NPH + NT - 1) / NT; ++k) {
+		const int i = tid + k * NT;
+		if (i < VDL2_NPH)
+			sh.pbuf[i] = keep[k];
+	}
+	if (tid == 0) {
+		sh.errs[0] = e0;
+		sh.errs[1] = e1;
+		sh.frs[0] = f0;
+	}
+	__syncthreads();
+}
+
+/* Build the detector state at a history-free instant (n, r): the ring holds the
+ * free-running phases of the previous 68 evaluations and perr/p2err/pfr are
+ * those of evaluations n-2 and n-4.  Needs samples back to n-152. */
+template <int NT> __device__ __forceinline__ void mach_materialize(MachSharedT<NT> &sh, const MachCtx &cx, long long n, int r)
+{
+	const int tid = threadIdx.x;
+	for (int i = tid; i < VDL2_NPH; i += NT) {
+		const long long q = n - 2LL * (VDL2_NPH - i);
+		sh.pbuf[i] = k2_fir_phase(cx.x + (q - 16 - cx.dec_base), r);
+	}
+	__syncthreads();
+	if (tid < 2) {
+		float fr;
+		const float e = k2_sync_metric<4>(&sh.pbuf[3 - tid], &fr);
+		sh.errs[1 - tid] = e;	/* tid 0: evaluation n-2 -> perr; tid 1: n-4 -> p2err */
+		if (tid == 0)
+			sh.frs[0] = fr;
+	}
+	__syncthreads();
+}
+
+/* stop_steady: return MR_STEADY as soon as the detector is history-free and at least
+ * `min_trig` triggers were handled.  first_nev: size of the first search window (a hint). */
+template <int NT> __device__ int machine_run(MachSharedT<NT> &sh, const MachCtx &cx, MachState &st, bool stop_steady,
+					     int min_trig, int max_bursts, int first_nev, MachOut &out)
+{
+	const int tid = threadIdx.x;
+	const float2 *x0 = cx.x - cx.dec_base;	/* x0[n] = sample at stream time n */
+	long long pos = st.pos;
+	int r = st.r, fresh = st.fresh;
+	int rc = MR_END;
 	for (;;) {
-		long long rem = (avail_end - pos + 1) / 2;
-		const int nev = rem > K2_THREADS ? K2_THREADS : (int)rem;
-		if (nev <= 0)
+		if (stop_steady && fresh >= VDL2_STEADY && out.ntrig >= min_trig) {
+			rc = MR_STEADY;
 			break;
-		/* ---- search window: evaluations at pos, pos+2, ... */
-		if (tid < nev) {
-			const long long n = pos + 2 * tid;
-			sh.pbuf[VDL2_NPH + tid] = k2_fir_phase(x0 + (size_t)(n - VDL2_HIST - dec_base) * VDL2_CS, r);
 		}
+		if (out.nslots >= max_bursts) {
+			rc = MR_LIMIT;
+			break;
+		}
+		const long long rem = (cx.avail_end - pos + 1) / 2;
+		int nev = rem > NT ? NT : (int)rem;
+		if (nev <= 0) {
+			rc = MR_END;
+			break;
+		}
+		if (first_nev > 0) {
+			nev = nev < first_nev ? nev : first_nev;
+			first_nev = 0;
+		} else if (stop_steady && out.ntrig >= min_trig && fresh < VDL2_STEADY) {
+			const int need = VDL2_STEADY - fresh;
+			nev = nev < need ? nev : need;
+		}
+		/* ---- search window: evaluations at pos, pos+2, ... */
+		if (tid < nev)
+			sh.pbuf[VDL2_NPH + tid] = k2_fir_phase(x0 + (pos + 2 * tid - 16), r);
 		if (tid == 0)
 			sh.first = 0x7fffffff;
 		__syncthreads();
 		if (tid < nev) {
 			float fr;
-			const float err = k2_sync_metric(&sh.pbuf[tid + 4], &fr);
+			const float err = k2_sync_metric<4>(&sh.pbuf[tid + 4], &fr);
 			sh.errs[tid + 2] = err;
 			sh.frs[tid + 1] = fr;
 		}
@@ -387,21 +694,10 @@ void k2_demod(K2Params p)
 		const int ts = sh.first;
 		if (ts == 0x7fffffff) {
 			/* no trigger: commit the whole window */
-			float keep = 0.0f;
-			if (tid < VDL2_NPH)
-				keep = sh.pbuf[nev + tid];
-			const float e0 = sh.errs[nev], e1 = sh.errs[nev + 1], f0 = sh.frs[nev];
-			__syncthreads();
-			if (tid < VDL2_NPH)
-				sh.pbuf[tid] = keep;
-			if (tid == 0) {
-				sh.errs[0] = e0;
-				sh.errs[1] = e1;
-				sh.frs[0] = f0;
-			}
+			mach_shift_ring(sh, nev, sh.errs[nev], sh.errs[nev + 1], sh.frs[nev]);
 			pos += 2LL * nev;
-			n_eval += nev;
-			__syncthreads();
+			out.neval += nev;
+			fresh = fresh + nev > 1000000 ? 1000000 : fresh + nev;
 			continue;
 		}
 		/* ---- sync trigger at evaluation ts (stream time nstar) */
@@ -415,32 +711,30 @@ void k2_demod(K2Params p)
 				clk0 = 0;	/* unreachable for finite inputs: of is in [4,12] */
 			if (clk0 > 68)
 				clk0 = 68;
-			int j0 = (32 - clk0 + 3) / 4;
-			if (j0 < 1)
-				j0 = 1;
+			int j0, rb0;
+			burst_timing(clk0, &j0, &rb0);
 			sh.ctl[0] = clk0;
 			sh.ctl[1] = j0;
-			sh.ctl[2] = clk0 + 4 * j0 - 32;	/* sub-phase during and after the burst */
+			sh.ctl[2] = rb0;
 			sh.fctl[0] = sh.frs[ts];	/* df = pfr, d8psk.c:301 */
 		}
 		__syncthreads();
 		const int clk0 = sh.ctl[0], j0 = sh.ctl[1], rb = sh.ctl[2];
 		const float df = sh.fctl[0];
 		const long long nsym0 = nstar + j0;	/* stream time of burst symbol 0 */
-		bool defer = (nsym0 + 64 >= avail_end);	/* 9 header symbols must be present */
+		bool defer = (nsym0 + 64 >= cx.avail_end);	/* 9 header symbols must be present */
 		int accepted = 0, nbrow = 0, nlbyte = 0, nsym = 0;
-		int nd_rows = 0, nd_last = 0, nf_rows = 0, nf_last = 0, ND = 0, NF = 0;
 		if (!defer) {
 			if (tid < 9)
-				sh.psym[tid] = k2_fir_phase(x0 + (size_t)(nsym0 + 8 * tid - VDL2_HIST - dec_base) * VDL2_CS, rb);
+				sh.psym[tid] = k2_fir_phase(x0 + (nsym0 + 8 * tid - 16), rb);
 			if (tid == 9)
-				sh.fctl[1] = k2_fir_phase(x0 + (size_t)(nstar - VDL2_HIST - dec_base) * VDL2_CS, clk0);	/* P1 */
+				sh.fctl[1] = k2_fir_phase(x0 + (nstar - 16), clk0);	/* P1 */
 			__syncthreads();
 			if (tid < 25) {
 				const int k = tid / 3;
 				const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
 				const int idx = k2_grey_index(sh.psym[k], pprev, df);
-				float v = k2_soft_bit(idx, tid % 3, p.pn[tid]);
+				float v = k2_soft_bit(idx, tid % 3, cx.pn[tid]);
 				if (tid < 3)
 					v = 0.0f;	/* reserved bits forced, d8psk.c:81-82 */
 				sh.hsoft[tid] = v;
@@ -479,11 +773,11 @@ void k2_demod(K2Params p)
 			__syncthreads();
 			if (tid == 0) {
 				unsigned word = 0, mask = 1;
-				int st = 0;
+				int sv = 0;
 				for (int n = 25; n > 0; --n) {
-					if (sh.vbv[n][st])
+					if (sh.vbv[n][sv])
 						word |= mask;
-					st = sh.vbk[n][st];
+					sv = sh.vbk[n][sv];
 					mask <<= 1;
 				}
 				word >>= 5;	/* drop the 5 parity bits, d8psk.c:90 */
@@ -501,213 +795,572 @@ void k2_demod(K2Params p)
 			nbrow = sh.ctl[4];
 			nlbyte = sh.ctl[5];
 			if (accepted) {
-				/* receiver's byte schedule, d8psk.c:117-206 */
-				nd_rows = nbrow;
-				nd_last = nlbyte ? nlbyte : 249;	/* nlbyte==0: zero-fill loop is skipped */
-				ND = (nbrow - 1) * 249 + nd_last;
-				if (nlbyte <= 2) {
-					nf_rows = nbrow - 1;
-					nf_last = 6;
-				} else {
-					nf_rows = nbrow;
-					nf_last = (nlbyte <= 30) ? 2 : (nlbyte <= 67 ? 4 : 6);
-				}
-				NF = (nf_rows - 1) * 6 + nf_last;
-				if (nf_rows <= 0)
-					NF = 0;
-				nsym = (25 + 8 * (ND + NF) + 2) / 3;
-				if (nsym0 + 8LL * (nsym - 1) >= avail_end)
+				nsym = burst_geom(nbrow, nlbyte).nsym;
+				if (nsym0 + 8LL * (nsym - 1) >= cx.avail_end)
 					defer = true;
 			}
 		}
 		if (defer) {
 			/* the burst is not completely inside the data we hold: commit the
 			 * evaluations before the trigger and retry on the next push */
-			float keep = 0.0f;
-			if (tid < VDL2_NPH)
-				keep = sh.pbuf[ts + tid];
-			const float e0 = sh.errs[ts], e1 = sh.errs[ts + 1], f0 = sh.frs[ts];
-			__syncthreads();
-			if (tid < VDL2_NPH)
-				sh.pbuf[tid] = keep;
-			if (tid == 0) {
-				sh.errs[0] = e0;
-				sh.errs[1] = e1;
-				sh.frs[0] = f0;
-			}
+			mach_shift_ring(sh, ts, sh.errs[ts], sh.errs[ts + 1], sh.frs[ts]);
 			pos += 2LL * ts;
-			n_eval += ts;
-			n_defer++;
-			__syncthreads();
+			out.neval += ts;
+			fresh = fresh + ts > 1000000 ? 1000000 : fresh + ts;
+			out.ndefer++;
+			rc = MR_DEFER;
 			break;
 		}
-		n_trig++;
+		out.ntrig++;
 		long long nlast;
 		if (!accepted) {
-			n_reject++;
+			out.nrej++;
 			nlast = nsym0 + 64;	/* state returns to WSYNC on the 25th bit (symbol 8) */
 		} else {
 			nlast = nsym0 + 8LL * (nsym - 1);
-			for (int k = tid; k < nsym; k += K2_THREADS)
-				sh.psym[k] = k2_fir_phase(x0 + (size_t)(nsym0 + 8LL * k - VDL2_HIST - dec_base) * VDL2_CS, rb);
 			if (tid == 0) {
-				unsigned slot = atomicAdd(p.rec_count, 1u);
-				if (slot >= p.rec_cap) {
-					atomicAdd(p.overflow, 1u);
+				unsigned slot = atomicAdd(cx.rec_count, 1u);
+				if (slot >= cx.rec_cap) {
+					atomicAdd(cx.rec_ovf, 1u);
 					slot = 0xffffffffu;
+				} else if (cx.desc) {
+					BurstDesc d;
+					d.nstar = nstar;
+					d.sc = cx.sc;
+					d.clk0 = clk0;
+					d.df = df;
+					d.nbrow = nbrow;
+					d.nlbyte = nlbyte;
+					d.pad = 0;
+					cx.desc[slot] = d;
 				}
 				sh.ctl[6] = (int)slot;
 			}
 			__syncthreads();
 			const unsigned slot = (unsigned)sh.ctl[6];
-			for (int k = tid; k < nsym; k += K2_THREADS) {
-				const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
-				const int idx = k2_grey_index(sh.psym[k], pprev, df);
-				int hb = 0;
-#pragma unroll
-				for (int i = 0; i < 3; ++i) {
-					const float v = k2_soft_bit(idx, i, p.pn[3 * k + i]);
-					if ((double)v > 0.5)
-						hb |= 1 << i;
-				}
-				sh.hbits[k] = (uint8_t)hb;
-			}
-			vdl2gpu_burst_t *rec = (slot != 0xffffffffu) ? p.recs + slot : nullptr;
-			if (rec) {
-				uint32_t *w = reinterpret_cast<uint32_t *>(&rec->data[0][0]);
-				for (int i = tid; i < VDL2GPU_MAXROWS * VDL2GPU_ROWLEN / 4; i += K2_THREADS)
-					w[i] = 0u;
-			}
-			__syncthreads();
-			if (rec) {
-				for (int b = tid; b < ND + NF; b += K2_THREADS) {
-					const int q0 = 25 + 8 * b;
-					unsigned byte = 0;
-#pragma unroll
-					for (int i = 0; i < 8; ++i) {
-						const int q = q0 + i;
-						byte |= (unsigned)((sh.hbits[q / 3] >> (q % 3)) & 1) << i;
-					}
-					/* column-major walk with a short last row -> (row, col) */
-					int row, col;
-					if (b < ND) {
-						const int full = nd_last * nd_rows;
-						if (b < full) {
-							col = b / nd_rows;
-							row = b % nd_rows;
-						} else {
-							const int bb = b - full;
-							col = nd_last + bb / (nd_rows - 1);
-							row = bb % (nd_rows - 1);
-						}
-					} else {
-						const int bf = b - ND;
-						const int full = nf_last * nf_rows;
-						if (bf < full) {
-							col = bf / nf_rows;
-							row = bf % nf_rows;
-						} else {
-							const int bb = bf - full;
-							col = nf_last + bb / (nf_rows - 1);
-							row = bb % (nf_rows - 1);
-						}
-						col += 249;
-					}
-					rec->data[row][col] = (uint8_t)byte;
-				}
-				if (tid == 0) {
-					const ChanCfg cf = p.cfg[(size_t)s * VDL2_CS + c];
-					rec->stream = s;
-					rec->chn = cf.chn;
-					rec->Fr = cf.Fr;
-					rec->nbrow = nbrow;
-					rec->nlbyte = nlbyte;
-					rec->df = df;
-					rec->ppm = 0.0f;	/* host: d8psk.c:302 needs libm double math */
-					rec->trig_dec = nstar;
-					rec->end_dec = nlast;
-					rec->trig_sample = 0;
-					rec->end_sample = 0;
-				}
-			}
-			n_burst++;
+			if (!cx.desc && slot != 0xffffffffu)
+				burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg);
+			if (out.nslots < VDL2_CL_MAXB)
+				out.slots[out.nslots] = (int)slot;
+			out.nslots++;
+			out.nburst++;
 		}
 		/* back to the idle detector: ring keeps the phases up to the trigger
 		 * evaluation (Ph is not written during a burst), errors re-armed
 		 * (d8psk.c:308), sub-phase sticks at rb */
-		{
-			float keep = 0.0f;
-			if (tid < VDL2_NPH)
-				keep = sh.pbuf[ts + 1 + tid];
-			const float f0 = sh.frs[ts];
-			__syncthreads();
-			if (tid < VDL2_NPH)
-				sh.pbuf[tid] = keep;
-			if (tid == 0) {
-				sh.errs[0] = 500.0f;
-				sh.errs[1] = 500.0f;
-				sh.frs[0] = f0;
+		mach_shift_ring(sh, ts + 1, 500.0f, 500.0f, sh.frs[ts]);
+		out.neval += ts + 1;
+		pos = nlast + 2;
+		r = rb;
+		fresh = 0;
+	}
+	st.pos = pos;
+	st.r = r;
+	st.fresh = fresh;
+	return rc;
+}
+
+__device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, int c, bool to_stage)
+{
+	const StreamState *ss = p.ss + s;
+	cx.x = p.dec + ((size_t)s * VDL2_CS + c) * p.cap;
+	cx.dec_base = ss->dec_base;
+	cx.avail_end = ss->dec_base + ss->dec_fill + p.J;
+	cx.pn = p.pn;
+	cx.sc = s * VDL2_CS + c;
+	if (to_stage) {
+		cx.recs = nullptr;
+		cx.desc = p.stage;
+		cx.rec_count = p.ctl + CTL_STAGE;
+		cx.rec_ovf = p.ctl + CTL_STAGE_OVF;
+		cx.rec_cap = p.stage_cap;
+	} else {
+		cx.recs = p.recs;
+		cx.desc = nullptr;
+		cx.rec_count = p.ctl + CTL_OUT;
+		cx.rec_ovf = p.ctl + CTL_OUT_OVF;
+		cx.rec_cap = p.rec_cap;
+	}
+	cx.stream = s;
+	cx.cfg = p.cfg[(size_t)s * VDL2_CS + c];
+}
+
+/* ====================================================================== K2a
+ * Sync scan.  For every sample n >= pos of a channel and every FIR sub-phase
+ * r in 0..3 compute the filtered phase P_r(n) and the free-running fit error
+ * E_r(n) from P_r(n), P_r(n-8), .. P_r(n-128); record every (n, r) where the
+ * idle detector would fire: E_r(n-2) < 4 && E_r(n) > E_r(n-2).
+ * One workgroup = K2A_TS consecutive samples of one channel, staged in LDS.
+ */
+#define K2A_THREADS 256
+#define K2A_TS 1024
+#define K2A_POFF 132		/* phases needed before the tile: 128 + 4 */
+#define K2A_XOFF (K2A_POFF + 16)
+
+__global__ __launch_bounds__(K2A_THREADS)
+void k2a_scan(K2Params p)
+{
+	__shared__ float2 xs[K2A_TS + K2A_XOFF];
+	__shared__ float ph[4][K2A_TS + K2A_POFF];
+	__shared__ float eb[K2A_TS + 4], fb[K2A_TS + 4];
+	const int tid = threadIdx.x;
+	const int c = blockIdx.y, s = blockIdx.z;
+	const int sc = s * VDL2_CS + c;
+	const StreamState *ss = p.ss + s;
+	const long long dec_base = ss->dec_base;
+	const long long avail_end = dec_base + ss->dec_fill + p.J;
+	const long long n0 = p.cs[sc].pos + (long long)blockIdx.x * K2A_TS;
+	if (n0 >= avail_end || p.force_serial)
+		return;
+	const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
+	const float2 *x = p.dec + (size_t)sc * p.cap + (n0 - K2A_XOFF - dec_base);
+	for (int i = tid; i < nt + K2A_XOFF; i += K2A_THREADS)
+		xs[i] = x[i];
+	__syncthreads();
+	/* phases for samples n0-POFF .. n0+nt-1, all four sub-phases from one register copy */
+	for (int q = tid; q < nt + K2A_POFF; q += K2A_THREADS) {
+		float2 xv[17];
+#pragma unroll
+		for (int j = 0; j < 17; ++j)
+			xv[j] = xs[q + j];	/* sample (n0-POFF+q) - 16 + j */
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			float sr = 0.0f, si = 0.0f;
+#pragma unroll
+			for (int j = 0; j < 17; ++j) {
+				if (r + 4 * j < 65) {
+					const float m = d_tab(c_mflt, r + 4 * j);
+					sr += xv[j].x * m;
+					si += xv[j].y * m;
+				}
 			}
-			n_eval += ts + 1;
-			pos = nlast + 2;
-			r = rb;
-			__syncthreads();
+			ph[r][q] = vdl2_atan2f(si, sr);
 		}
 	}
-	/* persist */
-	if (tid < VDL2_NPH)
-		cs->ring[tid] = sh.pbuf[tid];
+	__syncthreads();
+	unsigned *cnt = p.ctl + CTL_CAND0 + sc;
+	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
+	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	for (int r = 0; r < 4; ++r) {
+		/* fit errors for samples n0-4 .. n0+nt-1: eb[i] <-> sample n0-4+i */
+		for (int i = tid; i < nt + 4; i += K2A_THREADS) {
+			float fr;
+			/* newest phase of sample n0-4+i sits at ph index POFF-4+i; oldest 128 before */
+			eb[i] = k2_sync_metric<8>(&ph[r][K2A_POFF - 4 + i - 128], &fr);
+			fb[i] = fr;
+		}
+		__syncthreads();
+		for (int i = tid; i < nt; i += K2A_THREADS) {
+			const float perr = eb[i + 2], err = eb[i + 4];
+			if (perr < 4.0f && err > perr) {
+				const unsigned k = atomicAdd(cnt, 1u);
+				if (k < VDL2_CAND_CAP) {
+					Cand cd;
+					cd.nrel = (int)(n0 + i - dec_base);
+					cd.r = r;
+					cd.p2err = eb[i];
+					cd.perr = perr;
+					cd.err = err;
+					cd.pfr = fb[i + 2];
+					cl[k] = cd;
+				} else
+					*ovf = 1u;
+			}
+		}
+		__syncthreads();
+	}
+}
+
+/* ====================================================================== K2b
+ * One workgroup per trigger candidate (persistent workgroups pull tickets):
+ * put the detector in the history-free state at the candidate, run the exact
+ * machine through the burst (and any burst that follows before the detector is
+ * history-free again) and record where and how the idle search resumes.
+ */
+__global__ __launch_bounds__(K2B_NT)
+void k2b_clusters(K2Params p)
+{
+	__shared__ MachSharedT<K2B_NT> sh;
+	__shared__ int s_ticket;
+	const int tid = threadIdx.x;
+	const int nsc = p.nstreams * VDL2_CS;
+	if (p.force_serial)
+		return;
+	for (;;) {
+		if (tid == 0)
+			s_ticket = (int)atomicAdd(p.ctl + CTL_TICKET, 1u);
+		__syncthreads();
+		int idx = s_ticket;
+		int sc = 0;
+		for (; sc < nsc; ++sc) {
+			unsigned n = p.ctl[CTL_CAND0 + sc];
+			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
+			if (idx < (int)n)
+				break;
+			idx -= (int)n;
+		}
+		if (sc >= nsc)
+			break;
+		const int s = sc / VDL2_CS, c = sc % VDL2_CS;
+		MachCtx cx;
+		mach_ctx(cx, p, s, c, true);
+		const Cand cd = p.cands[(size_t)sc * VDL2_CAND_CAP + idx];
+		Cluster *cl = p.clusters + (size_t)sc * VDL2_CAND_CAP + idx;
+		MachState st;
+		st.pos = cx.dec_base + cd.nrel;
+		st.r = cd.r;
+		st.fresh = VDL2_STEADY;
+		MachOut out;
+		out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+		out.neval = 0;
+		const long long t0 = wall_clock64();
+		mach_materialize(sh, cx, st.pos, st.r);
+		const long long t1 = wall_clock64();
+		const int rc = machine_run(sh, cx, st, true, 1, VDL2_CL_MAXB, 1, out);
+		const long long t2 = wall_clock64();
+		if (tid == 0 && p.dbg) {
+			atomicAdd(p.dbg + 0, (unsigned long long)(t1 - t0));
+			atomicAdd(p.dbg + 1, (unsigned long long)(t2 - t1));
+			atomicAdd(p.dbg + 2, 1ull);
+			atomicAdd(p.dbg + 3, (unsigned long long)out.ntrig);
+			atomicAdd(p.dbg + 4, (unsigned long long)out.neval);
+			atomicMax(p.dbg + 5, (unsigned long long)(t2 - t1));
+			atomicAdd(p.dbg + 6, (unsigned long long)(rc == MR_STEADY));
+			atomicAdd(p.dbg + 7, (unsigned long long)out.nrej);
+		}
+		int status;
+		if (rc == MR_STEADY)
+			status = CL_STEADY;
+		else if (rc == MR_DEFER && out.ntrig == 0)
+			status = CL_DEFER_FIRST;
+		else
+			status = CL_NONSTEADY;
+		bool bad = false;
+		for (int i = 0; i < out.nslots && i < VDL2_CL_MAXB; ++i)
+			if (out.slots[i] < 0)
+				bad = true;	/* staging pool full */
+		if (bad)
+			status = CL_INVALID;
+		if (status == CL_NONSTEADY)
+			mach_store(sh, st, &cl->saved);
+		if (tid == 0) {
+			cl->status = status;
+			cl->r_s = st.r;
+			cl->n_s = st.pos;
+			cl->nslots = out.nslots < VDL2_CL_MAXB ? out.nslots : VDL2_CL_MAXB;
+			for (int i = 0; i < VDL2_CL_MAXB; ++i)
+				cl->slots[i] = out.slots[i < out.nslots ? i : 0];
+			cl->ntrig = out.ntrig;
+			cl->nrej = out.nrej;
+			cl->nburst = out.nburst;
+		}
+		__syncthreads();
+	}
+}
+
+/* ====================================================================== K2c
+ * Resolver: one workgroup per VDL channel follows the real chain of events.
+ * While the detector is history-free the next event is simply the first
+ * candidate of the current (sub-phase, sample parity) at or after `pos`, and
+ * its consequences were precomputed by K2b; otherwise the serial machine runs
+ * until the detector is history-free again.
+ *   1. rank-sort the channel's candidates by time                 (parallel)
+ *   2. for every candidate: status + index of the candidate that  (parallel)
+ *      follows its cluster  -> successor table in LDS
+ *   3. walk the chain through the successor table                 (one lane, LDS only)
+ *   4. mark the staged bursts of the visited clusters, add counters (parallel)
+ */
+#define K2C_NOCAND 0xffffu
+
+/* first sorted candidate at/after stream-relative time `want` of class (r, parity), from `from` */
+__device__ __forceinline__ int k2c_next(const int *skey, int ncand, int from, int want, int r)
+{
+	/* lower bound on time */
+	int lo = from, hi = ncand;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if ((skey[mid] >> 2) < want)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	for (; lo < ncand; ++lo) {
+		const int k = skey[lo];
+		if ((k & 3) == r && (((k >> 2) - want) & 1) == 0)
+			return lo;
+	}
+	return -1;
+}
+
+__global__ __launch_bounds__(K2_NT)
+void k2c_resolve(K2Params p)
+{
+	__shared__ MachSharedT<K2_NT> sh;
+	__shared__ int skey[VDL2_CAND_CAP];		/* sorted keys: nrel*4 + r */
+	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
+	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
+	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
+	__shared__ uint8_t ssel[VDL2_CAND_CAP];		/* visited by the real chain */
+	__shared__ int s_walk[4];
+	__shared__ int s_cnt[4];
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	ChanState *cs = p.cs + sc;
+	MachCtx cx;
+	mach_ctx(cx, p, s, c, false);
+	MachState st;
+	st.pos = cs->pos;
+	st.r = cs->r;
+	st.fresh = cs->fresh;
+	mach_load(sh, cs);
+	MachOut out;
+	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.neval = 0;
+	unsigned long long n_slow = 0;
+	int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	const bool tables_ok = !p.force_serial && ncand <= VDL2_CAND_CAP && p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] == 0;
+	if (!tables_ok)
+		ncand = 0;
+	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
+	/* 1. rank sort (keys are unique: one candidate per (n, r)) */
+	const long long pos_in = st.pos;
+	for (int i = tid; i < ncand; i += K2_NT)
+		skey[i] = cands[i].nrel * 4 + cands[i].r;
+	__syncthreads();
+	{
+		/* ranks computed against the unsorted array, then scattered in two phases */
+		int myk[VDL2_CAND_CAP / K2_NT], myr[VDL2_CAND_CAP / K2_NT];
+#pragma unroll 1
+		for (int t = 0, i = tid; i < ncand; i += K2_NT, ++t) {
+			const int k = skey[i];
+			int rank = 0;
+			for (int j = 0; j < ncand; ++j)
+				rank += (skey[j] < k) ? 1 : 0;
+			myk[t] = k;
+			myr[t] = rank;
+		}
+		__syncthreads();
+#pragma unroll 1
+		for (int t = 0, i = tid; i < ncand; i += K2_NT, ++t) {
+			skey[myr[t]] = myk[t];
+			sidx[myr[t]] = (unsigned short)i;
+		}
+	}
+	__syncthreads();
+	/* 2. successor table */
+	for (int j = tid; j < ncand; j += K2_NT) {
+		const Cluster *cl = clusters + sidx[j];
+		const int status = cl->status;
+		int nx = -1;
+		if (status == CL_STEADY)
+			nx = k2c_next(skey, ncand, j + 1, (int)(cl->n_s - cx.dec_base), cl->r_s);
+		sstat[j] = (uint8_t)status;
+		snext[j] = (nx < 0) ? (unsigned short)K2C_NOCAND : (unsigned short)nx;
+		ssel[j] = 0;
+	}
+	__syncthreads();
+	bool steady_end = false;
+	for (;;) {
+		if (!tables_ok || st.fresh < VDL2_STEADY) {
+			/* history-dependent stretch (or no tables): serial machine */
+			const long long p0 = st.pos;
+			const int rc = machine_run(sh, cx, st, tables_ok, 0, 1 << 30, 0, out);
+			n_slow += (unsigned long long)(st.pos - p0);
+			if (rc != MR_STEADY)
+				break;
+			continue;
+		}
+		/* 3. history-free: walk the successor table until something special happens */
+		if (tid == 0) {
+			int cur = k2c_next(skey, ncand, 0, (int)(st.pos - cx.dec_base), st.r);
+			int last = -1, why = 0;	/* why: 0 = no more candidates, 1 = special cluster at cur */
+			while (cur >= 0) {
+				const int stt = sstat[cur];
+				if (stt != CL_STEADY) {
+					why = 1;
+					break;
+				}
+				ssel[cur] = 1;
+				last = cur;
+				const int nx = snext[cur];
+				cur = (nx == K2C_NOCAND) ? -1 : nx;
+			}
+			s_walk[0] = cur;
+			s_walk[1] = last;
+			s_walk[2] = why;
+		}
+		__syncthreads();
+		const int cur = s_walk[0], last = s_walk[1], why = s_walk[2];
+		__syncthreads();
+		if (last >= 0) {
+			const Cluster *cl = clusters + sidx[last];
+			st.pos = cl->n_s;
+			st.r = cl->r_s;
+		}
+		if (!why) {
+			/* idle to the end of the data: next evaluation is the first one past it */
+			const long long rem = (cx.avail_end - st.pos + 1) / 2;
+			if (rem > 0)
+				st.pos += 2 * rem;
+			steady_end = true;
+			break;
+		}
+		const long long ncand_t = cx.dec_base + (skey[cur] >> 2);
+		const Cluster *cl = clusters + sidx[cur];
+		const int status = sstat[cur];
+		if (status == CL_DEFER_FIRST) {
+			st.pos = ncand_t;
+			out.ndefer++;
+			steady_end = true;
+			break;
+		}
+		if (status == CL_INVALID) {
+			/* staging pool was full: replay this stretch here */
+			st.pos = ncand_t;
+			mach_materialize(sh, cx, st.pos, st.r);
+			const int rc = machine_run(sh, cx, st, true, 1, 1 << 30, 1, out);
+			if (rc != MR_STEADY)
+				break;
+			continue;
+		}
+		/* CL_NONSTEADY: its bursts count, then continue from the explicit state it stopped in */
+		if (tid == 0)
+			ssel[cur] = 1;
+		mach_load(sh, &cl->saved);
+		st.pos = cl->saved.pos;
+		st.r = cl->saved.r;
+		st.fresh = cl->saved.fresh < VDL2_STEADY ? cl->saved.fresh : VDL2_STEADY - 1;
+	}
+	__syncthreads();
+	/* 4. publish the visited clusters */
+	if (tid < 4)
+		s_cnt[tid] = 0;
+	__syncthreads();
+	{
+		int a = 0, b = 0, d = 0;
+		for (int j = tid; j < ncand; j += K2_NT)
+			if (ssel[j]) {
+				const Cluster *cl = clusters + sidx[j];
+				const int ns = cl->nslots;
+				for (int i = 0; i < ns; ++i)
+					p.stage_sel[cl->slots[i]] = 1;
+				a += cl->ntrig;
+				b += cl->nrej;
+				d += cl->nburst;
+			}
+		if (a)
+			atomicAdd(&s_cnt[0], a);
+		if (b)
+			atomicAdd(&s_cnt[1], b);
+		if (d)
+			atomicAdd(&s_cnt[2], d);
+	}
+	__syncthreads();
+	if (steady_end) {
+		mach_materialize(sh, cx, st.pos, st.r);
+		st.fresh = VDL2_STEADY;
+	}
+	__syncthreads();
+	mach_store(sh, st, cs);
 	if (tid == 0) {
-		cs->pos = pos;
-		cs->r = r;
-		cs->p2err = sh.errs[0];
-		cs->perr = sh.errs[1];
-		cs->pfr = sh.frs[0];
-		cs->n_eval += n_eval;
-		cs->n_trig += n_trig;
-		cs->n_reject += n_reject;
-		cs->n_burst += n_burst;
-		cs->n_defer += n_defer;
+		cs->n_eval += (unsigned long long)((st.pos - pos_in) / 2);	/* evaluation instants covered */
+		cs->n_trig += (unsigned long long)(out.ntrig + s_cnt[0]);
+		cs->n_reject += (unsigned long long)(out.nrej + s_cnt[1]);
+		cs->n_burst += (unsigned long long)(out.nburst + s_cnt[2]);
+		cs->n_defer += (unsigned long long)out.ndefer;
+		cs->n_slow += n_slow;
+		cs->n_cand += (unsigned long long)ncand;
+	}
+}
+
+/* ====================================================================== K2d
+ * Payload decode of the bursts that lie on the real chain: one workgroup per
+ * selected burst descriptor, one lane per byte.
+ */
+#define K2D_NT 256
+__global__ __launch_bounds__(K2D_NT)
+void k2d_payload(K2Params p)
+{
+	__shared__ unsigned s_slot;
+	unsigned n = p.ctl[CTL_STAGE];
+	n = n > p.stage_cap ? p.stage_cap : n;
+	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+		if (!p.stage_sel[i])
+			continue;
+		if (threadIdx.x == 0) {
+			unsigned slot = atomicAdd(p.ctl + CTL_OUT, 1u);
+			if (slot >= p.rec_cap) {
+				atomicAdd(p.ctl + CTL_OUT_OVF, 1u);
+				slot = 0xffffffffu;
+			}
+			s_slot = slot;
+			p.stage_sel[i] = 0;
+		}
+		__syncthreads();
+		const unsigned slot = s_slot;
+		if (slot != 0xffffffffu) {
+			const BurstDesc d = p.stage[i];
+			const int s = d.sc / VDL2_CS;
+			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
+			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc]);
+		}
+		__syncthreads();
 	}
 }
 
 /* ======================================================================= K3
- * Move the frames no channel has consumed yet (plus FIR history) to the front
- * of the other ping-pong buffer and rebase stream time.  Normally ~20 frames;
- * up to one full burst when a channel is waiting for the end of a long burst.
+ * Move the frames no channel has consumed yet (plus history) to the front of
+ * the other ping-pong plane set and rebase stream time.  Normally ~170 frames
+ * per plane; up to one full burst when a channel waits for the end of one.
  */
-#define K3_THREADS 1024
+#define K3_THREADS 256
 __global__ __launch_bounds__(K3_THREADS)
 void k3_compact(K3Params p)
 {
-	const int s = blockIdx.x;
-	StreamState *ss = p.ss + s;
-	__shared__ long long sh_base, sh_fill;
-	if (threadIdx.x == 0) {
-		long long mn = 0x7fffffffffffffffLL;
-		for (int c = 0; c < p.nbch; ++c) {
-			const long long q = p.cs[(size_t)s * VDL2_CS + c].pos;
-			mn = q < mn ? q : mn;
-		}
-		sh_base = ss->dec_base;
-		sh_fill = ss->dec_fill + p.J;
-		const long long end = sh_base + sh_fill;
-		long long nb = mn - VDL2_HIST;
-		if (nb > end - VDL2_HIST)
-			nb = end - VDL2_HIST;	/* always keep the FIR history */
-		if (nb < sh_base)
-			nb = sh_base;
-		ss->dec_base = nb;
-		ss->dec_fill = end - nb;
+	const int s = blockIdx.y, c = blockIdx.x;
+	const StreamState *ss = p.ss + s;
+	long long mn = 0x7fffffffffffffffLL;
+	for (int k = 0; k < p.nbch; ++k) {
+		const long long q = p.cs[(size_t)s * VDL2_CS + k].pos;
+		mn = q < mn ? q : mn;
 	}
-	__syncthreads();
-	const long long shift = ss->dec_base - sh_base;
-	const long long keep = ss->dec_fill;
-	const float4 *src = reinterpret_cast<const float4 *>(p.src + ((size_t)s * p.cap + shift) * VDL2_CS);
-	float4 *dst = reinterpret_cast<float4 *>(p.dst + (size_t)s * p.cap * VDL2_CS);
-	const long long n4 = keep * (VDL2_CS / 2);
-	for (long long i = threadIdx.x; i < n4; i += K3_THREADS)
+	const long long base = ss->dec_base;
+	const long long end = base + ss->dec_fill + p.J;
+	long long nb = mn - VDL2_HIST;
+	if (nb > end - VDL2_HIST)
+		nb = end - VDL2_HIST;	/* always keep the history */
+	if (nb < base)
+		nb = base;
+	const long long keep = end - nb;
+	const float2 *src = p.src + ((size_t)s * VDL2_CS + c) * p.cap + (nb - base);
+	float2 *dst = p.dst + ((size_t)s * VDL2_CS + c) * p.cap;
+	for (long long i = threadIdx.x; i < keep; i += K3_THREADS)
 		dst[i] = src[i];
+}
+
+/* runs after k3_compact (same stream): publish the new time base */
+__global__ void k3_rebase(K3Params p)
+{
+	const int s = blockIdx.x;
+	if (threadIdx.x != 0)
+		return;
+	StreamState *ss = p.ss + s;
+	long long mn = 0x7fffffffffffffffLL;
+	for (int k = 0; k < p.nbch; ++k) {
+		const long long q = p.cs[(size_t)s * VDL2_CS + k].pos;
+		mn = q < mn ? q : mn;
+	}
+	const long long base = ss->dec_base;
+	const long long end = base + ss->dec_fill + p.J;
+	long long nb = mn - VDL2_HIST;
+	if (nb > end - VDL2_HIST)
+		nb = end - VDL2_HIST;
+	if (nb < base)
+		nb = base;
+	ss->dec_base = nb;
+	ss->dec_fill = end - nb;
 }
 
 __global__ void k_atan2f(const float *y, const float *x, float *out, size_t n)

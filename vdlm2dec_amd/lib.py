@@ -16,13 +16,14 @@ FMT = {"cu8": 0, "cs16": 1, "cf32": 2, "f32": 3}
 SAMPLE_BYTES = {"cu8": 2, "cs16": 4, "cf32": 8, "f32": 4}
 MEM_HOST, MEM_DEVICE = 0, 1
 F_KEEP_DEC = 1
+F_SERIAL = 2
 
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
     "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
     "vdl2gpu_poll", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
-    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f",
+    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters",
 )
 
 
@@ -46,11 +47,12 @@ class BurstT(C.Structure):
 
 class StatsT(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples_in", "dec_samples", "sync_evals", "triggers",
-                                          "header_rejects", "bursts", "deferrals", "overflowed")]
+                                          "header_rejects", "bursts", "deferrals", "candidates", "serial_samples", "overflowed")]
 
 
 class TimingT(C.Structure):
-    _fields_ = [("channelise_ms", C.c_double), ("demod_ms", C.c_double), ("other_ms", C.c_double),
+    _fields_ = [("channelise_ms", C.c_double), ("demod_ms", C.c_double), ("scan_ms", C.c_double),
+                ("cluster_ms", C.c_double), ("resolve_ms", C.c_double), ("other_ms", C.c_double),
                 ("pushes", C.c_uint64), ("samples", C.c_uint64)]
 
 
@@ -115,5 +117,7 @@ def load():
     L.vdl2gpu_debug_lo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_atan2f.restype = C.c_int
     L.vdl2gpu_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2gpu_debug_counters.restype = C.c_int
+    L.vdl2gpu_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     _lib = L
     return L
