@@ -137,13 +137,24 @@ def main():
     first = []
     nbursts = 0
 
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd.demod import Burst
+    rawbuf = (_lib.BurstT * 16384)()
+
     def step(collect=None):
+        # one hand-off of resident samples + delivery of the decoded msgblk records to the host
         nonlocal nbursts
         rx.push_device(dbatch.data_ptr(), batch)
-        b = rx.poll(8192)
-        nbursts += len(b)
-        if collect is not None:
-            collect += b
+        while True:
+            n = rx.poll_raw(rawbuf, 16384)
+            nbursts += n
+            if collect is not None:
+                for i in range(n):
+                    b = rawbuf[i]
+                    collect.append(Burst(b.stream, b.chn, b.Fr, b.nbrow, b.nlbyte, b.df, b.ppm, b.trig_dec,
+                                         b.end_dec, b.trig_sample, b.end_sample, bytes(b.data)))
+            if n < 16384:
+                break
 
     for i in range(args.warmup):
         step(first if i == 0 else None)
@@ -215,7 +226,7 @@ def main():
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
                                            "candidates", "serial_samples", "overflowed")},
             "parity": parity,
-            "dbg": rx.debug_counters(),
+            "dbg": rx.debug_counters(24),
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos)

@@ -50,7 +50,12 @@ VDL2_HD float vdl2_u2f(uint32_t u)
 	return f;
 }
 
-/* atan(x) for finite or infinite x (NaN is not produced by the pipeline). */
+/* atan(x) for finite or infinite x (NaN is not produced by the pipeline).
+ * Written without data-dependent branches (selects only) so that a 64-lane
+ * wavefront does not serialise the four argument-reduction ranges; every
+ * selected expression is the reference's, so the result bits are unchanged:
+ * the unreduced range uses hi = lo = 0 and den = 1 (x/1 == x,
+ * 0 - ((t*s - 0) - t) == t - t*s exactly), and sign symmetry is exact. */
 VDL2_HD float vdl2_atanf(float x)
 {
 	/* breakpoints atan(0.5), atan(1), atan(1.5), atan(inf): hi + lo parts */
@@ -68,53 +73,23 @@ VDL2_HD float vdl2_atanf(float x)
 
 	const uint32_t hx = vdl2_f2u(x);
 	const uint32_t ix = hx & 0x7fffffffu;
-	const int neg = (int)(hx >> 31);
-	float hi, lo;
-	int reduced = 1;
-
-	if (ix >= 0x4c000000u) {	/* |x| >= 2^25: atan = +-pi/2 */
-		float r = hi3 + lo3;
-		return neg ? -r : r;
-	}
-	if (ix < 0x3ee00000u) {	/* |x| < 7/16: no reduction */
-		if (ix < 0x31000000u)	/* |x| < 2^-29: atan(x) == x in float */
-			return x;
-		reduced = 0;
-		hi = lo = 0.0f;
-	} else {
-		float ax = vdl2_u2f(ix);
-		if (ix < 0x3f980000u) {	/* |x| < 19/16 */
-			if (ix < 0x3f300000u) {	/* 7/16 <= |x| < 11/16 */
-				hi = hi0;
-				lo = lo0;
-				x = (2.0f * ax - 1.0f) / (2.0f + ax);
-			} else {
-				hi = hi1;
-				lo = lo1;
-				x = (ax - 1.0f) / (ax + 1.0f);
-			}
-		} else if (ix < 0x401c0000u) {	/* |x| < 39/16 */
-			hi = hi2;
-			lo = lo2;
-			x = (ax - 1.5f) / (1.0f + 1.5f * ax);
-		} else {
-			hi = hi3;
-			lo = lo3;
-			x = -1.0f / ax;
-		}
-	}
-	{
-		const float z = x * x;
-		const float w = z * z;
-		const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
-		const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
-		if (!reduced)
-			return x - x * (s1 + s2);
-		{
-			const float r = hi - ((x * (s1 + s2) - lo) - x);
-			return neg ? -r : r;
-		}
-	}
+	const float ax = vdl2_u2f(ix);
+	const int c0 = ix < 0x3ee00000u;	/* |x| < 7/16: no reduction */
+	const int c1 = ix < 0x3f300000u;	/* < 11/16 */
+	const int c2 = ix < 0x3f980000u;	/* < 19/16 */
+	const int c3 = ix < 0x401c0000u;	/* < 39/16 */
+	const float num = c0 ? ax : (c1 ? (2.0f * ax - 1.0f) : (c2 ? (ax - 1.0f) : (c3 ? (ax - 1.5f) : -1.0f)));
+	const float den = c0 ? 1.0f : (c1 ? (2.0f + ax) : (c2 ? (ax + 1.0f) : (c3 ? (1.0f + 1.5f * ax) : ax)));
+	const float hi = c0 ? 0.0f : (c1 ? hi0 : (c2 ? hi1 : (c3 ? hi2 : hi3)));
+	const float lo = c0 ? 0.0f : (c1 ? lo0 : (c2 ? lo1 : (c3 ? lo2 : lo3)));
+	const float t = num / den;
+	const float z = t * t;
+	const float w = z * z;
+	const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+	const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+	float r = hi - ((t * (s1 + s2) - lo) - t);
+	r = (ix >= 0x4c000000u) ? (hi3 + lo3) : r;	/* |x| >= 2^25: +-pi/2 */
+	return vdl2_u2f(vdl2_f2u(r) ^ (hx & 0x80000000u));
 }
 
 VDL2_HD float vdl2_atan2f(float y, float x)

@@ -61,7 +61,7 @@ struct vdl2gpu {
 	Cand *d_cands = nullptr;
 	Cluster *d_clusters = nullptr;
 	BurstDesc *d_stage = nullptr;
-	uint8_t *d_stage_sel = nullptr;
+	unsigned *d_sel_list = nullptr;
 	unsigned stage_cap = 0;
 	int force_serial = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -207,7 +207,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_cands);
 	(void)hipFree(h->d_clusters);
 	(void)hipFree(h->d_stage);
-	(void)hipFree(h->d_stage_sel);
+	(void)hipFree(h->d_sel_list);
 	(void)hipFree(h->d_dbg);
 	if (h->stream)
 		(void)hipStreamDestroy(h->stream);
@@ -244,8 +244,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_clusters, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
 	h->stage_cap = 131072u * (unsigned)S;
 	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
-	HIPCHK(h, hipMalloc(&h->d_stage_sel, h->stage_cap));
-	HIPCHK(h, hipMemsetAsync(h->d_stage_sel, 0, h->stage_cap, h->stream));
+	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)h->stage_cap * sizeof(unsigned)));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
@@ -463,12 +462,12 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.clusters = h->d_clusters;
 		k2.ctl = h->d_ctl;
 		k2.stage = h->d_stage;
-		k2.stage_sel = h->d_stage_sel;
+		k2.sel_list = h->d_sel_list;
 		k2.stage_cap = h->stage_cap;
 		k2.recs = h->d_recs;
 		k2.rec_cap = h->rec_cap;
 		k2.force_serial = h->force_serial;
-		k2.dbg = h->d_dbg;
+		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		hipLaunchKernelGGL(k2a_scan, dim3(tiles, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());

@@ -136,7 +136,7 @@ struct K2Params {
 	unsigned *ctl;		/* [0]=out count [1]=out overflow [2]=stage count [3]=k2b ticket [4]=stage overflow
 				 * [8 + S*8 ...] cand counts, then cand overflow flags */
 	BurstDesc *stage;	/* burst descriptors of all clusters */
-	uint8_t *stage_sel;
+	unsigned *sel_list;	/* descriptors on the real chain (K2c -> K2d) */
 	unsigned stage_cap;
 	vdl2gpu_burst_t *recs;
 	unsigned rec_cap;
@@ -148,6 +148,7 @@ struct K2Params {
 #define CTL_STAGE 2
 #define CTL_TICKET 3
 #define CTL_STAGE_OVF 4
+#define CTL_NSEL 5
 #define CTL_CAND0 8
 
 struct K3Params {
@@ -418,6 +419,7 @@ __device__ __forceinline__ float k2_soft_bit(int idx, int which, int pnbit)
  */
 #define K2_NT 256		/* workgroup size of the serial machine in the resolver */
 #define K2B_NT 64		/* one wavefront per burst cluster */
+#define VDL2_XT 256		/* samples in the LDS tile: >= 152+1 (ring), 16+2*64+1 (window), 16+7+65 (header) */
 
 /* receiver's byte schedule for a burst of nbrow rows / nlbyte bytes in the last row
  * (d8psk.c:117-206): ND data bytes then NF FEC bytes, column-major over the rows,
@@ -533,6 +535,8 @@ template <int NT> struct MachSharedT {
 	float errs[NT + 2];		/* errs[t+2] = err of eval t; [0],[1] = p2err, perr */
 	float frs[NT + 1];		/* frs[t+1] = slope of eval t; [0] = pfr */
 	float psym[12];			/* header symbol phases */
+	float2 xt[VDL2_XT];		/* LDS tile of the channel's samples (cluster mode) */
+	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45), zero padded */
 	float hsoft[25];		/* descrambled header soft bits */
 	uint8_t vbk[26][32], vbv[26][32];	/* Viterbi back pointers / decided bits */
 	int first;
@@ -547,6 +551,9 @@ struct MachCtx {
 	vdl2gpu_burst_t *recs;	/* sink: output ring, payload decoded at once (K2c serial stretches) ... */
 	BurstDesc *desc;	/* ... or descriptor pool, payload decoded by K2d if selected (K2b) */
 	int sc;
+	unsigned long long *dbg;
+	long long t_lo, t_hi;	/* stream-time range currently held in the LDS tile (cluster mode) */
+	const float *grey;	/* 3 x 257 soft-bit tables in LDS, or nullptr -> constant memory */
 	unsigned *rec_count, *rec_ovf;
 	unsigned rec_cap;
 	int stream;
@@ -565,6 +572,71 @@ struct MachOut {
 };
 
 enum { MR_END = 0, MR_DEFER = 1, MR_STEADY = 2, MR_LIMIT = 3 };
+
+#define VDL2_PN_HEAD 0xa423d8c8u	/* first 32 scrambler bits from seed 0x4D4B (d8psk.c:54-65, 299) */
+
+__device__ __forceinline__ float mach_soft_bit(const MachCtx &cx, int idx, int which, int pnbit)
+{
+	const float v = cx.grey ? cx.grey[which * 257 + idx]
+				: d_tab(which == 0 ? c_grey1 : (which == 1 ? c_grey2 : c_grey3), idx);
+	return pnbit ? (float)(1.0 - (double)v) : v;	/* descrambler, d8psk.c:60-63 */
+}
+
+
+/* XL = true: all sample reads of the machine go through the LDS tile sh.xt, which
+ * mach_need() (re)fills from the channel plane whenever the next phase of work leaves it;
+ * XL = false: samples are read from the plane in HBM/L2 directly. */
+template <int NT, bool XL> __device__ __forceinline__ void mach_need(MachSharedT<NT> &sh, MachCtx &cx, long long lo, long long hi)
+{
+	if (!XL)
+		return;
+	if (lo >= cx.t_lo && hi <= cx.t_hi)
+		return;		/* uniform: cx is the same in every lane */
+	__syncthreads();
+	long long cnt = cx.avail_end - lo;
+	cnt = cnt > VDL2_XT ? VDL2_XT : cnt;
+	const float2 *src = cx.x + (lo - cx.dec_base);
+	for (int i = threadIdx.x; i < (int)cnt; i += NT)
+		sh.xt[i] = src[i];
+	cx.t_lo = lo;
+	cx.t_hi = lo + (cnt > 0 ? cnt : 0);
+	__syncthreads();
+}
+
+template <int NT> __device__ __forceinline__ void mach_init_taps(MachSharedT<NT> &sh)
+{
+	for (int i = threadIdx.x; i < 72; i += NT)
+		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	__syncthreads();
+}
+
+/* filteredphase() at the sample of stream time n with first tap `tap0` (d8psk.c:219-230) */
+template <int NT, bool XL> __device__ __forceinline__ float mach_fir(const MachSharedT<NT> &sh, const MachCtx &cx, long long n, int tap0)
+{
+	float2 v[17];
+	if (XL) {
+		const float2 *x = &sh.xt[(int)(n - 16 - cx.t_lo)];
+#pragma unroll
+		for (int j = 0; j < 17; ++j)
+			v[j] = x[j];
+	} else {
+		const float2 *x = cx.x + (n - 16 - cx.dec_base);
+#pragma unroll
+		for (int j = 0; j < 17; ++j)
+			v[j] = x[j];
+	}
+	float sr = 0.0f, si = 0.0f;
+#pragma unroll
+	for (int j = 0; j < 17; ++j) {
+		const int i = tap0 + 4 * j;
+		if (i < 65) {
+			const float m = sh.smf[i];
+			sr += v[j].x * m;
+			si += v[j].y * m;
+		}
+	}
+	return vdl2_atan2f(si, sr);
+}
 
 template <int NT> __device__ __forceinline__ void mach_load(MachSharedT<NT> &sh, const ChanState *cs)
 {
@@ -622,12 +694,13 @@ template <int NT> __device__ __forceinline__ void mach_shift_ring(MachSharedT<NT
 /* Build the detector state at a history-free instant (n, r): the ring holds the
  * free-running phases of the previous 68 evaluations and perr/p2err/pfr are
  * those of evaluations n-2 and n-4.  Needs samples back to n-152. */
-template <int NT> __device__ __forceinline__ void mach_materialize(MachSharedT<NT> &sh, const MachCtx &cx, long long n, int r)
+template <int NT, bool XL> __device__ __forceinline__ void mach_materialize(MachSharedT<NT> &sh, MachCtx &cx, long long n, int r)
 {
 	const int tid = threadIdx.x;
+	mach_need<NT, XL>(sh, cx, n - 152, n + 1);
 	for (int i = tid; i < VDL2_NPH; i += NT) {
 		const long long q = n - 2LL * (VDL2_NPH - i);
-		sh.pbuf[i] = k2_fir_phase(cx.x + (q - 16 - cx.dec_base), r);
+		sh.pbuf[i] = mach_fir<NT, XL>(sh, cx, q, r);
 	}
 	__syncthreads();
 	if (tid < 2) {
@@ -642,7 +715,7 @@ template <int NT> __device__ __forceinline__ void mach_materialize(MachSharedT<N
 
 /* stop_steady: return MR_STEADY as soon as the detector is history-free and at least
  * `min_trig` triggers were handled.  first_nev: size of the first search window (a hint). */
-template <int NT> __device__ int machine_run(MachSharedT<NT> &sh, const MachCtx &cx, MachState &st, bool stop_steady,
+template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachCtx &cx, MachState &st, bool stop_steady,
 					     int min_trig, int max_bursts, int first_nev, MachOut &out)
 {
 	const int tid = threadIdx.x;
@@ -673,8 +746,9 @@ template <int NT> __device__ int machine_run(MachSharedT<NT> &sh, const MachCtx 
 			nev = nev < need ? nev : need;
 		}
 		/* ---- search window: evaluations at pos, pos+2, ... */
+		mach_need<NT, XL>(sh, cx, pos - 16, pos + 2LL * nev);
 		if (tid < nev)
-			sh.pbuf[VDL2_NPH + tid] = k2_fir_phase(x0 + (pos + 2 * tid - 16), r);
+			sh.pbuf[VDL2_NPH + tid] = mach_fir<NT, XL>(sh, cx, pos + 2 * tid, r);
 		if (tid == 0)
 			sh.first = 0x7fffffff;
 		__syncthreads();
@@ -725,16 +799,17 @@ template <int NT> __device__ int machine_run(MachSharedT<NT> &sh, const MachCtx 
 		bool defer = (nsym0 + 64 >= cx.avail_end);	/* 9 header symbols must be present */
 		int accepted = 0, nbrow = 0, nlbyte = 0, nsym = 0;
 		if (!defer) {
+			mach_need<NT, XL>(sh, cx, nstar - 16, nsym0 + 65);
 			if (tid < 9)
-				sh.psym[tid] = k2_fir_phase(x0 + (nsym0 + 8 * tid - 16), rb);
+				sh.psym[tid] = mach_fir<NT, XL>(sh, cx, nsym0 + 8 * tid, rb);
 			if (tid == 9)
-				sh.fctl[1] = k2_fir_phase(x0 + (nstar - 16), clk0);	/* P1 */
+				sh.fctl[1] = mach_fir<NT, XL>(sh, cx, nstar, clk0);	/* P1 */
 			__syncthreads();
 			if (tid < 25) {
 				const int k = tid / 3;
 				const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
 				const int idx = k2_grey_index(sh.psym[k], pprev, df);
-				float v = k2_soft_bit(idx, tid % 3, cx.pn[tid]);
+				float v = mach_soft_bit(cx, idx, tid % 3, (int)((VDL2_PN_HEAD >> tid) & 1u));
 				if (tid < 3)
 					v = 0.0f;	/* reserved bits forced, d8psk.c:81-82 */
 				sh.hsoft[tid] = v;
@@ -838,10 +913,12 @@ template <int NT> __device__ int machine_run(MachSharedT<NT> &sh, const MachCtx 
 			}
 			__syncthreads();
 			const unsigned slot = (unsigned)sh.ctl[6];
-			if (!cx.desc && slot != 0xffffffffu)
+			if (!XL && !cx.desc && slot != 0xffffffffu)
 				burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg);
-			if (out.nslots < VDL2_CL_MAXB)
-				out.slots[out.nslots] = (int)slot;
+#pragma unroll
+			for (int i = 0; i < VDL2_CL_MAXB; ++i)
+				if (out.nslots == i)
+					out.slots[i] = (int)slot;
 			out.nslots++;
 			out.nburst++;
 		}
@@ -868,6 +945,9 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 	cx.avail_end = ss->dec_base + ss->dec_fill + p.J;
 	cx.pn = p.pn;
 	cx.sc = s * VDL2_CS + c;
+	cx.dbg = to_stage ? p.dbg : nullptr;
+	cx.t_lo = cx.t_hi = 0;
+	cx.grey = nullptr;
 	if (to_stage) {
 		cx.recs = nullptr;
 		cx.desc = p.stage;
@@ -981,26 +1061,45 @@ __global__ __launch_bounds__(K2B_NT)
 void k2b_clusters(K2Params p)
 {
 	__shared__ MachSharedT<K2B_NT> sh;
+	__shared__ float sgrey[3 * 257];
 	__shared__ int s_ticket;
+	__shared__ unsigned s_pref[65];
 	const int tid = threadIdx.x;
 	const int nsc = p.nstreams * VDL2_CS;
 	if (p.force_serial)
 		return;
+	for (int i = tid; i < 257; i += K2B_NT) {
+		sgrey[i] = d_tab(c_grey1, i);
+		sgrey[257 + i] = d_tab(c_grey2, i);
+		sgrey[514 + i] = d_tab(c_grey3, i);
+	}
+	mach_init_taps(sh);
+	/* exclusive prefix of the (clamped) candidate counts; nsc <= 64 in one pass per 64 */
+	if (tid == 0) {
+		unsigned acc = 0;
+		for (int k = 0; k < nsc && k < 64; ++k) {
+			unsigned n = p.ctl[CTL_CAND0 + k];
+			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
+			s_pref[k] = acc;
+			acc += n;
+		}
+		s_pref[nsc < 64 ? nsc : 64] = acc;
+	}
+	__syncthreads();
+	const int nsc64 = nsc < 64 ? nsc : 64;
+	const unsigned total = s_pref[nsc64];
 	for (;;) {
 		if (tid == 0)
 			s_ticket = (int)atomicAdd(p.ctl + CTL_TICKET, 1u);
 		__syncthreads();
-		int idx = s_ticket;
-		int sc = 0;
-		for (; sc < nsc; ++sc) {
-			unsigned n = p.ctl[CTL_CAND0 + sc];
-			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
-			if (idx < (int)n)
-				break;
-			idx -= (int)n;
-		}
-		if (sc >= nsc)
+		const unsigned tk = (unsigned)s_ticket;
+		__syncthreads();
+		if (tk >= total)
 			break;
+		int sc = 0;
+		while (sc + 1 < nsc64 && s_pref[sc + 1] <= tk)
+			++sc;
+		const int idx = (int)(tk - s_pref[sc]);
 		const int s = sc / VDL2_CS, c = sc % VDL2_CS;
 		MachCtx cx;
 		mach_ctx(cx, p, s, c, true);
@@ -1010,15 +1109,19 @@ void k2b_clusters(K2Params p)
 		st.pos = cx.dec_base + cd.nrel;
 		st.r = cd.r;
 		st.fresh = VDL2_STEADY;
+		cx.grey = sgrey;
 		MachOut out;
 		out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
 		out.neval = 0;
+#pragma unroll
+		for (int i = 0; i < VDL2_CL_MAXB; ++i)
+			out.slots[i] = 0;
 		const long long t0 = wall_clock64();
-		mach_materialize(sh, cx, st.pos, st.r);
+		mach_materialize<K2B_NT, true>(sh, cx, st.pos, st.r);
 		const long long t1 = wall_clock64();
-		const int rc = machine_run(sh, cx, st, true, 1, VDL2_CL_MAXB, 1, out);
+		const int rc = machine_run<K2B_NT, true>(sh, cx, st, true, 1, VDL2_CL_MAXB, 1, out);
 		const long long t2 = wall_clock64();
-		if (tid == 0 && p.dbg) {
+		if (tid == 0 && p.dbg && (tk & 15u) == 0) {
 			atomicAdd(p.dbg + 0, (unsigned long long)(t1 - t0));
 			atomicAdd(p.dbg + 1, (unsigned long long)(t2 - t1));
 			atomicAdd(p.dbg + 2, 1ull);
@@ -1036,9 +1139,10 @@ void k2b_clusters(K2Params p)
 		else
 			status = CL_NONSTEADY;
 		bool bad = false;
-		for (int i = 0; i < out.nslots && i < VDL2_CL_MAXB; ++i)
-			if (out.slots[i] < 0)
-				bad = true;	/* staging pool full */
+#pragma unroll
+		for (int i = 0; i < VDL2_CL_MAXB; ++i)
+			if (i < out.nslots && out.slots[i] < 0)
+				bad = true;	/* descriptor pool full */
 		if (bad)
 			status = CL_INVALID;
 		if (status == CL_NONSTEADY)
@@ -1048,8 +1152,9 @@ void k2b_clusters(K2Params p)
 			cl->r_s = st.r;
 			cl->n_s = st.pos;
 			cl->nslots = out.nslots < VDL2_CL_MAXB ? out.nslots : VDL2_CL_MAXB;
+#pragma unroll
 			for (int i = 0; i < VDL2_CL_MAXB; ++i)
-				cl->slots[i] = out.slots[i < out.nslots ? i : 0];
+				cl->slots[i] = out.slots[i];
 			cl->ntrig = out.ntrig;
 			cl->nrej = out.nrej;
 			cl->nburst = out.nburst;
@@ -1097,6 +1202,7 @@ void k2c_resolve(K2Params p)
 {
 	__shared__ MachSharedT<K2_NT> sh;
 	__shared__ int skey[VDL2_CAND_CAP];		/* sorted keys: nrel*4 + r */
+	__shared__ unsigned long long sbuf[VDL2_CAND_CAP];	/* sort buffer */
 	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
 	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
 	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
@@ -1113,6 +1219,7 @@ void k2c_resolve(K2Params p)
 	st.pos = cs->pos;
 	st.r = cs->r;
 	st.fresh = cs->fresh;
+	mach_init_taps(sh);
 	mach_load(sh, cs);
 	MachOut out;
 	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
@@ -1124,31 +1231,38 @@ void k2c_resolve(K2Params p)
 		ncand = 0;
 	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
 	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
-	/* 1. rank sort (keys are unique: one candidate per (n, r)) */
+	/* 1. sort the candidates by time: bitonic network on (key << 16 | index) in LDS */
 	const long long pos_in = st.pos;
-	for (int i = tid; i < ncand; i += K2_NT)
-		skey[i] = cands[i].nrel * 4 + cands[i].r;
+	const long long tk0 = wall_clock64();
+	int npow = 1;
+	while (npow < ncand)
+		npow <<= 1;
+	for (int i = tid; i < npow; i += K2_NT)
+		sbuf[i] = (i < ncand) ? (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i
+				      : ~0ull;
 	__syncthreads();
-	{
-		/* ranks computed against the unsorted array, then scattered in two phases */
-		int myk[VDL2_CAND_CAP / K2_NT], myr[VDL2_CAND_CAP / K2_NT];
-#pragma unroll 1
-		for (int t = 0, i = tid; i < ncand; i += K2_NT, ++t) {
-			const int k = skey[i];
-			int rank = 0;
-			for (int j = 0; j < ncand; ++j)
-				rank += (skey[j] < k) ? 1 : 0;
-			myk[t] = k;
-			myr[t] = rank;
+	for (int k = 2; k <= npow; k <<= 1)
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			for (int i = tid; i < npow; i += K2_NT) {
+				const int l = i ^ j;
+				if (l > i) {
+					const unsigned long long a0 = sbuf[i], b0 = sbuf[l];
+					const bool up = ((i & k) == 0);
+					if ((a0 > b0) == up) {
+						sbuf[i] = b0;
+						sbuf[l] = a0;
+					}
+				}
+			}
+			__syncthreads();
 		}
-		__syncthreads();
-#pragma unroll 1
-		for (int t = 0, i = tid; i < ncand; i += K2_NT, ++t) {
-			skey[myr[t]] = myk[t];
-			sidx[myr[t]] = (unsigned short)i;
-		}
+	for (int i = tid; i < ncand; i += K2_NT) {
+		const unsigned long long v = sbuf[i];
+		skey[i] = (int)(v >> 16);
+		sidx[i] = (unsigned short)(v & 0xffffu);
 	}
 	__syncthreads();
+	const long long tk1 = wall_clock64();
 	/* 2. successor table */
 	for (int j = tid; j < ncand; j += K2_NT) {
 		const Cluster *cl = clusters + sidx[j];
@@ -1161,12 +1275,13 @@ void k2c_resolve(K2Params p)
 		ssel[j] = 0;
 	}
 	__syncthreads();
+	const long long tk2 = wall_clock64();
 	bool steady_end = false;
 	for (;;) {
 		if (!tables_ok || st.fresh < VDL2_STEADY) {
 			/* history-dependent stretch (or no tables): serial machine */
 			const long long p0 = st.pos;
-			const int rc = machine_run(sh, cx, st, tables_ok, 0, 1 << 30, 0, out);
+			const int rc = machine_run<K2_NT, false>(sh, cx, st, tables_ok, 0, 1 << 30, 0, out);
 			n_slow += (unsigned long long)(st.pos - p0);
 			if (rc != MR_STEADY)
 				break;
@@ -1219,8 +1334,8 @@ void k2c_resolve(K2Params p)
 		if (status == CL_INVALID) {
 			/* staging pool was full: replay this stretch here */
 			st.pos = ncand_t;
-			mach_materialize(sh, cx, st.pos, st.r);
-			const int rc = machine_run(sh, cx, st, true, 1, 1 << 30, 1, out);
+			mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
+			const int rc = machine_run<K2_NT, false>(sh, cx, st, true, 1, 1 << 30, 1, out);
 			if (rc != MR_STEADY)
 				break;
 			continue;
@@ -1234,6 +1349,7 @@ void k2c_resolve(K2Params p)
 		st.fresh = cl->saved.fresh < VDL2_STEADY ? cl->saved.fresh : VDL2_STEADY - 1;
 	}
 	__syncthreads();
+	const long long tk3 = wall_clock64();
 	/* 4. publish the visited clusters */
 	if (tid < 4)
 		s_cnt[tid] = 0;
@@ -1245,7 +1361,7 @@ void k2c_resolve(K2Params p)
 				const Cluster *cl = clusters + sidx[j];
 				const int ns = cl->nslots;
 				for (int i = 0; i < ns; ++i)
-					p.stage_sel[cl->slots[i]] = 1;
+					p.sel_list[atomicAdd(p.ctl + CTL_NSEL, 1u)] = (unsigned)cl->slots[i];
 				a += cl->ntrig;
 				b += cl->nrej;
 				d += cl->nburst;
@@ -1259,7 +1375,7 @@ void k2c_resolve(K2Params p)
 	}
 	__syncthreads();
 	if (steady_end) {
-		mach_materialize(sh, cx, st.pos, st.r);
+		mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
 		st.fresh = VDL2_STEADY;
 	}
 	__syncthreads();
@@ -1272,6 +1388,14 @@ void k2c_resolve(K2Params p)
 		cs->n_defer += (unsigned long long)out.ndefer;
 		cs->n_slow += n_slow;
 		cs->n_cand += (unsigned long long)ncand;
+		if (p.dbg) {
+			const long long tk4 = wall_clock64();
+			atomicAdd(p.dbg + 16, (unsigned long long)(tk1 - tk0));
+			atomicAdd(p.dbg + 17, (unsigned long long)(tk2 - tk1));
+			atomicAdd(p.dbg + 18, (unsigned long long)(tk3 - tk2));
+			atomicAdd(p.dbg + 19, (unsigned long long)(tk4 - tk3));
+			atomicAdd(p.dbg + 20, 1ull);
+		}
 	}
 }
 
@@ -1284,11 +1408,9 @@ __global__ __launch_bounds__(K2D_NT)
 void k2d_payload(K2Params p)
 {
 	__shared__ unsigned s_slot;
-	unsigned n = p.ctl[CTL_STAGE];
+	unsigned n = p.ctl[CTL_NSEL];
 	n = n > p.stage_cap ? p.stage_cap : n;
 	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-		if (!p.stage_sel[i])
-			continue;
 		if (threadIdx.x == 0) {
 			unsigned slot = atomicAdd(p.ctl + CTL_OUT, 1u);
 			if (slot >= p.rec_cap) {
@@ -1296,12 +1418,11 @@ void k2d_payload(K2Params p)
 				slot = 0xffffffffu;
 			}
 			s_slot = slot;
-			p.stage_sel[i] = 0;
 		}
 		__syncthreads();
 		const unsigned slot = s_slot;
 		if (slot != 0xffffffffu) {
-			const BurstDesc d = p.stage[i];
+			const BurstDesc d = p.stage[p.sel_list[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
 			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc]);

@@ -129,6 +129,10 @@ class Receiver:
             if n < max_bursts:
                 return out
 
+    def poll_raw(self, buf, max_bursts: int) -> int:
+        """vdl2gpu_poll into a caller-owned (lib.BurstT * max_bursts) array; no Python objects."""
+        return self._check(self.L.vdl2gpu_poll(self.h, buf, max_bursts))
+
     def run(self, raw: np.ndarray, block: Optional[int] = None) -> List[Burst]:
         """Feed a whole recording in ``block``-sample hand-offs and return every burst."""
         a = np.ascontiguousarray(raw)
