@@ -435,15 +435,40 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
-		const unsigned gx = (unsigned)((J + 1 + per_block - 1) / per_block);
-		const dim3 grid(gx, (unsigned)h->S);
 		const size_t smem = ((size_t)(h->L + h->maxwin) * VDL2_CS + (size_t)K1_OPB * h->maxwin) * sizeof(float2);
-		switch (h->cfg.fmt) {
-		case VDL2GPU_FMT_CU8: launch_k1<VDL2GPU_FMT_CU8>(k1, grid, smem, h->stream); break;
-		case VDL2GPU_FMT_CS16: launch_k1<VDL2GPU_FMT_CS16>(k1, grid, smem, h->stream); break;
-		case VDL2GPU_FMT_CF32: launch_k1<VDL2GPU_FMT_CF32>(k1, grid, smem, h->stream); break;
-		default: launch_k1<VDL2GPU_FMT_F32R>(k1, grid, smem, h->stream); break;
-		}
+		auto generic = [&](long long jbeg, long long jend) {
+			if (jend < jbeg)
+				return;
+			K1Params q = k1;
+			q.jbeg = jbeg;
+			q.jend = jend;
+			const unsigned gx = (unsigned)((jend - jbeg + 1 + per_block - 1) / per_block);
+			const dim3 grid(gx, (unsigned)h->S);
+			switch (h->cfg.fmt) {
+			case VDL2GPU_FMT_CU8: launch_k1<VDL2GPU_FMT_CU8>(q, grid, smem, h->stream); break;
+			case VDL2GPU_FMT_CS16: launch_k1<VDL2GPU_FMT_CS16>(q, grid, smem, h->stream); break;
+			case VDL2GPU_FMT_CF32: launch_k1<VDL2GPU_FMT_CF32>(q, grid, smem, h->stream); break;
+			default: launch_k1<VDL2GPU_FMT_F32R>(q, grid, smem, h->stream); break;
+			}
+		};
+		const long long periods = J / K1F_PER_OUT;
+		const bool fast = (h->sdrclk == 500 && h->L == 80 && periods >= 4 && !getenv("VDL2GPU_NO_K1_FAST"));
+		if (fast) {
+			/* whole 1 ms periods in the middle on the register-resident fast path; the first
+			 * period (carried partial window) and the tail on the general kernel */
+			k1.per_lo = 1;
+			k1.per_n = periods - 2;
+			generic(0, K1F_PER_OUT - 1);
+			const dim3 grid((unsigned)((k1.per_n + K1F_PB - 1) / K1F_PB) * K1F_ROLES, (unsigned)h->S);
+			switch (h->cfg.fmt) {
+			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CS16>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			}
+			generic((periods - 1) * K1F_PER_OUT, J);
+		} else
+			generic(0, J);
 		HIPCHK(h, hipGetLastError());
 	}
 	HIPCHK(h, hipEventRecord(pt.e[1], h->stream));

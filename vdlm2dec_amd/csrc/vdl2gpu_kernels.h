@@ -116,6 +116,8 @@ struct K1Params {
 	int sdrclk, L, maxwin;
 	int c0, no0, nf0, parity;
 	long long N, J;
+	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
+	long long per_lo, per_n;	/* fast kernel: whole 84-output periods [per_lo, per_lo+per_n) */
 	const float2 *lo;	/* [S][8][L] */
 	float2 *dec;		/* this push's planes, [S][8][cap] */
 	long long cap;
@@ -229,8 +231,8 @@ void k1_channelise(K1Params p)
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
 	StreamState *ss = p.ss + s;
 	const long long fill = ss->dec_fill;
-	const long long jb = (long long)blockIdx.x * (K1_OPB * K1_PASSES);
-	if (blockIdx.x == 0 && tid == 0) {
+	const long long jb = p.jbeg + (long long)blockIdx.x * (K1_OPB * K1_PASSES);
+	if (blockIdx.x == 0 && tid == 0 && p.jbeg == 0) {
 		ss->last_fill = fill;
 		ss->last_J = p.J;
 	}
@@ -240,9 +242,9 @@ void k1_channelise(K1Params p)
 	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill;
 	for (int pass = 0; pass < K1_PASSES; ++pass) {
 		const long long jp = jb + (long long)pass * K1_OPB;
-		if (jp > p.J)
+		if (jp > p.jend)
 			break;
-		const long long jhi = (jp + K1_OPB - 1 < p.J) ? jp + K1_OPB - 1 : p.J;
+		const long long jhi = (jp + K1_OPB - 1 < p.jend) ? jp + K1_OPB - 1 : p.jend;
 		const long long in_lo = (jp == 0) ? 0 : k1_win_end(jp - 1, p.sdrclk, p.c0) + 1;
 		const long long in_hi = (jhi == p.J) ? p.N - 1 : k1_win_end(jhi, p.sdrclk, p.c0);
 		const int cnt = (int)(in_hi - in_lo + 1);
@@ -251,7 +253,7 @@ void k1_channelise(K1Params p)
 			xs[i] = k1_load<FMT>(raw, in_lo + i);
 		__syncthreads();
 		const long long j = jp + o;
-		if (j <= p.J && c < p.nbch) {
+		if (j <= p.jend && c < p.nbch) {
 			const long long a = (j == 0) ? 0 : k1_win_end(j - 1, p.sdrclk, p.c0) + 1;
 			const long long b = (j == p.J) ? p.N - 1 : k1_win_end(j, p.sdrclk, p.c0);
 			const int n = (int)(b - a + 1);
@@ -287,6 +289,172 @@ void k1_channelise(K1Params p)
 			} else {
 				const float fn = (float)nf;
 				dec[j] = make_float2(dre / fn, dim / fn);
+			}
+		}
+	}
+}
+
+
+/* ---- K1 fast path: SDRINRATE 2 MS/s (SDRCLK 500, LO period 80) ------------------------
+ * The dump schedule and the LO phase repeat every 2000 inputs = 84 outputs (1 ms of air
+ * time).  One WAVEFRONT owns 8 consecutive windows of the period x 8 channels (lane =
+ * window*8 + channel) for many periods.  A lane's 23/24 LO values never change, so they
+ * live in VGPRs; the ~190 samples the wave's 8 windows cover are fetched by the wave itself
+ * (3 coalesced loads per lane), converted once, and parked in a private double-buffered LDS
+ * slice, from which each sample is read once per window and broadcast to the 8 channel
+ * lanes.  Inner loop: 1 LDS read + 8 VALU ops per sample and channel.  No workgroup
+ * barrier anywhere: wavefronts never wait for each other, 16 of them per CU hide HBM latency.
+ * 84 = 10*8 + 4, so 11 wave roles cover a period (the last one half empty). */
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+/* (re, im) += x * w for complex x, w with the reference's operation order
+ *   pr = x.re*w.re - x.im*w.im;  pi = x.re*w.im + x.im*w.re;  acc += (pr, pi)
+ * as four packed-FP32 VALU ops (gfx950 issues plain FP32 at half the packed rate):
+ *   a = (x.re*w.re, x.re*w.im)          v_pk_mul_f32, op_sel picks x.re twice
+ *   b = (x.im*(-w.im), x.im*w.re)       v_pk_mul_f32, halves of w swapped, low lane negated
+ *   acc += (a + b)                      2 x v_pk_add_f32
+ * a.lo + b.lo = x.re*w.re + (-(x.im*w.im)) is bit-identical to the subtraction. */
+__device__ __forceinline__ void k1_cmac(v2f &acc, v2f x, v2f w)
+{
+	v2f a, b;
+	asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+	    "v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+	    : "=&v"(a), "=&v"(b)
+	    : "v"(x), "v"(w));
+	acc += (a + b);
+}
+
+#define K1F_THREADS 64
+#define K1F_PB 32		/* periods per wavefront */
+#define K1F_DEPTH 4		/* periods of raw samples in flight per wavefront (registers) */
+#define K1F_PER_IN 2000
+#define K1F_PER_OUT 84
+#define K1F_ROLES 11
+#define K1F_SLICE 192		/* >= 8 windows x 24 samples */
+
+template <int FMT> struct K1Raw;
+template <> struct K1Raw<VDL2GPU_FMT_CU8> { typedef unsigned short T; };
+template <> struct K1Raw<VDL2GPU_FMT_CS16> { typedef unsigned int T; };
+template <> struct K1Raw<VDL2GPU_FMT_CF32> { typedef float2 T; };
+template <> struct K1Raw<VDL2GPU_FMT_F32R> { typedef float T; };
+
+template <int FMT> __device__ __forceinline__ typename K1Raw<FMT>::T k1_raw_load(const char *raw, long long i)
+{
+	return reinterpret_cast<const typename K1Raw<FMT>::T *>(raw)[i];
+}
+
+template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<FMT>::T v)
+{
+	if constexpr (FMT == VDL2GPU_FMT_CU8) {
+		return make_float2((float)(v & 0xffu) - (float)127.37, (float)(v >> 8) - (float)127.37);
+	} else if constexpr (FMT == VDL2GPU_FMT_CS16) {
+		return make_float2((float)(short)(v & 0xffffu), (float)(short)(v >> 16));
+	} else if constexpr (FMT == VDL2GPU_FMT_CF32) {
+		return v;
+	} else {
+		return make_float2(v, 0.0f);
+	}
+}
+
+template <int FMT> __global__ __launch_bounds__(K1F_THREADS)
+void k1_fast(K1Params p)
+{
+	typedef typename K1Raw<FMT>::T raw_t;
+	__shared__ float2 xs[K1F_SLICE];
+	const int lane = threadIdx.x;
+	const int s = blockIdx.y;
+	const int g = blockIdx.x % K1F_ROLES;
+	const long long pp0 = p.per_lo + (long long)(blockIdx.x / K1F_ROLES) * K1F_PB;
+	long long npl = p.per_lo + p.per_n - pp0;
+	npl = npl > K1F_PB ? K1F_PB : npl;
+	if (npl <= 0)
+		return;
+	const int np = (int)npl;
+	const int kk = lane >> 3, c = lane & 7;
+	const int k = g * 8 + kk;
+	const bool active = (k < K1F_PER_OUT) && (c < p.nbch);
+	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
+	const long long fill = p.ss[s].dec_fill;
+	/* slice of this wave in period pp0: from the first sample of window 8g to the last of window 8g+7 */
+	const long long j0 = pp0 * K1F_PER_OUT + g * 8;		/* >= 84 */
+	const int klast = (g * 8 + 7 < K1F_PER_OUT) ? 7 : (K1F_PER_OUT - 1 - g * 8);
+	const long long sbase = k1_win_end(j0 - 1, p.sdrclk, p.c0) + 1;
+	const int slen = (int)(k1_win_end(j0 + klast, p.sdrclk, p.c0) - sbase + 1);
+	int off = 0, nwin = 0;
+	v2f w[24];
+#pragma unroll
+	for (int t = 0; t < 24; ++t)
+		w[t] = (v2f){0.0f, 0.0f};
+	if (active) {
+		const long long j = j0 + kk;
+		const long long a = k1_win_end(j - 1, p.sdrclk, p.c0) + 1;
+		const long long b = k1_win_end(j, p.sdrclk, p.c0);
+		off = (int)(a - sbase);
+		nwin = (int)(b - a + 1);
+		int ph = (int)((p.no0 + a) % 80);
+		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + c) * 80;
+#pragma unroll
+		for (int t = 0; t < 24; ++t) {
+			const float2 q = lo[ph];
+			w[t] = (v2f){q.x, q.y};
+			ph = (ph + 1 == 80) ? 0 : ph + 1;
+		}
+	}
+	const float fn = (float)nwin;
+	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill + pp0 * K1F_PER_OUT + k;
+	/* lanes fetch samples lane, lane+64, lane+128 of the slice (clamped: the tail lanes of the
+	 * last load re-read the last sample instead of branching) */
+	int li[3];
+#pragma unroll
+	for (int u = 0; u < 3; ++u) {
+		const int i = lane + u * 64;
+		li[u] = i < slen ? i : slen - 1;
+	}
+	raw_t rr[K1F_DEPTH][3];
+#pragma unroll
+	for (int d = 0; d < K1F_DEPTH; ++d)
+#pragma unroll
+		for (int u = 0; u < 3; ++u)
+			rr[d][u] = k1_raw_load<FMT>(raw, sbase + (long long)K1F_PER_IN * (d < np ? d : np - 1) + li[u]);
+	for (int q0 = 0; q0 < np; q0 += K1F_DEPTH) {
+#pragma unroll
+		for (int d = 0; d < K1F_DEPTH; ++d) {
+			const int q = q0 + d;
+			if (q < np) {
+				/* period q: registers -> float -> LDS slice, then refill the registers
+				 * with period q+DEPTH so that DEPTH periods stay in flight */
+#pragma unroll
+				for (int u = 0; u < 3; ++u)
+					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
+				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
+#pragma unroll
+				for (int u = 0; u < 3; ++u)
+					rr[d][u] = k1_raw_load<FMT>(raw, sbase + (long long)K1F_PER_IN * qn + li[u]);
+				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
+				if (active) {
+					const v2f *xp = reinterpret_cast<const v2f *>(&xs[off]);
+					v2f acc = {0.0f, 0.0f};
+					if (FMT == VDL2GPU_FMT_F32R) {
+#pragma unroll
+						for (int t = 0; t < 23; ++t) {
+							const float x = xp[t].x;
+							acc += (v2f){x, x} * w[t];
+						}
+						if (nwin == 24) {
+							const float x = xp[23].x;
+							acc += (v2f){x, x} * w[23];
+						}
+					} else {
+#pragma unroll
+						for (int t = 0; t < 23; ++t)
+							k1_cmac(acc, xp[t], w[t]);
+						if (nwin == 24)
+							k1_cmac(acc, xp[23], w[23]);
+					}
+					const v2f res = acc / (v2f){fn, fn};
+					dec[(long long)q * K1F_PER_OUT] = make_float2(res.x, res.y);
+				}
+				__syncthreads();	/* reads done before the slice is overwritten */
 			}
 		}
 	}
