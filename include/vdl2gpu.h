@@ -175,6 +175,8 @@ int vdl2gpu_plan(uint64_t total_in, uint64_t n, unsigned sdrclk, unsigned lo_len
 int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t max_complex);
 /* Local-oscillator table of (stream, channel index): len complex values. */
 int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, int max_complex);
+/* Trigger candidates of the last push's sync scan, 6 x int32 each {nrel, r, p2err, perr, err, pfr bits}. */
+int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, int max_cands);
 /* Development cycle counters of the demodulator kernels (meaning is internal). */
 int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int n, int reset);
 /* Device build of the fixed-sequence atan2f, elementwise (host arrays). */

@@ -71,7 +71,12 @@ struct vdl2gpu {
 	std::vector<PushTiming> pending;
 	std::vector<PushTiming> free_ev;
 	vdl2gpu_timing_t tm{};
-	std::vector<vdl2gpu_burst_t> ready;	/* fetched, sorted, not yet handed out */
+	std::vector<vdl2gpu_burst_t> ready;	/* fetched, not yet handed out (storage order) */
+	std::vector<uint32_t> ready_idx;	/* hand-out order: indices into `ready`, consumed from ready_pos */
+	size_t ready_pos = 0;
+	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
+	unsigned *h_pin_cnt = nullptr;
+	unsigned pin_recs = 0;
 	std::string err;
 };
 
@@ -209,6 +214,10 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_stage);
 	(void)hipFree(h->d_sel_list);
 	(void)hipFree(h->d_dbg);
+	if (h->h_pin)
+		(void)hipHostFree(h->h_pin);
+	if (h->h_pin_cnt)
+		(void)hipHostFree(h->h_pin_cnt);
 	if (h->stream)
 		(void)hipStreamDestroy(h->stream);
 	delete h;
@@ -246,6 +255,9 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
 	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)h->stage_cap * sizeof(unsigned)));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
+	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
+	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 2 * sizeof(unsigned), hipHostMallocDefault));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
 
@@ -541,22 +553,38 @@ static int fetch_records(vdl2gpu_t *h)
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
-	unsigned cnt[2] = { 0, 0 };
-	HIPCHK(h, hipMemcpy(cnt, h->d_ctl, sizeof cnt, hipMemcpyDeviceToHost));
-	unsigned n = std::min(cnt[0], h->rec_cap);
-	h->overflowed += cnt[1];
+	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt, h->d_ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	const unsigned c0 = h->h_pin_cnt[0], c1 = h->h_pin_cnt[1];
+	const unsigned n = std::min(c0, h->rec_cap);
+	h->overflowed += c1;
 	if (n) {
+		if (h->ready_pos == h->ready_idx.size()) {	/* everything handed out: recycle storage */
+			h->ready.clear();
+			h->ready_idx.clear();
+			h->ready_pos = 0;
+		}
 		const size_t old = h->ready.size();
 		h->ready.resize(old + n);
-		HIPCHK(h, hipMemcpy(h->ready.data() + old, h->d_recs, (size_t)n * sizeof(vdl2gpu_burst_t), hipMemcpyDeviceToHost));
+		for (unsigned done = 0; done < n; done += h->pin_recs) {
+			const unsigned m = std::min(h->pin_recs, n - done);
+			HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_recs + done, (size_t)m * sizeof(vdl2gpu_burst_t),
+						 hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(h, hipStreamSynchronize(h->stream));
+			memcpy(h->ready.data() + old + done, h->h_pin, (size_t)m * sizeof(vdl2gpu_burst_t));
+		}
+		const size_t iold = h->ready_idx.size();
 		for (size_t i = old; i < h->ready.size(); ++i) {
 			vdl2gpu_burst_t &b = h->ready[i];
 			b.trig_sample = dec_to_sample(b.trig_dec, (unsigned)h->sdrclk);
 			b.end_sample = dec_to_sample(b.end_dec, (unsigned)h->sdrclk);
 			/* d8psk.c:302, same mixed float/double expression */
 			b.ppm = (float)((double)(10500.0f * b.df) / (2.0 * M_PI * (double)b.Fr) * 1e6);
+			h->ready_idx.push_back((uint32_t)i);
 		}
-		std::sort(h->ready.begin() + old, h->ready.end(), [](const vdl2gpu_burst_t &a, const vdl2gpu_burst_t &b) {
+		const vdl2gpu_burst_t *rd = h->ready.data();
+		std::sort(h->ready_idx.begin() + iold, h->ready_idx.end(), [rd](uint32_t x, uint32_t y) {
+			const vdl2gpu_burst_t &a = rd[x], &b = rd[y];
 			if (a.end_dec != b.end_dec)
 				return a.end_dec < b.end_dec;
 			if (a.stream != b.stream)
@@ -564,8 +592,8 @@ static int fetch_records(vdl2gpu_t *h)
 			return a.chn < b.chn;
 		});
 	}
-	if (cnt[0] || cnt[1])
-		HIPCHK(h, hipMemset(h->d_ctl, 0, sizeof cnt));
+	if (c0 || c1)
+		HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(unsigned), h->stream));
 	return VDL2GPU_OK;
 }
 
@@ -576,7 +604,7 @@ extern "C" int vdl2gpu_pending(vdl2gpu_t *h)
 	int rc = fetch_records(h);
 	if (rc)
 		return rc;
-	return (int)h->ready.size();
+	return (int)(h->ready_idx.size() - h->ready_pos);
 }
 
 extern "C" int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
@@ -586,11 +614,10 @@ extern "C" int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 	int rc = fetch_records(h);
 	if (rc)
 		return rc;
-	const int n = std::min<int>(max, (int)h->ready.size());
-	if (n) {
-		memcpy(out, h->ready.data(), (size_t)n * sizeof(vdl2gpu_burst_t));
-		h->ready.erase(h->ready.begin(), h->ready.begin() + n);
-	}
+	const int n = std::min<int>(max, (int)(h->ready_idx.size() - h->ready_pos));
+	for (int i = 0; i < n; ++i)
+		out[i] = h->ready[h->ready_idx[h->ready_pos + i]];
+	h->ready_pos += (size_t)n;
 	return n;
 }
 
@@ -700,4 +727,23 @@ extern "C" int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int
 	if (reset)
 		HIPCHK(h, hipMemset(h->d_dbg, 0, 64 * sizeof(unsigned long long)));
 	return VDL2GPU_OK;
+}
+
+/* candidates of (stream, channel index) found by the last push's sync scan: 6 ints per candidate
+ * {nrel, r, bits(p2err), bits(perr), bits(err), bits(pfr)}; returns the count */
+extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, int max_cands)
+{
+	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	const int sc = stream * VDL2_CS + ch;
+	unsigned n = 0;
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	n = std::min<unsigned>(n, VDL2_CAND_CAP);
+	n = std::min<unsigned>(n, (unsigned)max_cands);
+	if (n)
+		HIPCHK(h, hipMemcpy(out, h->d_cands + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
+	return (int)n;
 }

@@ -174,6 +174,11 @@ class Receiver:
                                                 out.ctypes.data_as(C.c_void_p), y.size))
         return out
 
+    def debug_cands(self, stream: int, ch: int, max_cands: int = 4096) -> np.ndarray:
+        buf = np.zeros((max_cands, 6), np.int32)
+        n = self._check(self.L.vdl2gpu_debug_cands(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
+        return buf[:n].copy()
+
     def debug_counters(self, n: int = 16, reset: bool = True):
         buf = (C.c_ulonglong * 64)()
         self._check(self.L.vdl2gpu_debug_counters(self.h, buf, n, int(reset)))
