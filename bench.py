@@ -205,9 +205,23 @@ def main():
         k2b_ms = tm["cluster_ms"] / max(1, tm["pushes"])
         k2c_ms = tm["resolve_ms"] / max(1, tm["pushes"])
         k3_ms = tm["other_ms"] / max(1, tm["pushes"])
-        alg_bytes = float(batch) * sample_bytes
-        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        # dominant full-rate kernel: k1_fast (all whole 1 ms periods but the first and last of a push)
+        fast_ms = tm["channelise_fast_ms"] / max(1, tm["fast_pushes"])
+        fast_samples = (batch * 21 // 500 // 84 - 2) * 2000
+        alg_bytes = float(fast_samples) * sample_bytes
+        achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
         value = world * batch * args.steps / dt / 1e6
+        # HBM traffic of the same kernel from the committed PMC passes of this very command
+        # (profiles/r01_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs;
+        #  FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as reported)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")))
+            if args.tiles == 16 and args.fmt == "cs16":
+                traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"]["void k1_fast<1>"]
+                           + pm["WRITE_SIZE_KB_per_launch"]["void k1_fast<1>"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "IQ MS/s demodulated (8 ch, 2 MS/s cs16) + CRC-pass frame parity vs ref",
             "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,17 +231,21 @@ def main():
                        "fmt": args.fmt, "samples_per_step": batch, "air_time_s_per_step": batch / RATE,
                        "channels": 8, "streams_per_gpu": 1, "bursts_per_step": total_bursts / max(1, args.steps * world),
                        "x_real_time": value * 1e6 / RATE, "parallelism": f"stream-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k1_channelise", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
+            "roofline": {"bound": "hbm", "kernel": "k1_fast", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
+                         "note": "algorithmic bytes = 4 B per cs16 input sample, read once for all 8 channels; the "
+                                 "kernel also writes the 84 kS/s planes (2.7 B per input sample), which is "
+                                 "intermediate traffic, not algorithmic (SURVEY.md 8d)"},
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
                            "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms},
             "whole_path_GBps": alg_bytes / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9,
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
                                            "candidates", "serial_samples", "overflowed")},
             "parity": parity,
-            "dbg": rx.debug_counters(24),
         }
+        if os.environ.get("VDL2GPU_DEBUG_COUNTERS"):
+            out["dbg"] = rx.debug_counters(24)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos)
         print(json.dumps(out))

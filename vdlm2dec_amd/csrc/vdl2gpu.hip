@@ -34,9 +34,11 @@ extern "C" void sincosf(float, float *, float *);
 	} while (0)
 
 #define NEV 6
+#define NEVX 8	/* + e[6], e[7] bracket the k1_fast launch alone */
 struct PushTiming {
-	hipEvent_t e[NEV];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
+	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
+	bool fast;
 };
 
 struct vdl2gpu {
@@ -367,6 +369,12 @@ static int harvest_timing(vdl2gpu_t *h)
 		h->tm.resolve_ms += d[3];
 		h->tm.demod_ms += d[1] + d[2] + d[3];
 		h->tm.other_ms += d[4];
+		if (pt.fast) {
+			float f = 0;
+			HIPCHK(h, hipEventElapsedTime(&f, pt.e[6], pt.e[7]));
+			h->tm.channelise_fast_ms += f;
+			h->tm.fast_pushes++;
+		}
 		h->tm.pushes++;
 		h->tm.samples += pt.samples;
 		h->free_ev.push_back(pt);
@@ -443,6 +451,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	if (rc)
 		return rc;
 	pt.samples = nsamples;
+	pt.fast = false;
 	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
 	{
@@ -471,6 +480,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			k1.per_lo = 1;
 			k1.per_n = periods - 2;
 			generic(0, K1F_PER_OUT - 1);
+			pt.fast = true;
+			HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
 			const dim3 grid((unsigned)((k1.per_n + K1F_PB - 1) / K1F_PB) * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
@@ -478,6 +489,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
 			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
 			}
+			HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
 			generic((periods - 1) * K1F_PER_OUT, J);
 		} else
 			generic(0, J);

@@ -53,6 +53,7 @@ class StatsT(C.Structure):
 class TimingT(C.Structure):
     _fields_ = [("channelise_ms", C.c_double), ("demod_ms", C.c_double), ("scan_ms", C.c_double),
                 ("cluster_ms", C.c_double), ("resolve_ms", C.c_double), ("other_ms", C.c_double),
+                ("channelise_fast_ms", C.c_double), ("fast_pushes", C.c_uint64),
                 ("pushes", C.c_uint64), ("samples", C.c_uint64)]
 
 
