@@ -1,0 +1,120 @@
+/*
+ * vdl2gpu_rcv.c -- drop-in replacement for the reference's d8psk.c + viterbi.c.
+ *
+ * Build the reference with this file instead of those two (everything else unchanged) and
+ * link libvdl2gpu.so:
+ *
+ *     cc -DWITH_RTL ... main.c rtl.c vdlm2.c crc.c rs.c out*.c label.c cJSON.c \
+ *        dropin/vdl2gpu_rcv.c -Iinclude -L. -lvdl2gpu -lpthread -lm
+ *
+ * It keeps the three entry points the rest of the program uses (vdlm2.h:113-128):
+ *     void *rcv_thread(void *arg)        main.c:230 still spawns one per channel
+ *     int   initD8psk(channel_t *ch)
+ *     unsigned reversebits(unsigned,int) comes from libvdl2gpu.so (out.c:429 keeps working)
+ * and the reference's hand-off protocol: producer `Bar1 -> fill Cbuff -> Bar2`
+ * (rtl.c:283-294, air.c:203-212), consumers `Bar2 -> read Cbuff -> Bar1` (d8psk.c:360-383),
+ * barrier count nbch+1 (main.c:225-226).  The thread of channel 0 feeds the block to the GPU
+ * for ALL channels; the other rcv_threads only keep the barrier count.  Every finished burst
+ * is copied into that channel's `ch->blk` and handed to the unchanged decodeVdlm2()
+ * (vdlm2.c:189), so RS / HDLC / CRC / ACARS / output run exactly as before.
+ *
+ * This file contains no DSP.  It is compiled against the reference's own vdlm2.h.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include "vdlm2.h"
+#include "vdl2gpu.h"
+
+extern int nbch;		/* main.c:59 */
+
+static channel_t g_ch[MAXNBCHANNELS];
+static volatile int g_ready;	/* channels initialised so far (channel 0 must be first, vdlm2.c:172) */
+
+int initD8psk(channel_t *ch)
+{
+	(void)ch;
+	return 0;		/* all detector state lives on the GPU */
+}
+
+static void deliver(vdl2gpu_t *h)
+{
+	static vdl2gpu_burst_t b[64];
+	int n, i;
+	while ((n = vdl2gpu_poll(h, b, 64)) > 0) {
+		for (i = 0; i < n; i++) {
+			channel_t *ch = &g_ch[b[i].chn];
+			vdl2gpu_burst_to_msgblk(&b[i], ch->blk, sizeof(msgblk_t));
+			ch->df = b[i].df;			/* channel_t.df as d8psk.c:301 leaves it */
+			gettimeofday(&ch->blk->tv, NULL);	/* d8psk.c:295 stamps at sync; here at delivery */
+			decodeVdlm2(ch);			/* takes ch->blk, installs a fresh zeroed one */
+		}
+		if (n < 64)
+			break;
+	}
+	if (n < 0)
+		fprintf(stderr, "vdl2gpu_poll: %s\n", vdl2gpu_strerror(n));
+}
+
+void *rcv_thread(void *arg)
+{
+	thread_param_t *param = (thread_param_t *) arg;
+	channel_t *ch = &g_ch[param->chn];
+	vdl2gpu_t *h = NULL;
+
+	ch->chn = param->chn;
+	ch->Fr = param->Fr;
+	while (g_ready != param->chn)	/* initVdlm2 of channel 0 creates the block thread */
+		sched_yield();
+	initD8psk(ch);
+	initVdlm2(ch);
+	__sync_fetch_and_add(&g_ready, 1);
+
+	if (param->chn == 0) {
+		/* main.c passes &tparam[n]; the array is contiguous, so channel 0 sees the whole plan */
+		vdl2gpu_chan_t plan[MAXNBCHANNELS];
+		vdl2gpu_config_t cfg;
+		int n, rc;
+		while (g_ready != nbch)
+			sched_yield();
+		for (n = 0; n < nbch; n++) {
+			plan[n].chn = param[n].chn;
+			plan[n].Fr = param[n].Fr;
+			plan[n].Fo = param[n].Fo;
+		}
+		memset(&cfg, 0, sizeof cfg);
+		cfg.struct_size = sizeof cfg;
+		cfg.sdrinrate = SDRINRATE;
+		cfg.sdrclk = SDRCLK;
+#ifdef WITH_RTL
+		cfg.fmt = VDL2GPU_FMT_CF32;	/* Cbuff is complex float, rtl.c:273 */
+#else
+		cfg.fmt = VDL2GPU_FMT_F32R;	/* Cbuff is real float, air.c:190 */
+#endif
+		cfg.nbch = nbch;
+		cfg.nstreams = 1;
+		cfg.chan = plan;
+		cfg.max_push = RTLINBUFSZ / 2;
+		rc = vdl2gpu_create(&cfg, &h);
+		if (rc) {
+			fprintf(stderr, "vdl2gpu_create: %s\n", vdl2gpu_strerror(rc));
+			exit(1);
+		}
+	}
+
+	pthread_barrier_wait(&Bar1);
+	for (;;) {
+		pthread_barrier_wait(&Bar2);
+		if (h) {
+			/* returns once Cbuff has been copied out; demodulation continues asynchronously */
+			int rc = vdl2gpu_push(h, Cbuff, RTLINBUFSZ / 2, 0, VDL2GPU_MEM_HOST);
+			if (rc)
+				fprintf(stderr, "vdl2gpu_push: %s (%s)\n", vdl2gpu_strerror(rc), vdl2gpu_last_error(h));
+		}
+		pthread_barrier_wait(&Bar1);	/* producer may refill Cbuff */
+		if (h)
+			deliver(h);
+	}
+	return NULL;
+}

@@ -45,6 +45,7 @@ unsigned int SDRCLK = 500;
 unsigned int Fc = 0;
 int ppm = 0;
 int verbose = 0;
+int nbch = 1;		/* main.c:59 (only the GPU drop-in build reads it) */
 int grndmess = 1, emptymess = 1, undecmess = 1;
 FILE *logfd;
 pthread_barrier_t Bar1, Bar2;
@@ -102,12 +103,14 @@ int gettimeofday(struct timeval *tv, void *tz)
 	return 0;
 }
 
+#ifndef VDL2GPU_DROPIN
 extern void __real_viterbi_add(float V, int n);
 void __wrap_viterbi_add(float V, int n)
 {
 	tap(3, V, (float)n, 0);
 	__real_viterbi_add(V, n);
 }
+#endif
 
 extern void __real_decodeVdlm2(channel_t * ch);
 void __wrap_decodeVdlm2(channel_t * ch)
@@ -117,6 +120,8 @@ void __wrap_decodeVdlm2(channel_t * ch)
 	pthread_mutex_lock(&outmtx);
 	fprintf(outfd, "B %d %d %.9g %08x ", b->nbrow, b->nlbyte, b->ppm,
 		*(uint32_t *) & ch->df);
+	if (nbch > 1)
+		fprintf(outfd, "c%d ", b->chn);
 	for (r = 0; r < 8; r++)
 		for (i = 0; i < 255; i++)
 			fprintf(outfd, "%02x", b->data[r][i]);
@@ -139,6 +144,8 @@ void out(msgblk_t * blk, unsigned char *hdata, int l)
 	int i;
 	pthread_mutex_lock(&outmtx);
 	fprintf(outfd, "F %d %d %d ", blk->nbrow, blk->nlbyte, l);
+	if (nbch > 1)
+		fprintf(outfd, "c%d ", blk->chn);
 	for (i = 0; i < l; i++)
 		fprintf(outfd, "%02x", hdata[i]);
 	fprintf(outfd, "\n");
@@ -168,16 +175,29 @@ int main(int argc, char **argv)
 		tapfd = fopen(argv[8], "wb");
 	logfd = stderr;
 
-	static thread_param_t tp;
-	tp.chn = 0;
-	tp.Fo = atoi(argv[4]);
-	tp.Fr = atoi(argv[5]);
-	Fc = (unsigned)(tp.Fr - tp.Fo);
+	/* Fo and Fr may be comma-separated lists: several channels in one process is only used
+	 * by the GPU drop-in build (the reference itself is run one channel per process) */
+	static thread_param_t tp[MAXNBCHANNELS];
+	{
+		char *fo = strdup(argv[4]), *fr = strdup(argv[5]), *s1, *s2;
+		char *a = strtok_r(fo, ",", &s1), *b = strtok_r(fr, ",", &s2);
+		nbch = 0;
+		while (a && b && nbch < MAXNBCHANNELS) {
+			tp[nbch].chn = nbch;
+			tp[nbch].Fo = atoi(a);
+			tp[nbch].Fr = atoi(b);
+			nbch++;
+			a = strtok_r(NULL, ",", &s1);
+			b = strtok_r(NULL, ",", &s2);
+		}
+	}
+	Fc = (unsigned)(tp[0].Fr - tp[0].Fo);
 
-	pthread_barrier_init(&Bar1, NULL, 2);
-	pthread_barrier_init(&Bar2, NULL, 2);
-	pthread_t th;
-	pthread_create(&th, NULL, rcv_thread, &tp);
+	pthread_barrier_init(&Bar1, NULL, nbch + 1);
+	pthread_barrier_init(&Bar2, NULL, nbch + 1);
+	pthread_t th[MAXNBCHANNELS];
+	for (int n = 0; n < nbch; n++)
+		pthread_create(&th[n], NULL, rcv_thread, &tp[n]);
 
 	const int NB = RTLINBUFSZ / 2;
 	size_t ssz;
@@ -238,6 +258,9 @@ int main(int argc, char **argv)
 		pthread_barrier_wait(&Bar2);
 	}
 	pthread_barrier_wait(&Bar1);	/* consumer finished the last block */
+#ifdef VDL2GPU_DROPIN
+	usleep(200000);			/* the drop-in delivers after Bar1: let it hand the last bursts over */
+#endif
 	/* drain blk_thread: every enqueued block is freed at vdlm2.c:157 */
 	int spins = 0;
 	while (n_freed < n_enq && spins++ < 20000)

@@ -48,6 +48,7 @@ struct vdl2gpu {
 	size_t sample_bytes;
 	long long cap;		/* frames per stream per ping-pong buffer */
 	hipStream_t stream = nullptr;
+	hipEvent_t copy_done = nullptr;
 	void *d_raw = nullptr;
 	size_t raw_bytes = 0;
 	float2 *d_lo = nullptr;
@@ -220,6 +221,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipHostFree(h->h_pin);
 	if (h->h_pin_cnt)
 		(void)hipHostFree(h->h_pin_cnt);
+	if (h->copy_done)
+		(void)hipEventDestroy(h->copy_done);
 	if (h->stream)
 		(void)hipStreamDestroy(h->stream);
 	delete h;
@@ -422,6 +425,12 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw + (size_t)s * per,
 						 (const char *)iq + (size_t)s * stream_stride_bytes, per,
 						 hipMemcpyHostToDevice, h->stream));
+		/* the caller may reuse its buffer as soon as we return (the reference's producer refills
+		 * Cbuff right after the consumers pass Bar1, d8psk.c:383): wait for the copies only */
+		if (!h->copy_done)
+			HIPCHK(h, hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
+		HIPCHK(h, hipEventRecord(h->copy_done, h->stream));
+		HIPCHK(h, hipEventSynchronize(h->copy_done));
 		src = h->d_raw;
 		stride = per;
 	} else if (memkind != VDL2GPU_MEM_DEVICE)
