@@ -241,7 +241,7 @@ def main():
                            "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms},
             "whole_path_GBps": alg_bytes / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9,
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
-                                           "candidates", "serial_samples", "overflowed")},
+                                           "candidates", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,
         }
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS"):

@@ -86,6 +86,7 @@ typedef struct {
 } vdl2gpu_config_t;
 
 #define VDL2GPU_F_KEEP_DEC 1u	/* keep each push's decimated stream for vdl2gpu_debug_dec() */
+#define VDL2GPU_F_FULLSCAN 4u	/* scan all four FIR sub-phases everywhere instead of probe + regions + verify */
 #define VDL2GPU_F_SERIAL 2u	/* diagnostics: skip the parallel sync tables, one serial machine per channel */
 
 /* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */
@@ -113,6 +114,7 @@ typedef struct {
 	uint64_t bursts;	/* records handed out */
 	uint64_t deferrals;	/* bursts that waited for a later push to complete */
 	uint64_t candidates;	/* sync-trigger candidates found by the parallel scan (all timing hypotheses) */
+	uint64_t serial_redos;	/* channel-pushes redone serially because the verify pass found an unlisted event */
 	uint64_t serial_samples;	/* 84 kS/s samples handled by the serial machine (history-dependent stretches) */
 	uint64_t overflowed;	/* records dropped because the ring was full */
 } vdl2gpu_stats_t;

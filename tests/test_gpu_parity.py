@@ -182,3 +182,21 @@ def test_long_stream_properties(built, oracle):
     with _rx(spec.rate, spec.fo[:2], "cs16", max_push=1 << 21) as rx:
         c = rx.run(raw[: 2 * (1 << 21)])
     assert _gpu_keys(c) == sorted(x.key() for x in want)
+
+
+@pytest.mark.parametrize("mode", ["lazy", "full_scan", "serial"])
+def test_scan_modes_agree_with_oracle(built, oracle, mode):
+    """The three ways of finding sync triggers -- probe + regions + verify (default), all four
+    sub-phases everywhere, and the plain serial machine -- must give identical bursts."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 1 << 21, seed=91, bursts_per_s=12.0, info_max=120)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20,
+                  serial=(mode == "serial"), full_scan=(mode == "full_scan")) as rx:
+        got = rx.run(raw, block=700_001)
+        st = rx.stats()
+    assert _gpu_keys(got) == want and len(want) >= 20
+    assert st["serial_redos"] == 0
+    if mode == "serial":
+        assert st["candidates"] == 0

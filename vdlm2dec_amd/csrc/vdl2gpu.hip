@@ -33,8 +33,8 @@ extern "C" void sincosf(float, float *, float *);
 		}                                                                               \
 	} while (0)
 
-#define NEV 6
-#define NEVX 8	/* + e[6], e[7] bracket the k1_fast launch alone */
+#define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
+#define NEVX 10	/* + e[8], e[9] bracket the k1_fast launch alone */
 struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
@@ -65,6 +65,11 @@ struct vdl2gpu {
 	Cluster *d_clusters = nullptr;
 	BurstDesc *d_stage = nullptr;
 	unsigned *d_sel_list = nullptr;
+	int2 *d_regs = nullptr;
+	Seg *d_segs = nullptr;
+	int *d_fail = nullptr;
+	ChanState *d_cs_out = nullptr;
+	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int force_serial = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -216,6 +221,10 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_clusters);
 	(void)hipFree(h->d_stage);
 	(void)hipFree(h->d_sel_list);
+	(void)hipFree(h->d_regs);
+	(void)hipFree(h->d_segs);
+	(void)hipFree(h->d_fail);
+	(void)hipFree(h->d_cs_out);
 	(void)hipFree(h->d_dbg);
 	if (h->h_pin)
 		(void)hipHostFree(h->h_pin);
@@ -251,14 +260,19 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
 	HIPCHK(h, hipMalloc(&h->d_pn, VDL2_PN_BITS));
 	HIPCHK(h, hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
-	h->ctl_words = CTL_CAND0 + 2 * (size_t)S * VDL2_CS;
+	h->ctl_words = CTL_CAND0 + 5 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
 	HIPCHK(h, hipMalloc(&h->d_clusters, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
 	h->stage_cap = 131072u * (unsigned)S;
 	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
-	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)h->stage_cap * sizeof(unsigned)));
+	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
+	HIPCHK(h, hipMalloc(&h->d_regs, (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
+	HIPCHK(h, hipMalloc(&h->d_segs, (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
+	HIPCHK(h, hipMalloc(&h->d_fail, (size_t)S * VDL2_CS * sizeof(int)));
+	HIPCHK(h, hipMalloc(&h->d_cs_out, (size_t)S * VDL2_CS * sizeof(ChanState)));
+	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
@@ -367,14 +381,14 @@ static int harvest_timing(vdl2gpu_t *h)
 		for (int i = 0; i + 1 < NEV; ++i)
 			HIPCHK(h, hipEventElapsedTime(&d[i], pt.e[i], pt.e[i + 1]));
 		h->tm.channelise_ms += d[0];
-		h->tm.scan_ms += d[1];
+		h->tm.scan_ms += d[1] + d[4];
 		h->tm.cluster_ms += d[2];
-		h->tm.resolve_ms += d[3];
-		h->tm.demod_ms += d[1] + d[2] + d[3];
-		h->tm.other_ms += d[4];
+		h->tm.resolve_ms += d[3] + d[5];
+		h->tm.demod_ms += d[1] + d[2] + d[3] + d[4] + d[5];
+		h->tm.other_ms += d[6];
 		if (pt.fast) {
 			float f = 0;
-			HIPCHK(h, hipEventElapsedTime(&f, pt.e[6], pt.e[7]));
+			HIPCHK(h, hipEventElapsedTime(&f, pt.e[8], pt.e[9]));
 			h->tm.channelise_fast_ms += f;
 			h->tm.fast_pushes++;
 		}
@@ -462,6 +476,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	pt.samples = nsamples;
 	pt.fast = false;
 	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->d_fail, 0x7f, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
 	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
@@ -490,7 +505,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			k1.per_n = periods - 2;
 			generic(0, K1F_PER_OUT - 1);
 			pt.fast = true;
-			HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
+			HIPCHK(h, hipEventRecord(pt.e[8], h->stream));
 			const dim3 grid((unsigned)((k1.per_n + K1F_PB - 1) / K1F_PB) * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
@@ -498,7 +513,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
 			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
 			}
-			HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
+			HIPCHK(h, hipEventRecord(pt.e[9], h->stream));
 			generic((periods - 1) * K1F_PER_OUT, J);
 		} else
 			generic(0, J);
@@ -526,19 +541,32 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.rec_cap = h->rec_cap;
 		k2.force_serial = h->force_serial;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
+		k2.full_scan = h->full_scan;
+		k2.regs = h->d_regs;
+		k2.segs = h->d_segs;
+		k2.fail = h->d_fail;
+		k2.cs_out = h->d_cs_out;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
-		hipLaunchKernelGGL(k2a_scan, dim3(tiles, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		const dim3 gch((unsigned)h->C, (unsigned)h->S);
+		hipLaunchKernelGGL(k2a_probe, dim3(tiles, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2r_regions, gch, dim3(256), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
 		hipLaunchKernelGGL(k2b_clusters, dim3(2048), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
-		hipLaunchKernelGGL(k2c_resolve, dim3((unsigned)h->C, (unsigned)h->S), dim3(K2_NT), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
-		hipLaunchKernelGGL(k2d_payload, dim3(2048), dim3(K2D_NT), 0, h->stream, k2);
+		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
+		hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
+		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
+	HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
 	{
 		K3Params k3{};
 		k3.src = h->d_dec[par];
@@ -553,7 +581,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
+	HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
 	h->pending.push_back(pt);
 	h->total_in += nsamples;
 	h->pushes++;
@@ -664,6 +692,7 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 			out->deferrals += x.n_defer;
 			out->serial_samples += x.n_slow;
 			out->candidates += x.n_cand;
+			out->serial_redos += x.n_redo;
 		}
 	out->overflowed = h->overflowed;
 	return VDL2GPU_OK;

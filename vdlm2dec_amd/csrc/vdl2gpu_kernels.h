@@ -61,6 +61,7 @@
 #define VDL2_PN_BITS (16384 + 64)
 #define VDL2_CAND_CAP 4096	/* trigger candidates per channel per push */
 #define VDL2_CL_MAXB 4		/* bursts per cluster before the resolver takes over */
+#define VDL2_SEL_CAP 16384	/* bursts on the real chain per channel per push */
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -80,7 +81,7 @@ struct ChanState {
 	int fresh;		/* evaluations since the last trigger/reset, saturating */
 	float perr, p2err, pfr;	/* channel_t.perr/p2err/pfr */
 	float ring[VDL2_NPH];	/* channel_t.Ph in time order, ring[67] newest */
-	unsigned long long n_eval, n_trig, n_reject, n_burst, n_defer, n_slow, n_cand;
+	unsigned long long n_eval, n_trig, n_reject, n_burst, n_defer, n_slow, n_cand, n_redo;
 };
 
 struct ChanCfg {
@@ -107,6 +108,10 @@ struct BurstDesc {		/* a burst found by a cluster; payload decoded later if it i
 	int clk0;		/* (int)roundf(of), d8psk.c:305 */
 	float df;
 	int nbrow, nlbyte, pad;
+};
+
+struct Seg {			/* the chain idled in class (r, parity of lo) over stream-relative [lo, hi) */
+	int lo, hi, r, pad;
 };
 
 struct K1Params {
@@ -143,6 +148,11 @@ struct K2Params {
 	vdl2gpu_burst_t *recs;
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
+	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
+	int2 *regs;		/* [S*8][REG_CAP] (lo, count) stream-relative */
+	Seg *segs;		/* [S*8][SEG_CAP] */
+	int *fail;		/* [S*8] earliest unexpected hit (stream-relative), INT_MAX = verified */
+	ChanState *cs_out;	/* resolver result, committed by K2f */
 	unsigned long long *dbg;	/* diagnostics: cycle counters */
 };
 #define CTL_OUT 0
@@ -150,8 +160,10 @@ struct K2Params {
 #define CTL_STAGE 2
 #define CTL_TICKET 3
 #define CTL_STAGE_OVF 4
-#define CTL_NSEL 5
-#define CTL_CAND0 8
+#define CTL_CAND0 8		/* [S*8] candidate counts, [S*8] overflow flags, then: */
+#define CTL_NREG0 (CTL_CAND0 + 2 * p.nstreams * VDL2_CS)
+#define CTL_NSEG0 (CTL_CAND0 + 3 * p.nstreams * VDL2_CS)
+#define CTL_NSEL0 (CTL_CAND0 + 4 * p.nstreams * VDL2_CS)
 
 struct K3Params {
 	const float2 *src;
@@ -717,7 +729,8 @@ struct MachCtx {
 	long long dec_base, avail_end;
 	const uint8_t *pn;
 	vdl2gpu_burst_t *recs;	/* sink: output ring, payload decoded at once (K2c serial stretches) ... */
-	BurstDesc *desc;	/* ... or descriptor pool, payload decoded by K2d if selected (K2b) */
+	BurstDesc *desc;	/* ... or descriptor pool, payload decoded by K2d if selected (K2b, K2c) */
+	unsigned *sel, *nsel;	/* K2c: descriptors made by its serial stretches are on the real chain */
 	int sc;
 	unsigned long long *dbg;
 	long long t_lo, t_hi;	/* stream-time range currently held in the LDS tile (cluster mode) */
@@ -1076,6 +1089,8 @@ template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachC
 					d.nlbyte = nlbyte;
 					d.pad = 0;
 					cx.desc[slot] = d;
+					if (cx.sel)
+						cx.sel[atomicAdd(cx.nsel, 1u)] = slot;
 				}
 				sh.ctl[6] = (int)slot;
 			}
@@ -1116,6 +1131,7 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 	cx.dbg = to_stage ? p.dbg : nullptr;
 	cx.t_lo = cx.t_hi = 0;
 	cx.grey = nullptr;
+	cx.sel = cx.nsel = nullptr;
 	if (to_stage) {
 		cx.recs = nullptr;
 		cx.desc = p.stage;
@@ -1134,24 +1150,137 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 }
 
 /* ====================================================================== K2a
- * Sync scan.  For every sample n >= pos of a channel and every FIR sub-phase
- * r in 0..3 compute the filtered phase P_r(n) and the free-running fit error
- * E_r(n) from P_r(n), P_r(n-8), .. P_r(n-128); record every (n, r) where the
- * idle detector would fire: E_r(n-2) < 4 && E_r(n) > E_r(n-2).
- * One workgroup = K2A_TS consecutive samples of one channel, staged in LDS.
+ * Sync scan.  For a run of evaluation instants n = nbase + S*i of one channel and a set of FIR
+ * sub-phases r, compute the filtered phase P_r(n) and the free-running fit error E_r(n) from
+ * P_r(n), P_r(n-8), .. P_r(n-128), and test where the idle detector would fire:
+ *     E_r(n-2) < 4 && E_r(n) > E_r(n-2)
+ * (S = 1: every sample, both parities; S = 2: one parity only -- n-8l and n-2 keep n's parity.)
+ *
+ * Three uses, all the same tile routine on K2A_TS instants staged in LDS:
+ *   k2a_probe   every sample >= pos of each channel, but ONLY the sub-phase the channel's
+ *               detector is in at the start of the push.  Finds every burst (a burst fires the
+ *               detector in all 8 (sub-phase, parity) classes within a few samples) and is
+ *               already the complete table for that sub-phase.
+ *   k2a_region  the other three sub-phases, only in the neighbourhood of the probe's hits.
+ *   k2a_verify  after the resolver: every stretch the real chain idled through in a class the
+ *               probe did not cover is scanned in exactly that class; a hit means the tables
+ *               missed an event and the channel is redone serially (K2f).  This is what makes
+ *               the shortcut exact instead of heuristic.
+ * VDL2GPU_F_FULLSCAN makes the probe cover all four sub-phases (no regions/verify needed).
  */
 #define K2A_THREADS 256
-#define K2A_TS 1024
-#define K2A_POFF 132		/* phases needed before the tile: 128 + 4 */
+#define K2A_TS 1024		/* evaluation instants per tile */
+#define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
+#define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
+#define K2A_RSLOTS 3		/* sub-phases per tile pass (a 4-sub-phase scan takes two passes) */
+#define VDL2_REG_CAP 1024	/* probe-hit regions per channel per push */
+#define VDL2_REG_PAD 40		/* samples scanned on either side of a probe hit */
+#define VDL2_REG_GAP 96		/* hits closer than this share a region */
+#define VDL2_SEG_CAP 4096	/* verify segments per channel per push */
+
+struct K2aShared {
+	float2 xs[K2A_XMAX];
+	float ph[K2A_RSLOTS][K2A_TS + K2A_POFF];
+	float eb[K2A_TS + 4], fb[K2A_TS + 4];
+};
+
+/* mode 0: append candidates; mode 1: report the earliest hit in [chk_lo, chk_hi) to *fail */
+template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
+					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail)
+{
+	const int tid = threadIdx.x;
+	constexpr int PH = K2A_POFF / S;	/* phase instants of history */
+	constexpr int LSTR = 8 / S;		/* one symbol in instants */
+	constexpr int E2 = 2 / S, E4 = 4 / S;	/* previous two evaluations in instants */
+	const float2 *x = p.dec + (size_t)sc * p.cap + (nbase - K2A_XOFF - dec_base);
+	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
+	__syncthreads();
+	for (int i = tid; i < nx; i += K2A_THREADS)
+		sh.xs[i] = x[i];
+	__syncthreads();
+	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
+	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
+	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	unsigned todo = rmask & 0xfu;
+	while (todo) {
+		/* up to K2A_RSLOTS sub-phases per pass */
+		int rs[K2A_RSLOTS], nr = 0;
+		for (int r = 0; r < 4 && nr < K2A_RSLOTS; ++r)
+			if (todo & (1u << r)) {
+				rs[nr++] = r;
+				todo &= ~(1u << r);
+			}
+		/* phases of instants -PH .. cnt-1 from one register copy of the 17-sample window */
+		for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
+			float2 xv[17];
+			const float2 *xq = &sh.xs[S * q + (K2A_POFF - S * PH)];	/* sample (nbase + S*(q-PH)) - 16 */
+#pragma unroll
+			for (int j = 0; j < 17; ++j)
+				xv[j] = xq[j];
+#pragma unroll
+			for (int k = 0; k < K2A_RSLOTS; ++k) {
+				if (k < nr) {
+					const int r = rs[k];
+					float sr = 0.0f, si = 0.0f;
+					switch (r) {
+#define K2A_FIR(R)									\
+					case R:								\
+						_Pragma("unroll") for (int j = 0; j < 17; ++j)		\
+							if (R + 4 * j < 65) {				\
+								const float m = d_tab(c_mflt, R + 4 * j);	\
+								sr += xv[j].x * m;			\
+								si += xv[j].y * m;			\
+							}						\
+						break;
+					K2A_FIR(0) K2A_FIR(1) K2A_FIR(2) K2A_FIR(3)
+#undef K2A_FIR
+					}
+					sh.ph[k][q] = vdl2_atan2f(si, sr);
+				}
+			}
+		}
+		__syncthreads();
+		for (int k = 0; k < nr; ++k) {
+			const int r = rs[k];
+			/* fit errors for instants -E4 .. cnt-1: eb[i] <-> instant i - E4 */
+			for (int i = tid; i < cnt + E4; i += K2A_THREADS) {
+				float fr;
+				sh.eb[i] = k2_sync_metric<LSTR>(&sh.ph[k][PH - E4 + i - 16 * LSTR], &fr);
+				sh.fb[i] = fr;
+			}
+			__syncthreads();
+			for (int i = tid; i < cnt; i += K2A_THREADS) {
+				const float perr = sh.eb[i + E4 - E2], err = sh.eb[i + E4];
+				if (perr < 4.0f && err > perr) {
+					const long long n = nbase + (long long)S * i;
+					if (mode == 0) {
+						const unsigned kk = atomicAdd(cntp, 1u);
+						if (kk < VDL2_CAND_CAP) {
+							Cand cd;
+							cd.nrel = (int)(n - dec_base);
+							cd.r = r;
+							cd.p2err = sh.eb[i];
+							cd.perr = perr;
+							cd.err = err;
+							cd.pfr = sh.fb[i + E4 - E2];
+							cl[kk] = cd;
+						} else
+							*ovf = 1u;
+					} else if (n >= chk_lo && n < chk_hi) {
+						atomicMin(fail, (int)(n - dec_base));
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
 
 __global__ __launch_bounds__(K2A_THREADS)
-void k2a_scan(K2Params p)
+void k2a_probe(K2Params p)
 {
-	__shared__ float2 xs[K2A_TS + K2A_XOFF];
-	__shared__ float ph[4][K2A_TS + K2A_POFF];
-	__shared__ float eb[K2A_TS + 4], fb[K2A_TS + 4];
-	const int tid = threadIdx.x;
+	__shared__ K2aShared sh;
 	const int c = blockIdx.y, s = blockIdx.z;
 	const int sc = s * VDL2_CS + c;
 	const StreamState *ss = p.ss + s;
@@ -1161,61 +1290,135 @@ void k2a_scan(K2Params p)
 	if (n0 >= avail_end || p.force_serial)
 		return;
 	const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
-	const float2 *x = p.dec + (size_t)sc * p.cap + (n0 - K2A_XOFF - dec_base);
-	for (int i = tid; i < nt + K2A_XOFF; i += K2A_THREADS)
-		xs[i] = x[i];
+	const unsigned rmask = p.full_scan ? 0xfu : (1u << p.cs[sc].r);
+	k2a_tile<1>(sh, p, sc, dec_base, n0, nt, rmask, 0, 0, 0, nullptr);
+}
+
+/* ---- regions around the probe's hits (one workgroup per channel) */
+__global__ __launch_bounds__(256)
+void k2r_regions(K2Params p)
+{
+	__shared__ int key[VDL2_CAND_CAP];
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial || p.full_scan)
+		return;
+	int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	ncand = ncand > VDL2_CAND_CAP ? VDL2_CAND_CAP : ncand;
+	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	int npow = 1;
+	while (npow < ncand)
+		npow <<= 1;
+	for (int i = tid; i < npow; i += 256)
+		key[i] = (i < ncand) ? cands[i].nrel : 0x7fffffff;
 	__syncthreads();
-	/* phases for samples n0-POFF .. n0+nt-1, all four sub-phases from one register copy */
-	for (int q = tid; q < nt + K2A_POFF; q += K2A_THREADS) {
-		float2 xv[17];
-#pragma unroll
-		for (int j = 0; j < 17; ++j)
-			xv[j] = xs[q + j];	/* sample (n0-POFF+q) - 16 + j */
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			float sr = 0.0f, si = 0.0f;
-#pragma unroll
-			for (int j = 0; j < 17; ++j) {
-				if (r + 4 * j < 65) {
-					const float m = d_tab(c_mflt, r + 4 * j);
-					sr += xv[j].x * m;
-					si += xv[j].y * m;
+	for (int k = 2; k <= npow; k <<= 1)
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			for (int i = tid; i < npow; i += 256) {
+				const int l = i ^ j;
+				if (l > i) {
+					const int a0 = key[i], b0 = key[l];
+					if ((a0 > b0) == ((i & k) == 0)) {
+						key[i] = b0;
+						key[l] = a0;
+					}
 				}
 			}
-			ph[r][q] = vdl2_atan2f(si, sr);
+			__syncthreads();
+		}
+	if (tid == 0) {
+		const StreamState *ss = p.ss + s;
+		const int lo_lim = (int)(p.cs[sc].pos - ss->dec_base);
+		const int hi_lim = (int)(ss->dec_fill + p.J);
+		int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
+		int n = 0, i = 0;
+		bool over = false;
+		while (i < ncand) {
+			int lo = key[i], hi = key[i];
+			while (i + 1 < ncand && key[i + 1] - hi <= VDL2_REG_GAP)
+				hi = key[++i];
+			++i;
+			lo = lo - VDL2_REG_PAD < lo_lim ? lo_lim : lo - VDL2_REG_PAD;
+			hi = hi + VDL2_REG_PAD + 1 > hi_lim ? hi_lim : hi + VDL2_REG_PAD + 1;
+			/* long merged regions (bursts back to back) are cut into tile-sized pieces */
+			for (int q = lo; q < hi; q += K2A_TS) {
+				if (n >= VDL2_REG_CAP) {
+					over = true;
+					break;
+				}
+				regs[n++] = make_int2(q, (hi - q < K2A_TS) ? hi - q : K2A_TS);
+			}
+		}
+		p.ctl[CTL_NREG0 + sc] = (unsigned)n;
+		if (over)
+			p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 1u;	/* tables unusable -> serial */
+	}
+}
+
+__global__ __launch_bounds__(K2A_THREADS)
+void k2a_region(K2Params p)
+{
+	__shared__ K2aShared sh;
+	const int c = blockIdx.y, s = blockIdx.z;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial || p.full_scan)
+		return;
+	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
+	const long long dec_base = p.ss[s].dec_base;
+	for (unsigned k = blockIdx.x; k < nreg; k += gridDim.x) {
+		const int2 rg = p.regs[(size_t)sc * VDL2_REG_CAP + k];
+		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu & ~(1u << p.cs[sc].r), 0, 0, 0, nullptr);
+	}
+}
+
+/* one tile = 2*K2A_TS samples; every verify segment overlapping it is scanned in its own class */
+__global__ __launch_bounds__(K2A_THREADS)
+void k2a_verify(K2Params p)
+{
+	__shared__ K2aShared sh;
+	__shared__ int s_list[64], s_nl;
+	const int tid = threadIdx.x;
+	const int c = blockIdx.y, s = blockIdx.z;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial || p.full_scan)
+		return;
+	const StreamState *ss = p.ss + s;
+	const long long dec_base = ss->dec_base;
+	const int t_lo = (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * 2 * K2A_TS;
+	const int t_end = (int)(ss->dec_fill + p.J);
+	if (t_lo >= t_end)
+		return;
+	const int t_hi = t_lo + 2 * K2A_TS < t_end ? t_lo + 2 * K2A_TS : t_end;
+	const int nseg = (int)p.ctl[CTL_NSEG0 + sc];
+	const Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
+	if (tid == 0)
+		s_nl = 0;
+	__syncthreads();
+	for (int k = tid; k < nseg && k < VDL2_SEG_CAP; k += K2A_THREADS) {
+		const Seg g = segs[k];
+		if (g.lo < t_hi && g.hi > t_lo && g.hi > g.lo) {
+			const int q = atomicAdd(&s_nl, 1);
+			if (q < 64)
+				s_list[q] = k;
 		}
 	}
 	__syncthreads();
-	unsigned *cnt = p.ctl + CTL_CAND0 + sc;
-	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
-	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
-	for (int r = 0; r < 4; ++r) {
-		/* fit errors for samples n0-4 .. n0+nt-1: eb[i] <-> sample n0-4+i */
-		for (int i = tid; i < nt + 4; i += K2A_THREADS) {
-			float fr;
-			/* newest phase of sample n0-4+i sits at ph index POFF-4+i; oldest 128 before */
-			eb[i] = k2_sync_metric<8>(&ph[r][K2A_POFF - 4 + i - 128], &fr);
-			fb[i] = fr;
-		}
-		__syncthreads();
-		for (int i = tid; i < nt; i += K2A_THREADS) {
-			const float perr = eb[i + 2], err = eb[i + 4];
-			if (perr < 4.0f && err > perr) {
-				const unsigned k = atomicAdd(cnt, 1u);
-				if (k < VDL2_CAND_CAP) {
-					Cand cd;
-					cd.nrel = (int)(n0 + i - dec_base);
-					cd.r = r;
-					cd.p2err = eb[i];
-					cd.perr = perr;
-					cd.err = err;
-					cd.pfr = fb[i + 2];
-					cl[k] = cd;
-				} else
-					*ovf = 1u;
-			}
-		}
-		__syncthreads();
+	const int nl = s_nl;
+	if (nl > 64) {		/* absurdly fragmented tile: give up on the tables for this channel */
+		if (tid == 0)
+			atomicMin(p.fail + sc, 0);
+		return;
+	}
+	for (int q = 0; q < nl; ++q) {
+		const Seg g = segs[s_list[q]];
+		int lo = g.lo > t_lo ? g.lo : t_lo;
+		const int hi = g.hi < t_hi ? g.hi : t_hi;
+		lo += (lo ^ g.lo) & 1;		/* keep the segment's parity */
+		if (lo >= hi)
+			continue;
+		const int cnt = (hi - lo + 1) / 2;
+		k2a_tile<2>(sh, p, sc, dec_base, dec_base + lo, cnt, 1u << g.r, 1, dec_base + lo, dec_base + hi, p.fail + sc);
 	}
 }
 
@@ -1380,13 +1583,24 @@ void k2c_resolve(K2Params p)
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
-	ChanState *cs = p.cs + sc;
+	const ChanState *cs = p.cs + sc;	/* input state: left untouched until K2f commits */
+	ChanState *cs_out = p.cs_out + sc;
+	unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
+	unsigned *nsel = p.ctl + CTL_NSEL0 + sc;
+	Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
+	unsigned *nseg = p.ctl + CTL_NSEG0 + sc;
 	MachCtx cx;
-	mach_ctx(cx, p, s, c, false);
+	mach_ctx(cx, p, s, c, true);	/* bursts of serial stretches become descriptors too */
+	cx.sel = sel;
+	cx.nsel = nsel;
+	cx.dbg = nullptr;
 	MachState st;
 	st.pos = cs->pos;
 	st.r = cs->r;
 	st.fresh = cs->fresh;
+	const int r_probe = cs->r;
+	const int t_end = (int)(cx.avail_end - cx.dec_base);
+	const bool lazy = !p.full_scan;
 	mach_init_taps(sh);
 	mach_load(sh, cs);
 	MachOut out;
@@ -1459,6 +1673,20 @@ void k2c_resolve(K2Params p)
 		if (tid == 0) {
 			int cur = k2c_next(skey, ncand, 0, (int)(st.pos - cx.dec_base), st.r);
 			int last = -1, why = 0;	/* why: 0 = no more candidates, 1 = special cluster at cur */
+			if (lazy && st.r != r_probe) {
+				/* the chain idles from here to the next candidate in a class the probe did not
+				 * scan: K2a-verify must confirm there really is nothing in between */
+				const unsigned q = atomicAdd(nseg, 1u);
+				if (q < VDL2_SEG_CAP) {
+					Seg g;
+					g.lo = (int)(st.pos - cx.dec_base);
+					g.hi = (cur >= 0) ? (skey[cur] >> 2) : t_end;
+					g.r = st.r;
+					g.pad = 0;
+					segs[q] = g;
+				} else
+					atomicMin(p.fail + sc, 0);
+			}
 			while (cur >= 0) {
 				const int stt = sstat[cur];
 				if (stt != CL_STEADY) {
@@ -1529,10 +1757,24 @@ void k2c_resolve(K2Params p)
 				const Cluster *cl = clusters + sidx[j];
 				const int ns = cl->nslots;
 				for (int i = 0; i < ns; ++i)
-					p.sel_list[atomicAdd(p.ctl + CTL_NSEL, 1u)] = (unsigned)cl->slots[i];
+					sel[atomicAdd(nsel, 1u)] = (unsigned)cl->slots[i];
 				a += cl->ntrig;
 				b += cl->nrej;
 				d += cl->nburst;
+				if (lazy && sstat[j] == CL_STEADY && cl->r_s != r_probe) {
+					/* after this cluster the chain idles in class (r_s, parity of n_s) until
+					 * the successor's trigger (or the end of the data) */
+					const unsigned q = atomicAdd(nseg, 1u);
+					if (q < VDL2_SEG_CAP) {
+						Seg g;
+						g.lo = (int)(cl->n_s - cx.dec_base);
+						g.hi = (snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2);
+						g.r = cl->r_s;
+						g.pad = 0;
+						segs[q] = g;
+					} else
+						atomicMin(p.fail + sc, 0);
+				}
 			}
 		if (a)
 			atomicAdd(&s_cnt[0], a);
@@ -1547,15 +1789,16 @@ void k2c_resolve(K2Params p)
 		st.fresh = VDL2_STEADY;
 	}
 	__syncthreads();
-	mach_store(sh, st, cs);
+	mach_store(sh, st, cs_out);
 	if (tid == 0) {
-		cs->n_eval += (unsigned long long)((st.pos - pos_in) / 2);	/* evaluation instants covered */
-		cs->n_trig += (unsigned long long)(out.ntrig + s_cnt[0]);
-		cs->n_reject += (unsigned long long)(out.nrej + s_cnt[1]);
-		cs->n_burst += (unsigned long long)(out.nburst + s_cnt[2]);
-		cs->n_defer += (unsigned long long)out.ndefer;
-		cs->n_slow += n_slow;
-		cs->n_cand += (unsigned long long)ncand;
+		cs_out->n_eval = cs->n_eval + (unsigned long long)((st.pos - pos_in) / 2);	/* evaluation instants covered */
+		cs_out->n_trig = cs->n_trig + (unsigned long long)(out.ntrig + s_cnt[0]);
+		cs_out->n_reject = cs->n_reject + (unsigned long long)(out.nrej + s_cnt[1]);
+		cs_out->n_burst = cs->n_burst + (unsigned long long)(out.nburst + s_cnt[2]);
+		cs_out->n_defer = cs->n_defer + (unsigned long long)out.ndefer;
+		cs_out->n_slow = cs->n_slow + n_slow;
+		cs_out->n_cand = cs->n_cand + (unsigned long long)ncand;
+		cs_out->n_redo = cs->n_redo;
 		if (p.dbg) {
 			const long long tk4 = wall_clock64();
 			atomicAdd(p.dbg + 16, (unsigned long long)(tk1 - tk0));
@@ -1564,6 +1807,55 @@ void k2c_resolve(K2Params p)
 			atomicAdd(p.dbg + 19, (unsigned long long)(tk4 - tk3));
 			atomicAdd(p.dbg + 20, 1ull);
 		}
+	}
+}
+
+/* ====================================================================== K2f
+ * Commit.  If K2a-verify found nothing the resolver's result becomes the channel state.  If it
+ * found a detector hit the tables did not contain, the channel's push is redone from its input
+ * state by the serial machine alone (always exact; it writes its bursts itself) and the
+ * resolver's selection for that channel is dropped.
+ */
+__global__ __launch_bounds__(K2_NT)
+void k2f_commit(K2Params p)
+{
+	__shared__ MachSharedT<K2_NT> sh;
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	ChanState *cs = p.cs + sc;
+	if (p.fail[sc] >= 0x7f000000) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.cs_out + sc);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(cs);
+		for (int i = tid; i < (int)(sizeof(ChanState) / 4); i += K2_NT)
+			dst[i] = src[i];
+		return;
+	}
+	MachCtx cx;
+	mach_ctx(cx, p, s, c, false);
+	cx.dbg = nullptr;
+	MachState st;
+	st.pos = cs->pos;
+	st.r = cs->r;
+	st.fresh = cs->fresh;
+	const long long p0 = st.pos;
+	mach_init_taps(sh);
+	mach_load(sh, cs);
+	MachOut out;
+	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.neval = 0;
+	machine_run<K2_NT, false>(sh, cx, st, false, 0, 1 << 30, 0, out);
+	__syncthreads();
+	mach_store(sh, st, cs);
+	if (tid == 0) {
+		cs->n_eval += (unsigned long long)out.neval;
+		cs->n_trig += (unsigned long long)out.ntrig;
+		cs->n_reject += (unsigned long long)out.nrej;
+		cs->n_burst += (unsigned long long)out.nburst;
+		cs->n_defer += (unsigned long long)out.ndefer;
+		cs->n_slow += (unsigned long long)(st.pos - p0);
+		cs->n_redo += 1;
+		p.ctl[CTL_NSEL0 + sc] = 0;	/* K2d: nothing of the resolver's for this channel */
 	}
 }
 
@@ -1576,8 +1868,10 @@ __global__ __launch_bounds__(K2D_NT)
 void k2d_payload(K2Params p)
 {
 	__shared__ unsigned s_slot;
-	unsigned n = p.ctl[CTL_NSEL];
-	n = n > p.stage_cap ? p.stage_cap : n;
+	const int sc = blockIdx.y;
+	unsigned n = p.ctl[CTL_NSEL0 + sc];
+	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
+	const unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
 	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
 		if (threadIdx.x == 0) {
 			unsigned slot = atomicAdd(p.ctl + CTL_OUT, 1u);
@@ -1590,7 +1884,7 @@ void k2d_payload(K2Params p)
 		__syncthreads();
 		const unsigned slot = s_slot;
 		if (slot != 0xffffffffu) {
-			const BurstDesc d = p.stage[p.sel_list[i]];
+			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
 			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc]);

@@ -17,6 +17,7 @@ SAMPLE_BYTES = {"cu8": 2, "cs16": 4, "cf32": 8, "f32": 4}
 MEM_HOST, MEM_DEVICE = 0, 1
 F_KEEP_DEC = 1
 F_SERIAL = 2
+F_FULLSCAN = 4
 
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
@@ -47,7 +48,7 @@ class BurstT(C.Structure):
 
 class StatsT(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples_in", "dec_samples", "sync_evals", "triggers",
-                                          "header_rejects", "bursts", "deferrals", "candidates", "serial_samples", "overflowed")]
+                                          "header_rejects", "bursts", "deferrals", "candidates", "serial_redos", "serial_samples", "overflowed")]
 
 
 class TimingT(C.Structure):
