@@ -265,7 +265,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
 	HIPCHK(h, hipMalloc(&h->d_clusters, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
-	h->stage_cap = 131072u * (unsigned)S;
+	h->stage_cap = (unsigned)S * VDL2_CS * VDL2_CAND_CAP * VDL2_CL_MAXB + 65536u;	/* static slots + dynamic tail */
 	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
 	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
 	HIPCHK(h, hipMalloc(&h->d_regs, (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
@@ -553,7 +553,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
-		hipLaunchKernelGGL(k2b_clusters, dim3(2048), dim3(K2B_NT), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3(getenv("K2B_GRID") ? atoi(getenv("K2B_GRID")) : 3072), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);

@@ -731,6 +731,8 @@ struct MachCtx {
 	vdl2gpu_burst_t *recs;	/* sink: output ring, payload decoded at once (K2c serial stretches) ... */
 	BurstDesc *desc;	/* ... or descriptor pool, payload decoded by K2d if selected (K2b, K2c) */
 	unsigned *sel, *nsel;	/* K2c: descriptors made by its serial stretches are on the real chain */
+	unsigned dyn_base;	/* first dynamic descriptor slot */
+	long long desc_static;	/* >= 0: descriptor slots are desc_static + burst index (K2b: no atomics) */
 	int sc;
 	unsigned long long *dbg;
 	long long t_lo, t_hi;	/* stream-time range currently held in the LDS tile (cluster mode) */
@@ -1075,7 +1077,15 @@ template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachC
 		} else {
 			nlast = nsym0 + 8LL * (nsym - 1);
 			if (tid == 0) {
-				unsigned slot = atomicAdd(cx.rec_count, 1u);
+				unsigned slot;
+				if (cx.desc_static >= 0)
+					slot = (unsigned)(cx.desc_static + out.nslots);	/* out.nslots < VDL2_CL_MAXB here */
+				else {
+					/* dynamic slots live behind the static region of the pool */
+					slot = atomicAdd(cx.rec_count, 1u);
+					if (cx.desc)
+						slot += cx.dyn_base;
+				}
 				if (slot >= cx.rec_cap) {
 					atomicAdd(cx.rec_ovf, 1u);
 					slot = 0xffffffffu;
@@ -1132,14 +1142,17 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 	cx.t_lo = cx.t_hi = 0;
 	cx.grey = nullptr;
 	cx.sel = cx.nsel = nullptr;
+	cx.desc_static = -1;
 	if (to_stage) {
 		cx.recs = nullptr;
+		cx.dyn_base = (unsigned)p.nstreams * VDL2_CS * VDL2_CAND_CAP * VDL2_CL_MAXB;
 		cx.desc = p.stage;
 		cx.rec_count = p.ctl + CTL_STAGE;
 		cx.rec_ovf = p.ctl + CTL_STAGE_OVF;
 		cx.rec_cap = p.stage_cap;
 	} else {
 		cx.recs = p.recs;
+		cx.dyn_base = 0;
 		cx.desc = nullptr;
 		cx.rec_count = p.ctl + CTL_OUT;
 		cx.rec_ovf = p.ctl + CTL_OUT_OVF;
@@ -1327,32 +1340,43 @@ void k2r_regions(K2Params p)
 			}
 			__syncthreads();
 		}
-	if (tid == 0) {
+	{
+		/* every run of hits closer than VDL2_REG_GAP becomes a region (order is irrelevant) */
+		__shared__ int s_nreg;
 		const StreamState *ss = p.ss + s;
 		const int lo_lim = (int)(p.cs[sc].pos - ss->dec_base);
 		const int hi_lim = (int)(ss->dec_fill + p.J);
 		int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
-		int n = 0, i = 0;
-		bool over = false;
-		while (i < ncand) {
-			int lo = key[i], hi = key[i];
-			while (i + 1 < ncand && key[i + 1] - hi <= VDL2_REG_GAP)
-				hi = key[++i];
-			++i;
-			lo = lo - VDL2_REG_PAD < lo_lim ? lo_lim : lo - VDL2_REG_PAD;
-			hi = hi + VDL2_REG_PAD + 1 > hi_lim ? hi_lim : hi + VDL2_REG_PAD + 1;
+		if (tid == 0)
+			s_nreg = 0;
+		__syncthreads();
+		for (int i = tid; i < ncand; i += 256) {
+			if (i > 0 && key[i] - key[i - 1] <= VDL2_REG_GAP)
+				continue;	/* not the first hit of its run */
+			int j = i;
+			while (j + 1 < ncand && key[j + 1] - key[j] <= VDL2_REG_GAP)
+				++j;
+			int lo = key[i] - VDL2_REG_PAD, hi = key[j] + VDL2_REG_PAD + 1;
+			lo = lo < lo_lim ? lo_lim : lo;
+			hi = hi > hi_lim ? hi_lim : hi;
+			if (hi <= lo)
+				continue;
 			/* long merged regions (bursts back to back) are cut into tile-sized pieces */
-			for (int q = lo; q < hi; q += K2A_TS) {
-				if (n >= VDL2_REG_CAP) {
-					over = true;
-					break;
+			const int nchunk = (hi - lo + K2A_TS - 1) / K2A_TS;
+			const int base = atomicAdd(&s_nreg, nchunk);
+			for (int k = 0; k < nchunk; ++k)
+				if (base + k < VDL2_REG_CAP) {
+					const int q = lo + k * K2A_TS;
+					regs[base + k] = make_int2(q, (hi - q < K2A_TS) ? hi - q : K2A_TS);
 				}
-				regs[n++] = make_int2(q, (hi - q < K2A_TS) ? hi - q : K2A_TS);
-			}
 		}
-		p.ctl[CTL_NREG0 + sc] = (unsigned)n;
-		if (over)
-			p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 1u;	/* tables unusable -> serial */
+		__syncthreads();
+		if (tid == 0) {
+			const int n = s_nreg;
+			p.ctl[CTL_NREG0 + sc] = (unsigned)(n > VDL2_REG_CAP ? VDL2_REG_CAP : n);
+			if (n > VDL2_REG_CAP)
+				p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 1u;	/* tables unusable -> serial */
+		}
 	}
 }
 
@@ -1428,12 +1452,11 @@ void k2a_verify(K2Params p)
  * machine through the burst (and any burst that follows before the detector is
  * history-free again) and record where and how the idle search resumes.
  */
-__global__ __launch_bounds__(K2B_NT)
+__global__ __launch_bounds__(K2B_NT, 3)
 void k2b_clusters(K2Params p)
 {
 	__shared__ MachSharedT<K2B_NT> sh;
 	__shared__ float sgrey[3 * 257];
-	__shared__ int s_ticket;
 	__shared__ unsigned s_pref[65];
 	const int tid = threadIdx.x;
 	const int nsc = p.nstreams * VDL2_CS;
@@ -1459,14 +1482,7 @@ void k2b_clusters(K2Params p)
 	__syncthreads();
 	const int nsc64 = nsc < 64 ? nsc : 64;
 	const unsigned total = s_pref[nsc64];
-	for (;;) {
-		if (tid == 0)
-			s_ticket = (int)atomicAdd(p.ctl + CTL_TICKET, 1u);
-		__syncthreads();
-		const unsigned tk = (unsigned)s_ticket;
-		__syncthreads();
-		if (tk >= total)
-			break;
+	for (unsigned tk = blockIdx.x; tk < total; tk += gridDim.x) {
 		int sc = 0;
 		while (sc + 1 < nsc64 && s_pref[sc + 1] <= tk)
 			++sc;
@@ -1481,6 +1497,7 @@ void k2b_clusters(K2Params p)
 		st.r = cd.r;
 		st.fresh = VDL2_STEADY;
 		cx.grey = sgrey;
+		cx.desc_static = ((long long)sc * VDL2_CAND_CAP + idx) * VDL2_CL_MAXB;
 		MachOut out;
 		out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
 		out.neval = 0;
