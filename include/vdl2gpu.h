@@ -146,9 +146,13 @@ void vdl2gpu_destroy(vdl2gpu_t *h);
 int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind);
 /* Wait until everything pushed so far has been demodulated. */
 int vdl2gpu_sync(vdl2gpu_t *h);
-/* Collect finished bursts (implies vdl2gpu_sync).  Bursts come out ordered by
+/* Collect finished bursts (waits for everything pushed so far).  Bursts come out ordered by
  * (end_sample, stream, chn).  Returns the count (>=0) or a negative error. */
 int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
+/* Same, but never waits: hands out only the bursts of pushes the GPU has already finished.  Lets
+ * a caller keep the next push running while it consumes the previous one (two pushes can be in
+ * flight; a third push first collects the oldest). */
+int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Number of bursts a poll would currently return (implies vdl2gpu_sync). */
 int vdl2gpu_pending(vdl2gpu_t *h);
 

@@ -57,7 +57,12 @@ struct vdl2gpu {
 	ChanState *d_cs = nullptr;
 	ChanCfg *d_cfg = nullptr;
 	uint8_t *d_pn = nullptr;
-	vdl2gpu_burst_t *d_recs = nullptr;
+	vdl2gpu_burst_t *d_recs[2] = { nullptr, nullptr };	/* output rings, alternating per push */
+	unsigned *d_outc = nullptr;	/* [ring][2] = records written, dropped */
+	hipEvent_t ring_done[2] = { nullptr, nullptr };
+	bool ring_busy[2] = { false, false };
+	uint64_t ring_push[2] = { 0, 0 };	/* which push filled the ring */
+	hipStream_t copy_stream = nullptr;
 	unsigned *d_ctl = nullptr;	/* control words, see CTL_* in vdl2gpu_kernels.h */
 	size_t ctl_words = 0;
 	unsigned rec_cap = 0;
@@ -215,7 +220,14 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_cs);
 	(void)hipFree(h->d_cfg);
 	(void)hipFree(h->d_pn);
-	(void)hipFree(h->d_recs);
+	(void)hipFree(h->d_recs[0]);
+	(void)hipFree(h->d_recs[1]);
+	(void)hipFree(h->d_outc);
+	for (auto &e : h->ring_done)
+		if (e)
+			(void)hipEventDestroy(e);
+	if (h->copy_stream)
+		(void)hipStreamDestroy(h->copy_stream);
 	(void)hipFree(h->d_ctl);
 	(void)hipFree(h->d_cands);
 	(void)hipFree(h->d_clusters);
@@ -259,7 +271,13 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_cs, (size_t)S * VDL2_CS * sizeof(ChanState)));
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
 	HIPCHK(h, hipMalloc(&h->d_pn, VDL2_PN_BITS));
-	HIPCHK(h, hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
+	for (int r = 0; r < 2; ++r) {
+		HIPCHK(h, hipMalloc(&h->d_recs[r], (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
+		HIPCHK(h, hipEventCreateWithFlags(&h->ring_done[r], hipEventDisableTiming));
+	}
+	HIPCHK(h, hipMalloc(&h->d_outc, 4 * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 4 * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 	h->ctl_words = CTL_CAND0 + 5 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
@@ -276,7 +294,7 @@ static int create_impl(vdl2gpu_t *h)
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 2 * sizeof(unsigned), hipHostMallocDefault));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 4 * sizeof(unsigned), hipHostMallocDefault));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
 
@@ -400,6 +418,8 @@ static int harvest_timing(vdl2gpu_t *h)
 	return VDL2GPU_OK;
 }
 
+static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking);
+
 template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
 {
 	hipLaunchKernelGGL(k1_channelise<FMT>, grid, dim3(K1_THREADS), smem, st, p);
@@ -420,6 +440,13 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		int rc = harvest_timing(h);
 		if (rc)
+			return rc;
+	}
+	/* output ring of this push; if the push that last used it has not been collected yet, collect it now */
+	const int ring = (int)(h->pushes & 1);
+	if (h->ring_busy[ring]) {
+		int rc = harvest_ring(h, ring, true);
+		if (rc < 0)
 			return rc;
 	}
 	const void *src = iq;
@@ -476,6 +503,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	pt.samples = nsamples;
 	pt.fast = false;
 	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->d_outc + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMemsetAsync(h->d_fail, 0x7f, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
 	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
 	{
@@ -537,7 +565,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.stage = h->d_stage;
 		k2.sel_list = h->d_sel_list;
 		k2.stage_cap = h->stage_cap;
-		k2.recs = h->d_recs;
+		k2.recs = h->d_recs[ring];
+		k2.outc = h->d_outc + 2 * ring;
 		k2.rec_cap = h->rec_cap;
 		k2.force_serial = h->force_serial;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
@@ -582,6 +611,10 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		HIPCHK(h, hipGetLastError());
 	}
 	HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
+	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 2 * ring, h->d_outc + 2 * ring, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipEventRecord(h->ring_done[ring], h->stream));
+	h->ring_busy[ring] = true;
+	h->ring_push[ring] = h->pushes;
 	h->pending.push_back(pt);
 	h->total_in += nsamples;
 	h->pushes++;
@@ -597,14 +630,24 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 	return harvest_timing(h);
 }
 
-static int fetch_records(vdl2gpu_t *h)
+/* Move the records of the push that filled `ring` to the host queue.  blocking = false: only if
+ * that push has finished (returns 1 if it has not).  The copy runs on its own stream, so a later
+ * push keeps the GPU busy meanwhile. */
+static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 {
-	int rc = vdl2gpu_sync(h);
-	if (rc)
-		return rc;
-	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt, h->d_ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(h, hipStreamSynchronize(h->stream));
-	const unsigned c0 = h->h_pin_cnt[0], c1 = h->h_pin_cnt[1];
+	if (!h->ring_busy[ring])
+		return 0;
+	if (!blocking) {
+		const hipError_t q = hipEventQuery(h->ring_done[ring]);
+		if (q == hipErrorNotReady)
+			return 1;
+		if (q != hipSuccess) {
+			h->err = std::string("hipEventQuery: ") + hipGetErrorString(q);
+			return VDL2GPU_EHIP;
+		}
+	}
+	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
+	const unsigned c0 = h->h_pin_cnt[2 * ring], c1 = h->h_pin_cnt[2 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
 	if (n) {
@@ -617,9 +660,9 @@ static int fetch_records(vdl2gpu_t *h)
 		h->ready.resize(old + n);
 		for (unsigned done = 0; done < n; done += h->pin_recs) {
 			const unsigned m = std::min(h->pin_recs, n - done);
-			HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_recs + done, (size_t)m * sizeof(vdl2gpu_burst_t),
-						 hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(h, hipStreamSynchronize(h->stream));
+			HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_recs[ring] + done, (size_t)m * sizeof(vdl2gpu_burst_t),
+						 hipMemcpyDeviceToHost, h->copy_stream));
+			HIPCHK(h, hipStreamSynchronize(h->copy_stream));
 			memcpy(h->ready.data() + old + done, h->h_pin, (size_t)m * sizeof(vdl2gpu_burst_t));
 		}
 		const size_t iold = h->ready_idx.size();
@@ -641,16 +684,40 @@ static int fetch_records(vdl2gpu_t *h)
 			return a.chn < b.chn;
 		});
 	}
-	if (c0 || c1)
-		HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(unsigned), h->stream));
-	return VDL2GPU_OK;
+	h->ring_busy[ring] = false;
+	return 0;
+}
+
+static int harvest_all(vdl2gpu_t *h, bool blocking)
+{
+	/* oldest push first */
+	const int first = (h->ring_busy[0] && h->ring_busy[1] && h->ring_push[1] < h->ring_push[0]) ? 1 : 0;
+	for (int k = 0; k < 2; ++k) {
+		const int ring = first ^ k;
+		const int rc = harvest_ring(h, ring, blocking);
+		if (rc < 0)
+			return rc;
+		if (rc == 1)
+			break;	/* not finished yet; anything newer is not finished either */
+	}
+	return 0;
+}
+
+static int hand_out(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
+{
+	const int n = std::min<int>(max, (int)(h->ready_idx.size() - h->ready_pos));
+	for (int i = 0; i < n; ++i)
+		out[i] = h->ready[h->ready_idx[h->ready_pos + i]];
+	h->ready_pos += (size_t)n;
+	return n;
 }
 
 extern "C" int vdl2gpu_pending(vdl2gpu_t *h)
 {
 	if (!h)
 		return VDL2GPU_EINVAL;
-	int rc = fetch_records(h);
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	int rc = harvest_all(h, true);
 	if (rc)
 		return rc;
 	return (int)(h->ready_idx.size() - h->ready_pos);
@@ -660,14 +727,22 @@ extern "C" int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	if (!h || (max > 0 && !out) || max < 0)
 		return VDL2GPU_EINVAL;
-	int rc = fetch_records(h);
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	int rc = harvest_all(h, true);
 	if (rc)
 		return rc;
-	const int n = std::min<int>(max, (int)(h->ready_idx.size() - h->ready_pos));
-	for (int i = 0; i < n; ++i)
-		out[i] = h->ready[h->ready_idx[h->ready_pos + i]];
-	h->ready_pos += (size_t)n;
-	return n;
+	return hand_out(h, out, max);
+}
+
+extern "C" int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
+{
+	if (!h || (max > 0 && !out) || max < 0)
+		return VDL2GPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	int rc = harvest_all(h, false);
+	if (rc)
+		return rc;
+	return hand_out(h, out, max);
 }
 
 extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)

@@ -145,7 +145,8 @@ struct K2Params {
 	BurstDesc *stage;	/* burst descriptors of all clusters */
 	unsigned *sel_list;	/* descriptors on the real chain (K2c -> K2d) */
 	unsigned stage_cap;
-	vdl2gpu_burst_t *recs;
+	vdl2gpu_burst_t *recs;	/* output ring of this push */
+	unsigned *outc;		/* [0] = records written, [1] = records dropped (ring full) */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
 	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
@@ -1154,8 +1155,8 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 		cx.recs = p.recs;
 		cx.dyn_base = 0;
 		cx.desc = nullptr;
-		cx.rec_count = p.ctl + CTL_OUT;
-		cx.rec_ovf = p.ctl + CTL_OUT_OVF;
+		cx.rec_count = p.outc;
+		cx.rec_ovf = p.outc + 1;
 		cx.rec_cap = p.rec_cap;
 	}
 	cx.stream = s;
@@ -1891,9 +1892,9 @@ void k2d_payload(K2Params p)
 	const unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
 	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
 		if (threadIdx.x == 0) {
-			unsigned slot = atomicAdd(p.ctl + CTL_OUT, 1u);
+			unsigned slot = atomicAdd(p.outc, 1u);
 			if (slot >= p.rec_cap) {
-				atomicAdd(p.ctl + CTL_OUT_OVF, 1u);
+				atomicAdd(p.outc + 1, 1u);
 				slot = 0xffffffffu;
 			}
 			s_slot = slot;

@@ -129,6 +129,10 @@ class Receiver:
             if n < max_bursts:
                 return out
 
+    def poll_ready_raw(self, buf, max_bursts: int) -> int:
+        """vdl2gpu_poll_ready: bursts of pushes that have already finished; never waits."""
+        return self._check(self.L.vdl2gpu_poll_ready(self.h, buf, max_bursts))
+
     def poll_raw(self, buf, max_bursts: int) -> int:
         """vdl2gpu_poll into a caller-owned (lib.BurstT * max_bursts) array; no Python objects."""
         return self._check(self.L.vdl2gpu_poll(self.h, buf, max_bursts))

@@ -22,7 +22,7 @@ F_FULLSCAN = 4
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
     "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
-    "vdl2gpu_poll", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
+    "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
     "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands",
 )
@@ -94,6 +94,8 @@ def load():
     L.vdl2gpu_sync.argtypes = [C.c_void_p]
     L.vdl2gpu_poll.restype = C.c_int
     L.vdl2gpu_poll.argtypes = [C.c_void_p, C.POINTER(BurstT), C.c_int]
+    L.vdl2gpu_poll_ready.restype = C.c_int
+    L.vdl2gpu_poll_ready.argtypes = [C.c_void_p, C.POINTER(BurstT), C.c_int]
     L.vdl2gpu_pending.restype = C.c_int
     L.vdl2gpu_pending.argtypes = [C.c_void_p]
     L.vdl2gpu_get_stats.restype = C.c_int
