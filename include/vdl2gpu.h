@@ -87,6 +87,7 @@ typedef struct {
 
 #define VDL2GPU_F_KEEP_DEC 1u	/* keep each push's decimated stream for vdl2gpu_debug_dec() */
 #define VDL2GPU_F_FULLSCAN 4u	/* scan all four FIR sub-phases everywhere instead of probe + regions + verify */
+#define VDL2GPU_F_TEST_NOREGION 8u	/* test hook: drop the region scan; the verify pass must then redo channels serially */
 #define VDL2GPU_F_SERIAL 2u	/* diagnostics: skip the parallel sync tables, one serial machine per channel */
 
 /* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */

@@ -200,3 +200,41 @@ def test_scan_modes_agree_with_oracle(built, oracle, mode):
     assert st["serial_redos"] == 0
     if mode == "serial":
         assert st["candidates"] == 0
+
+
+def test_verify_pass_catches_incomplete_tables(built, oracle):
+    """With the region scan switched off the candidate tables lack most trigger classes, so the
+    resolver's chain is wrong after the first burst; K2a-verify must notice and the serial redo must
+    still deliver exactly the oracle's bursts."""
+    from vdlm2dec_amd import lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = synth.random_scenario(2_000_000, S.FO8[:3], 1 << 21, seed=92, bursts_per_s=10.0, info_max=100)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20,
+                  flags=lib.F_TEST_NOREGION) as rx:
+        got = rx.run(raw, block=600_000)
+        st = rx.stats()
+    assert st["serial_redos"] > 0
+    assert _gpu_keys(got) == want and len(want) >= 15
+
+
+def test_pipelined_polling_delivers_everything_once(built, oracle):
+    """vdl2gpu_poll_ready (non-blocking) + a final vdl2gpu_poll: two pushes in flight, every burst
+    handed out exactly once, in stream-time order per poll."""
+    from vdlm2dec_amd import lib
+    from vdlm2dec_amd.demod import Burst
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 1 << 21, seed=93, bursts_per_s=12.0, info_max=80)
+    raw = synth.synth_stream(spec, "cu8")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cu8", spec.rate, spec.fo, S.FC))
+    buf = (lib.BurstT * 4096)()
+    got = []
+    with _rx(spec.rate, spec.fo, "cu8", max_push=1 << 18) as rx:
+        blk = 1 << 18
+        for s0 in range(0, spec.nsamples, blk):
+            rx.push(raw[2 * s0:2 * (s0 + blk)])
+            n = rx.poll_ready_raw(buf, 4096)
+            got += [(buf[i].chn, buf[i].nbrow, buf[i].nlbyte, bytes(buf[i].data)) for i in range(n)]
+        n = rx.poll_raw(buf, 4096)
+        got += [(buf[i].chn, buf[i].nbrow, buf[i].nlbyte, bytes(buf[i].data)) for i in range(n)]
+    assert sorted(got) == want and len(want) >= 20

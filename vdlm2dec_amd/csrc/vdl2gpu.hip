@@ -571,6 +571,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.force_serial = h->force_serial;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
 		k2.full_scan = h->full_scan;
+		k2.test_noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) ? 1 : 0;
 		k2.regs = h->d_regs;
 		k2.segs = h->d_segs;
 		k2.fail = h->d_fail;

@@ -150,6 +150,7 @@ struct K2Params {
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
 	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
+	int test_noregion;	/* test hook: skip the region scan so that K2a-verify must catch the misses */
 	int2 *regs;		/* [S*8][REG_CAP] (lo, count) stream-relative */
 	Seg *segs;		/* [S*8][SEG_CAP] */
 	int *fail;		/* [S*8] earliest unexpected hit (stream-relative), INT_MAX = verified */
@@ -1387,7 +1388,7 @@ void k2a_region(K2Params p)
 	__shared__ K2aShared sh;
 	const int c = blockIdx.y, s = blockIdx.z;
 	const int sc = s * VDL2_CS + c;
-	if (p.force_serial || p.full_scan)
+	if (p.force_serial || p.full_scan || p.test_noregion)
 		return;
 	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
 	const long long dec_base = p.ss[s].dec_base;

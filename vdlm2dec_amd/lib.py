@@ -18,6 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 F_KEEP_DEC = 1
 F_SERIAL = 2
 F_FULLSCAN = 4
+F_TEST_NOREGION = 8
 
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
