@@ -74,6 +74,8 @@ struct vdl2gpu {
 	Seg *d_segs = nullptr;
 	int *d_fail = nullptr;
 	ChanState *d_cs_out = nullptr;
+	int *d_skey = nullptr;
+	unsigned short *d_sidx = nullptr, *d_prim = nullptr;
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int force_serial = 0;
@@ -237,6 +239,9 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_segs);
 	(void)hipFree(h->d_fail);
 	(void)hipFree(h->d_cs_out);
+	(void)hipFree(h->d_skey);
+	(void)hipFree(h->d_sidx);
+	(void)hipFree(h->d_prim);
 	(void)hipFree(h->d_dbg);
 	if (h->h_pin)
 		(void)hipHostFree(h->h_pin);
@@ -278,7 +283,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_outc, 4 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 4 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-	h->ctl_words = CTL_CAND0 + 5 * (size_t)S * VDL2_CS;
+	h->ctl_words = CTL_CAND0 + 6 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
@@ -290,6 +295,9 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_segs, (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
 	HIPCHK(h, hipMalloc(&h->d_fail, (size_t)S * VDL2_CS * sizeof(int)));
 	HIPCHK(h, hipMalloc(&h->d_cs_out, (size_t)S * VDL2_CS * sizeof(ChanState)));
+	HIPCHK(h, hipMalloc(&h->d_skey, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
+	HIPCHK(h, hipMalloc(&h->d_sidx, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
+	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
@@ -576,12 +584,16 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.segs = h->d_segs;
 		k2.fail = h->d_fail;
 		k2.cs_out = h->d_cs_out;
+		k2.skey = h->d_skey;
+		k2.sidx = h->d_sidx;
+		k2.prim = h->d_prim;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
 		hipLaunchKernelGGL(k2a_probe, dim3(tiles, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2r_regions, gch, dim3(256), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
 		hipLaunchKernelGGL(k2b_clusters, dim3(getenv("K2B_GRID") ? atoi(getenv("K2B_GRID")) : 3072), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());

@@ -155,6 +155,9 @@ struct K2Params {
 	Seg *segs;		/* [S*8][SEG_CAP] */
 	int *fail;		/* [S*8] earliest unexpected hit (stream-relative), INT_MAX = verified */
 	ChanState *cs_out;	/* resolver result, committed by K2f */
+	int *skey;		/* [S*8][CAND_CAP] candidates sorted by time: nrel*4 + r */
+	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
+	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
 	unsigned long long *dbg;	/* diagnostics: cycle counters */
 };
 #define CTL_OUT 0
@@ -166,6 +169,7 @@ struct K2Params {
 #define CTL_NREG0 (CTL_CAND0 + 2 * p.nstreams * VDL2_CS)
 #define CTL_NSEG0 (CTL_CAND0 + 3 * p.nstreams * VDL2_CS)
 #define CTL_NSEL0 (CTL_CAND0 + 4 * p.nstreams * VDL2_CS)
+#define CTL_NPRIM0 (CTL_CAND0 + 5 * p.nstreams * VDL2_CS)
 
 struct K3Params {
 	const float2 *src;
@@ -1448,6 +1452,82 @@ void k2a_verify(K2Params p)
 	}
 }
 
+/* ====================================================================== K2s
+ * Per channel: sort the candidates by time (bitonic network in LDS) for the resolver, and pick the
+ * ones whose cluster is worth precomputing: the first of its (sub-phase, parity) class within a
+ * burst's worth of samples.  A later candidate of the same class can only be reached if the detector
+ * turns history-free in the few samples between the two; the resolver computes such a cluster itself
+ * when it ever needs one (status CL_INVALID), so this is a cost decision, never a correctness one.
+ */
+#define K2S_NT 1024
+#define K2S_LOOKBACK 72		/* a triggered detector is busy for at least 9 symbols = 72 samples */
+__global__ __launch_bounds__(K2S_NT)
+void k2s_sort(K2Params p)
+{
+	__shared__ unsigned long long sbuf[VDL2_CAND_CAP];
+	__shared__ int s_np;
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial)
+		return;
+	int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	if (ncand > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] != 0)
+		return;		/* tables unusable: the resolver runs serially */
+	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
+	int npow = 1;
+	while (npow < ncand)
+		npow <<= 1;
+	for (int i = tid; i < npow; i += K2S_NT)
+		sbuf[i] = (i < ncand) ? (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i
+				      : ~0ull;
+	if (tid == 0)
+		s_np = 0;
+	__syncthreads();
+	for (int k = 2; k <= npow; k <<= 1)
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			for (int i = tid; i < npow; i += K2S_NT) {
+				const int l = i ^ j;
+				if (l > i) {
+					const unsigned long long a0 = sbuf[i], b0 = sbuf[l];
+					if ((a0 > b0) == ((i & k) == 0)) {
+						sbuf[i] = b0;
+						sbuf[l] = a0;
+					}
+				}
+			}
+			__syncthreads();
+		}
+	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
+	for (int j = tid; j < ncand; j += K2S_NT) {
+		const unsigned long long v = sbuf[j];
+		const int key = (int)(v >> 16), idx = (int)(v & 0xffffu);
+		skey[j] = key;
+		sidx[j] = (unsigned short)idx;
+		const int n = key >> 2, cls = (key & 3) * 2 + (n & 1);
+		bool primary = true;
+		for (int i = j - 1; i >= 0; --i) {
+			const int ki = (int)(sbuf[i] >> 16), ni = ki >> 2;
+			if (n - ni >= K2S_LOOKBACK)
+				break;
+			if ((ki & 3) * 2 + (ni & 1) == cls) {
+				primary = false;
+				break;
+			}
+		}
+		if (primary)
+			prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
+		else
+			clusters[idx].status = CL_INVALID;
+	}
+	__syncthreads();
+	if (tid == 0)
+		p.ctl[CTL_NPRIM0 + sc] = (unsigned)s_np;
+}
+
 /* ====================================================================== K2b
  * One workgroup per trigger candidate (persistent workgroups pull tickets):
  * put the detector in the history-free state at the candidate, run the exact
@@ -1474,7 +1554,7 @@ void k2b_clusters(K2Params p)
 	if (tid == 0) {
 		unsigned acc = 0;
 		for (int k = 0; k < nsc && k < 64; ++k) {
-			unsigned n = p.ctl[CTL_CAND0 + k];
+			unsigned n = p.ctl[CTL_NPRIM0 + k];
 			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
 			s_pref[k] = acc;
 			acc += n;
@@ -1488,7 +1568,7 @@ void k2b_clusters(K2Params p)
 		int sc = 0;
 		while (sc + 1 < nsc64 && s_pref[sc + 1] <= tk)
 			++sc;
-		const int idx = (int)(tk - s_pref[sc]);
+		const int idx = (int)p.prim[(size_t)sc * VDL2_CAND_CAP + (tk - s_pref[sc])];
 		const int s = sc / VDL2_CS, c = sc % VDL2_CS;
 		MachCtx cx;
 		mach_ctx(cx, p, s, c, true);
@@ -1592,7 +1672,6 @@ void k2c_resolve(K2Params p)
 {
 	__shared__ MachSharedT<K2_NT> sh;
 	__shared__ int skey[VDL2_CAND_CAP];		/* sorted keys: nrel*4 + r */
-	__shared__ unsigned long long sbuf[VDL2_CAND_CAP];	/* sort buffer */
 	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
 	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
 	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
@@ -1632,35 +1711,12 @@ void k2c_resolve(K2Params p)
 		ncand = 0;
 	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
 	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
-	/* 1. sort the candidates by time: bitonic network on (key << 16 | index) in LDS */
+	/* 1. candidates sorted by time (K2s) */
 	const long long pos_in = st.pos;
 	const long long tk0 = wall_clock64();
-	int npow = 1;
-	while (npow < ncand)
-		npow <<= 1;
-	for (int i = tid; i < npow; i += K2_NT)
-		sbuf[i] = (i < ncand) ? (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i
-				      : ~0ull;
-	__syncthreads();
-	for (int k = 2; k <= npow; k <<= 1)
-		for (int j = k >> 1; j > 0; j >>= 1) {
-			for (int i = tid; i < npow; i += K2_NT) {
-				const int l = i ^ j;
-				if (l > i) {
-					const unsigned long long a0 = sbuf[i], b0 = sbuf[l];
-					const bool up = ((i & k) == 0);
-					if ((a0 > b0) == up) {
-						sbuf[i] = b0;
-						sbuf[l] = a0;
-					}
-				}
-			}
-			__syncthreads();
-		}
 	for (int i = tid; i < ncand; i += K2_NT) {
-		const unsigned long long v = sbuf[i];
-		skey[i] = (int)(v >> 16);
-		sidx[i] = (unsigned short)(v & 0xffffu);
+		skey[i] = p.skey[(size_t)sc * VDL2_CAND_CAP + i];
+		sidx[i] = p.sidx[(size_t)sc * VDL2_CAND_CAP + i];
 	}
 	__syncthreads();
 	const long long tk1 = wall_clock64();
