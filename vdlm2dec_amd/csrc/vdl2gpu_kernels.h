@@ -1192,7 +1192,6 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
-#define K2A_RSLOTS 3		/* sub-phases per tile pass (a 4-sub-phase scan takes two passes) */
 #define VDL2_REG_CAP 1024	/* probe-hit regions per channel per push */
 #define VDL2_REG_PAD 40		/* samples scanned on either side of a probe hit */
 #define VDL2_REG_GAP 96		/* hits closer than this share a region */
@@ -1200,11 +1199,15 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 
 struct K2aShared {
 	float2 xs[K2A_XMAX];
-	float ph[K2A_RSLOTS][K2A_TS + K2A_POFF];
+	float ph[K2A_TS + K2A_POFF];
 	float eb[K2A_TS + 4], fb[K2A_TS + 4];
+	float smf[72];		/* low-pass taps mflt[] (d8psk.h:28-45) */
 };
 
-/* mode 0: append candidates; mode 1: report the earliest hit in [chk_lo, chk_hi) to *fail */
+/* mode 0: append candidates; mode 1: report the earliest hit in [chk_lo, chk_hi) to *fail.
+ * One sub-phase per pass: phases of all instants, barrier, fit errors, barrier, detector test.
+ * The taps are read from LDS with a wave-uniform index (mflt[r], mflt[r+4], ..) so that one code
+ * path serves every sub-phase and no scalar registers are spent on 4 x 17 tap constants. */
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
 					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail)
 {
@@ -1217,82 +1220,64 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	__syncthreads();
 	for (int i = tid; i < nx; i += K2A_THREADS)
 		sh.xs[i] = x[i];
+	for (int i = tid; i < 72; i += K2A_THREADS)
+		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
 	__syncthreads();
 	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
 	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
 	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
-	unsigned todo = rmask & 0xfu;
-	while (todo) {
-		/* up to K2A_RSLOTS sub-phases per pass */
-		int rs[K2A_RSLOTS], nr = 0;
-		for (int r = 0; r < 4 && nr < K2A_RSLOTS; ++r)
-			if (todo & (1u << r)) {
-				rs[nr++] = r;
-				todo &= ~(1u << r);
-			}
-		/* phases of instants -PH .. cnt-1 from one register copy of the 17-sample window */
+#pragma unroll 1
+	for (int r = 0; r < 4; ++r) {
+		if (!(rmask & (1u << r)))
+			continue;
+		/* phases of instants -PH .. cnt-1 */
+		const float *mf = &sh.smf[r];
+		const bool tap17 = (r == 0);	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
 		for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
-			float2 xv[17];
-			const float2 *xq = &sh.xs[S * q + (K2A_POFF - S * PH)];	/* sample (nbase + S*(q-PH)) - 16 */
+			const v2f *xq = reinterpret_cast<const v2f *>(&sh.xs[S * q + (K2A_POFF - S * PH)]);	/* sample (nbase + S*(q-PH)) - 16 */
+			v2f acc = {0.0f, 0.0f};
 #pragma unroll
-			for (int j = 0; j < 17; ++j)
-				xv[j] = xq[j];
-#pragma unroll
-			for (int k = 0; k < K2A_RSLOTS; ++k) {
-				if (k < nr) {
-					const int r = rs[k];
-					float sr = 0.0f, si = 0.0f;
-					switch (r) {
-#define K2A_FIR(R)									\
-					case R:								\
-						_Pragma("unroll") for (int j = 0; j < 17; ++j)		\
-							if (R + 4 * j < 65) {				\
-								const float m = d_tab(c_mflt, R + 4 * j);	\
-								sr += xv[j].x * m;			\
-								si += xv[j].y * m;			\
-							}						\
-						break;
-					K2A_FIR(0) K2A_FIR(1) K2A_FIR(2) K2A_FIR(3)
-#undef K2A_FIR
-					}
-					sh.ph[k][q] = vdl2_atan2f(si, sr);
+			for (int j = 0; j < 16; ++j) {
+				const float m = mf[4 * j];
+				acc += xq[j] * (v2f){m, m};
+			}
+			if (tap17) {
+				const float m = mf[64];
+				acc += xq[16] * (v2f){m, m};
+			}
+			sh.ph[q] = vdl2_atan2f(acc.y, acc.x);
+		}
+		__syncthreads();
+		/* fit errors for instants -E4 .. cnt-1: eb[i] <-> instant i - E4 */
+		for (int i = tid; i < cnt + E4; i += K2A_THREADS) {
+			float fr;
+			sh.eb[i] = k2_sync_metric<LSTR>(&sh.ph[PH - E4 + i - 16 * LSTR], &fr);
+			sh.fb[i] = fr;
+		}
+		__syncthreads();
+		for (int i = tid; i < cnt; i += K2A_THREADS) {
+			const float perr = sh.eb[i + E4 - E2], err = sh.eb[i + E4];
+			if (perr < 4.0f && err > perr) {
+				const long long n = nbase + (long long)S * i;
+				if (mode == 0) {
+					const unsigned kk = atomicAdd(cntp, 1u);
+					if (kk < VDL2_CAND_CAP) {
+						Cand cd;
+						cd.nrel = (int)(n - dec_base);
+						cd.r = r;
+						cd.p2err = sh.eb[i];
+						cd.perr = perr;
+						cd.err = err;
+						cd.pfr = sh.fb[i + E4 - E2];
+						cl[kk] = cd;
+					} else
+						*ovf = 1u;
+				} else if (n >= chk_lo && n < chk_hi) {
+					atomicMin(fail, (int)(n - dec_base));
 				}
 			}
 		}
 		__syncthreads();
-		for (int k = 0; k < nr; ++k) {
-			const int r = rs[k];
-			/* fit errors for instants -E4 .. cnt-1: eb[i] <-> instant i - E4 */
-			for (int i = tid; i < cnt + E4; i += K2A_THREADS) {
-				float fr;
-				sh.eb[i] = k2_sync_metric<LSTR>(&sh.ph[k][PH - E4 + i - 16 * LSTR], &fr);
-				sh.fb[i] = fr;
-			}
-			__syncthreads();
-			for (int i = tid; i < cnt; i += K2A_THREADS) {
-				const float perr = sh.eb[i + E4 - E2], err = sh.eb[i + E4];
-				if (perr < 4.0f && err > perr) {
-					const long long n = nbase + (long long)S * i;
-					if (mode == 0) {
-						const unsigned kk = atomicAdd(cntp, 1u);
-						if (kk < VDL2_CAND_CAP) {
-							Cand cd;
-							cd.nrel = (int)(n - dec_base);
-							cd.r = r;
-							cd.p2err = sh.eb[i];
-							cd.perr = perr;
-							cd.err = err;
-							cd.pfr = sh.fb[i + E4 - E2];
-							cl[kk] = cd;
-						} else
-							*ovf = 1u;
-					} else if (n >= chk_lo && n < chk_hi) {
-						atomicMin(fail, (int)(n - dec_base));
-					}
-				}
-			}
-			__syncthreads();
-		}
 	}
 }
 
