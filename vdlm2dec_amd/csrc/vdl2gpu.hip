@@ -589,7 +589,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.prim = h->d_prim;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
-		hipLaunchKernelGGL(k2a_probe, dim3(tiles, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2a_probe, dim3(h->full_scan ? tiles : tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2r_regions, gch, dim3(256), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());

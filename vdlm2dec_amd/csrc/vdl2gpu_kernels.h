@@ -1209,7 +1209,8 @@ struct K2aShared {
  * The taps are read from LDS with a wave-uniform index (mflt[r], mflt[r+4], ..) so that one code
  * path serves every sub-phase and no scalar registers are spent on 4 x 17 tap constants. */
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
-					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail)
+					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail,
+					   int skip_r = -1, int skip_par = 0)
 {
 	const int tid = threadIdx.x;
 	constexpr int PH = K2A_POFF / S;	/* phase instants of history */
@@ -1260,6 +1261,8 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 			if (perr < 4.0f && err > perr) {
 				const long long n = nbase + (long long)S * i;
 				if (mode == 0) {
+					if (r == skip_r && (int)(n & 1) == skip_par)
+						continue;	/* that class is the probe's: already in the table */
 					const unsigned kk = atomicAdd(cntp, 1u);
 					if (kk < VDL2_CAND_CAP) {
 						Cand cd;
@@ -1290,12 +1293,23 @@ void k2a_probe(K2Params p)
 	const StreamState *ss = p.ss + s;
 	const long long dec_base = ss->dec_base;
 	const long long avail_end = dec_base + ss->dec_fill + p.J;
-	const long long n0 = p.cs[sc].pos + (long long)blockIdx.x * K2A_TS;
-	if (n0 >= avail_end || p.force_serial)
+	if (p.force_serial)
 		return;
-	const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
-	const unsigned rmask = p.full_scan ? 0xfu : (1u << p.cs[sc].r);
-	k2a_tile<1>(sh, p, sc, dec_base, n0, nt, rmask, 0, 0, 0, nullptr);
+	if (p.full_scan) {
+		const long long n0 = p.cs[sc].pos + (long long)blockIdx.x * K2A_TS;
+		if (n0 >= avail_end)
+			return;
+		const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
+		k2a_tile<1>(sh, p, sc, dec_base, n0, nt, 0xfu, 0, 0, 0, nullptr);
+		return;
+	}
+	/* the class the channel's detector is in right now: sub-phase r, parity of pos */
+	const long long n0 = p.cs[sc].pos + 2LL * blockIdx.x * K2A_TS;
+	if (n0 >= avail_end)
+		return;
+	const long long left = (avail_end - n0 + 1) / 2;
+	const int nt = (int)(left < K2A_TS ? left : K2A_TS);
+	k2a_tile<2>(sh, p, sc, dec_base, n0, nt, 1u << p.cs[sc].r, 0, 0, 0, nullptr);
 }
 
 /* ---- regions around the probe's hits (one workgroup per channel) */
@@ -1383,7 +1397,7 @@ void k2a_region(K2Params p)
 	const long long dec_base = p.ss[s].dec_base;
 	for (unsigned k = blockIdx.x; k < nreg; k += gridDim.x) {
 		const int2 rg = p.regs[(size_t)sc * VDL2_REG_CAP + k];
-		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu & ~(1u << p.cs[sc].r), 0, 0, 0, nullptr);
+		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu, 0, 0, 0, nullptr, p.cs[sc].r, (int)(p.cs[sc].pos & 1));
 	}
 }
 
@@ -1682,6 +1696,7 @@ void k2c_resolve(K2Params p)
 	st.r = cs->r;
 	st.fresh = cs->fresh;
 	const int r_probe = cs->r;
+	const int par_probe = (int)(cs->pos & 1);	/* the probe scanned class (r_probe, par_probe) everywhere */
 	const int t_end = (int)(cx.avail_end - cx.dec_base);
 	const bool lazy = !p.full_scan;
 	mach_init_taps(sh);
@@ -1733,7 +1748,7 @@ void k2c_resolve(K2Params p)
 		if (tid == 0) {
 			int cur = k2c_next(skey, ncand, 0, (int)(st.pos - cx.dec_base), st.r);
 			int last = -1, why = 0;	/* why: 0 = no more candidates, 1 = special cluster at cur */
-			if (lazy && st.r != r_probe) {
+			if (lazy && (st.r != r_probe || (int)(st.pos & 1) != par_probe)) {
 				/* the chain idles from here to the next candidate in a class the probe did not
 				 * scan: K2a-verify must confirm there really is nothing in between */
 				const unsigned q = atomicAdd(nseg, 1u);
@@ -1821,7 +1836,7 @@ void k2c_resolve(K2Params p)
 				a += cl->ntrig;
 				b += cl->nrej;
 				d += cl->nburst;
-				if (lazy && sstat[j] == CL_STEADY && cl->r_s != r_probe) {
+				if (lazy && sstat[j] == CL_STEADY && (cl->r_s != r_probe || (int)(cl->n_s & 1) != par_probe)) {
 					/* after this cluster the chain idles in class (r_s, parity of n_s) until
 					 * the successor's trigger (or the end of the data) */
 					const unsigned q = atomicAdd(nseg, 1u);
