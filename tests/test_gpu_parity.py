@@ -238,3 +238,18 @@ def test_pipelined_polling_delivers_everything_once(built, oracle):
         n = rx.poll_raw(buf, 4096)
         got += [(buf[i].chn, buf[i].nbrow, buf[i].nlbyte, bytes(buf[i].data)) for i in range(n)]
     assert sorted(got) == want and len(want) >= 20
+
+
+def test_many_streams_batch(built, oracle):
+    """More than 8 streams (= more than 64 channel slots) in one handle: config-4 shape."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    specs = [S.eight_channels(seed=400 + i, dur=0.06, info=(3, 9, 5, 12, 7, 4, 6, 8)) for i in range(10)]
+    raws = [synth.synth_stream(sp, "cs16") for sp in specs]
+    n = min(len(r) for r in raws)
+    raw = np.stack([r[:n] for r in raws])
+    with Receiver(2_000_000, [plan_channels(S.FC, sp.fo) for sp in specs], fmt="cs16", max_push=n // 2) as rx:
+        got = rx.run(raw)
+    for s in (0, 7, 8, 9):
+        want = sorted(b.key() for b in oracle.run_oracle(raws[s][:n], "cs16", specs[s].rate, specs[s].fo, S.FC))
+        mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
+        assert mine == want and len(want) >= 6, s

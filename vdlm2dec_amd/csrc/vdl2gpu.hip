@@ -79,6 +79,7 @@ struct vdl2gpu {
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int force_serial = 0;
+	int n_cu = 256;
 	unsigned long long *d_dbg = nullptr;
 	uint64_t total_in = 0;		/* samples per stream pushed so far */
 	uint64_t pushes = 0;
@@ -263,6 +264,11 @@ static int create_impl(vdl2gpu_t *h)
 		return VDL2GPU_ENODEV;
 	}
 	HIPCHK(h, hipSetDevice(cfg.device));
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
+			h->n_cu = prop.multiProcessorCount;
+	}
 	HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	const int S = h->S, L = h->L;
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
@@ -537,15 +543,37 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		if (fast) {
 			/* whole 1 ms periods in the middle on the register-resident fast path; the first
 			 * period (carried partial window) and the tail on the general kernel */
+			k1.variant = getenv("VDL2GPU_K1_VARIANT") ? atoi(getenv("VDL2GPU_K1_VARIANT")) : 0;
 			k1.per_lo = 1;
 			k1.per_n = periods - 2;
 			generic(0, K1F_PER_OUT - 1);
 			pt.fast = true;
 			HIPCHK(h, hipEventRecord(pt.e[8], h->stream));
-			const dim3 grid((unsigned)((k1.per_n + K1F_PB - 1) / K1F_PB) * K1F_ROLES, (unsigned)h->S);
+			/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of
+			 * rounds of the GPU's wave slots (5 per SIMD at this kernel's register count) */
+			{
+				const double work = (double)k1.per_n * K1F_ROLES * h->S;
+				const double slots = (double)h->n_cu * 4 * 5;
+				double rounds = std::ceil(work / (slots * K1F_PB));
+				if (rounds < 1)
+					rounds = 1;
+				long long pb = (long long)std::ceil(work / (slots * rounds));
+				pb = std::max<long long>(8, std::min<long long>(pb, 64));
+				k1.per_pb = (int)pb;
+			}
+			const dim3 grid((unsigned)((k1.per_n + k1.per_pb - 1) / k1.per_pb) * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-			case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CS16>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			case VDL2GPU_FMT_CS16:
+				switch (k1.variant) {	/* development ablations; 0 in production */
+				case 1: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 1>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				case 2: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 2>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				case 3: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 3>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				case 4: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 4>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				case 7: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 7>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				default: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 0>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				}
+				break;
 			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
 			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
 			}
@@ -595,7 +623,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		HIPCHK(h, hipGetLastError());
 		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
-		hipLaunchKernelGGL(k2b_clusters, dim3(getenv("K2B_GRID") ? atoi(getenv("K2B_GRID")) : 3072), dim3(K2B_NT), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3(3072, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);

@@ -123,6 +123,8 @@ struct K1Params {
 	long long N, J;
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
 	long long per_lo, per_n;	/* fast kernel: whole 84-output periods [per_lo, per_lo+per_n) */
+	int per_pb;		/* periods per wavefront (chosen so that the waves fill the GPU evenly) */
+	int variant;		/* development only: 1 = skip stores, 2 = skip refills, 4 = skip mixing */
 	const float2 *lo;	/* [S][8][L] */
 	float2 *dec;		/* this push's planes, [S][8][cap] */
 	long long cap;
@@ -374,7 +376,7 @@ template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<F
 	}
 }
 
-template <int FMT> __global__ __launch_bounds__(K1F_THREADS)
+template <int FMT, int VAR = 0> __global__ __launch_bounds__(K1F_THREADS)
 void k1_fast(K1Params p)
 {
 	typedef typename K1Raw<FMT>::T raw_t;
@@ -382,9 +384,9 @@ void k1_fast(K1Params p)
 	const int lane = threadIdx.x;
 	const int s = blockIdx.y;
 	const int g = blockIdx.x % K1F_ROLES;
-	const long long pp0 = p.per_lo + (long long)(blockIdx.x / K1F_ROLES) * K1F_PB;
+	const long long pp0 = p.per_lo + (long long)(blockIdx.x / K1F_ROLES) * p.per_pb;
 	long long npl = p.per_lo + p.per_n - pp0;
-	npl = npl > K1F_PB ? K1F_PB : npl;
+	npl = npl > p.per_pb ? p.per_pb : npl;
 	if (npl <= 0)
 		return;
 	const int np = (int)npl;
@@ -419,6 +421,7 @@ void k1_fast(K1Params p)
 		}
 	}
 	const float fn = (float)nwin;
+	const float rfn = 1.0f / (nwin ? fn : 1.0f);	/* RN(1/nf) for the exact FMA division below */
 	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill + pp0 * K1F_PER_OUT + k;
 	/* lanes fetch samples lane, lane+64, lane+128 of the slice (clamped: the tail lanes of the
 	 * last load re-read the last sample instead of branching) */
@@ -445,9 +448,11 @@ void k1_fast(K1Params p)
 				for (int u = 0; u < 3; ++u)
 					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
 				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
+				if (!(VAR & 2)) {
 #pragma unroll
-				for (int u = 0; u < 3; ++u)
-					rr[d][u] = k1_raw_load<FMT>(raw, sbase + (long long)K1F_PER_IN * qn + li[u]);
+					for (int u = 0; u < 3; ++u)
+						rr[d][u] = k1_raw_load<FMT>(raw, sbase + (long long)K1F_PER_IN * qn + li[u]);
+				}
 				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
 				if (active) {
 					const v2f *xp = reinterpret_cast<const v2f *>(&xs[off]);
@@ -464,13 +469,26 @@ void k1_fast(K1Params p)
 						}
 					} else {
 #pragma unroll
-						for (int t = 0; t < 23; ++t)
+						for (int t = (VAR & 4) ? 22 : 0; t < 23; ++t)
 							k1_cmac(acc, xp[t], w[t]);
 						if (nwin == 24)
 							k1_cmac(acc, xp[23], w[23]);
 					}
-					const v2f res = acc / (v2f){fn, fn};
-					dec[(long long)q * K1F_PER_OUT] = make_float2(res.x, res.y);
+					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
+					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
+					 * checked for nf = 23, 24: tests/ctests/div_check.c); below that, and only
+					 * then, the plain IEEE division is used */
+					float qr, qi;
+					if (__all(fabsf(acc.x) >= 1e-30f && fabsf(acc.y) >= 1e-30f)) {
+						const float q0r = acc.x * rfn, q0i = acc.y * rfn;
+						qr = fmaf(fmaf(-q0r, fn, acc.x), rfn, q0r);
+						qi = fmaf(fmaf(-q0i, fn, acc.y), rfn, q0i);
+					} else {
+						qr = acc.x / fn;
+						qi = acc.y / fn;
+					}
+					if (!(VAR & 1) || qr == 12345.678f)
+						dec[(long long)q * K1F_PER_OUT] = make_float2(qr, qi);
 				}
 				__syncthreads();	/* reads done before the slice is overwritten */
 			}
@@ -1105,8 +1123,13 @@ template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachC
 					d.nlbyte = nlbyte;
 					d.pad = 0;
 					cx.desc[slot] = d;
-					if (cx.sel)
-						cx.sel[atomicAdd(cx.nsel, 1u)] = slot;
+					if (cx.sel) {
+						const unsigned q = atomicAdd(cx.nsel, 1u);
+						if (q < VDL2_SEL_CAP)
+							cx.sel[q] = slot;
+						else
+							atomicAdd(cx.rec_ovf, 1u);
+					}
 				}
 				sh.ctl[6] = (int)slot;
 			}
@@ -1549,25 +1572,28 @@ void k2b_clusters(K2Params p)
 		sgrey[514 + i] = d_tab(c_grey3, i);
 	}
 	mach_init_taps(sh);
-	/* exclusive prefix of the (clamped) candidate counts; nsc <= 64 in one pass per 64 */
+	/* blockIdx.y selects a group of up to 64 (stream, channel) slots; exclusive prefix of the
+	 * group's cluster counts maps a ticket to (slot, primary candidate) */
+	const int sc0 = (int)blockIdx.y * 64;
+	const int nsc64 = (nsc - sc0) < 64 ? (nsc - sc0) : 64;
 	if (tid == 0) {
 		unsigned acc = 0;
-		for (int k = 0; k < nsc && k < 64; ++k) {
-			unsigned n = p.ctl[CTL_NPRIM0 + k];
+		for (int k = 0; k < nsc64; ++k) {
+			unsigned n = p.ctl[CTL_NPRIM0 + sc0 + k];
 			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
 			s_pref[k] = acc;
 			acc += n;
 		}
-		s_pref[nsc < 64 ? nsc : 64] = acc;
+		s_pref[nsc64] = acc;
 	}
 	__syncthreads();
-	const int nsc64 = nsc < 64 ? nsc : 64;
 	const unsigned total = s_pref[nsc64];
 	for (unsigned tk = blockIdx.x; tk < total; tk += gridDim.x) {
-		int sc = 0;
-		while (sc + 1 < nsc64 && s_pref[sc + 1] <= tk)
-			++sc;
-		const int idx = (int)p.prim[(size_t)sc * VDL2_CAND_CAP + (tk - s_pref[sc])];
+		int scl = 0;
+		while (scl + 1 < nsc64 && s_pref[scl + 1] <= tk)
+			++scl;
+		const int sc = sc0 + scl;
+		const int idx = (int)p.prim[(size_t)sc * VDL2_CAND_CAP + (tk - s_pref[scl])];
 		const int s = sc / VDL2_CS, c = sc % VDL2_CS;
 		MachCtx cx;
 		mach_ctx(cx, p, s, c, true);
@@ -1831,8 +1857,13 @@ void k2c_resolve(K2Params p)
 			if (ssel[j]) {
 				const Cluster *cl = clusters + sidx[j];
 				const int ns = cl->nslots;
-				for (int i = 0; i < ns; ++i)
-					sel[atomicAdd(nsel, 1u)] = (unsigned)cl->slots[i];
+				for (int i = 0; i < ns; ++i) {
+					const unsigned q = atomicAdd(nsel, 1u);
+					if (q < VDL2_SEL_CAP)
+						sel[q] = (unsigned)cl->slots[i];
+					else
+						atomicAdd(p.outc + 1, 1u);
+				}
 				a += cl->ntrig;
 				b += cl->nrej;
 				d += cl->nburst;
