@@ -37,19 +37,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-RATE = 2_000_000
+RATE = 2_000_000          # default; --rate overrides (10 MS/s = config 3)
 FC = 136_975_000
 TILE = 4_200_000          # samples per generated tile (multiple of the 2000-sample LO/decimator period)
 HBM_PEAK_GBS = 8000.0     # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def make_tile(seed: int, fmt: str):
+def make_tile(seed: int, fmt: str, rate: int = RATE, fos=None):
     from vdlm2dec_amd import synth
-    spec = synth.random_scenario(RATE, synth.DEFAULT_FO_8CH, TILE, seed=seed, bursts_per_s=4.0, info_max=240)
+    fos = fos or synth.DEFAULT_FO_8CH
+    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0 * rate / RATE, info_max=240)
     return spec, synth.synth_stream(spec, fmt)
 
 
-def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0):
+def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0, rate: int = RATE):
     """Oracle ("port" of the reference path) on host cores: one thread per channel, like the
     reference's one rcv_thread per channel (main.c:228-231)."""
     from oracle import oracle as O
@@ -58,7 +59,7 @@ def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0):
     n_total = raw.size // per
     # size the sample so the run takes roughly budget_s: probe one channel on 1 MS first
     probe = min(n_total, 1_000_000)
-    ch = O.OracleChannel(RATE, fos[0], FC + fos[0])
+    ch = O.OracleChannel(rate, fos[0], FC + fos[0])
     t0 = time.perf_counter()
     ch.feed(raw[:probe * per], fmt)
     one = (time.perf_counter() - t0) / probe
@@ -69,7 +70,7 @@ def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0):
     # the recording is one tile; feed it repeatedly (the stream simply continues) until ~budget_s
     reps = max(1, int(budget_s / (one * n_total * passes)))
     n = n_total * reps
-    chans = [O.OracleChannel(RATE, fo, FC + fo, chn=i) for i, fo in enumerate(fos)]
+    chans = [O.OracleChannel(rate, fo, FC + fo, chn=i) for i, fo in enumerate(fos)]
 
     def work(idx):
         for c in range(idx, len(chans), nthreads):
@@ -107,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=16, help="tiles of 4.2 MS per step (batch = tiles*4.2 MS)")
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
+    ap.add_argument("--rate", type=int, default=RATE, help="SDRINRATE (config 3: 10000000)")
+    ap.add_argument("--streams", type=int, default=1, help="independent wideband streams per GPU (config 4: 8)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -125,15 +128,20 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local)
 
-    fos = synth.DEFAULT_FO_8CH
-    spec, tile = make_tile(seed=1234 + rank, fmt=args.fmt)
+    rate = args.rate
+    fos = synth.DEFAULT_FO_8CH if rate == RATE else tuple(int(f * rate / RATE) // 25000 * 25000 for f in synth.DEFAULT_FO_8CH)
+    nstr = args.streams
+    tiles_np = []
+    for st_i in range(nstr):
+        spec, tile = make_tile(seed=1234 + rank * 64 + st_i, fmt=args.fmt, rate=rate, fos=fos)
+        tiles_np.append(tile)
+    tile = tiles_np[0]
     batch = args.tiles * TILE
-    dtile = torch.from_numpy(tile).to(dev)
-    dbatch = dtile.repeat(args.tiles).contiguous()          # [batch * 2] raw values, resident in HBM
-    del dtile
+    dbatch = torch.stack([torch.from_numpy(t).to(dev).repeat(args.tiles) for t in tiles_np]).contiguous()  # [streams, batch*2]
     sample_bytes = 4 if args.fmt == "cs16" else 2
+    stride_bytes = dbatch.stride(0) * dbatch.element_size()
 
-    rx = Receiver(RATE, plan_channels(FC, fos), fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18)
+    rx = Receiver(rate, [plan_channels(FC, fos)] * nstr, fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18)
     first = []
     nbursts = 0
 
@@ -158,7 +166,7 @@ def main():
         # one hand-off of resident samples + delivery of decoded msgblk records to the host.
         # pipelined: take what earlier pushes have finished (vdl2gpu_poll_ready) while this push
         # runs; everything is drained inside the timed region after the last step.
-        rx.push_device(dbatch.data_ptr(), batch)
+        rx.push_device(dbatch.data_ptr(), batch, stride_bytes)
         drain(collect, ready_only=pipelined)
 
     for i in range(args.warmup):
@@ -198,8 +206,8 @@ def main():
     parity = None
     if rank == 0 and not args.no_parity:
         from oracle import oracle as O     # checker only
-        want = sorted(b.key() for b in O.run_oracle(tile, args.fmt, RATE, fos, FC))
-        got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in first if b.end_sample < TILE)
+        want = sorted(b.key() for b in O.run_oracle(tile, args.fmt, rate, fos, FC))
+        got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in first if b.end_sample < TILE and b.stream == 0)
         # oracle bursts still open at the tile end have no counterpart; both lists hold completed ones
         parity = {"level": "msgblk_t (pre-RS) bit-exact, first tile", "oracle_bursts": len(want),
                   "gpu_bursts": len(got), "equal": want == got}
@@ -213,17 +221,17 @@ def main():
         k3_ms = tm["other_ms"] / max(1, tm["pushes"])
         # dominant full-rate kernel: k1_fast (all whole 1 ms periods but the first and last of a push)
         fast_ms = tm["channelise_fast_ms"] / max(1, tm["fast_pushes"])
-        fast_samples = (batch * 21 // 500 // 84 - 2) * 2000
+        fast_samples = (batch * 21 // 500 // 84 - 2) * 2000 * nstr
         alg_bytes = float(fast_samples) * sample_bytes
         achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
-        value = world * batch * args.steps / dt / 1e6
+        value = world * nstr * batch * args.steps / dt / 1e6
         # HBM traffic of the same kernel from the committed PMC passes of this very command
         # (profiles/r01_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs;
         #  FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as reported)
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")))
-            if args.tiles == 16 and args.fmt == "cs16":
+            if args.tiles == 16 and args.fmt == "cs16" and nstr == 1 and rate == RATE:
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"]["void k1_fast<1>"]
                            + pm["WRITE_SIZE_KB_per_launch"]["void k1_fast<1>"]) * 1024.0
         except (OSError, KeyError, ValueError):
@@ -233,10 +241,12 @@ def main():
             "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 8 channels @ 2 MS/s on 1xMI355X, synthetic D8PSK bursts",
+            "config": {"workload": ("configs[1]: 8 channels @ 2 MS/s on 1xMI355X, synthetic D8PSK bursts" if (rate == RATE and nstr == 1)
+                                    else f"non-default: {nstr} stream(s) x 8 channels @ {rate / 1e6:g} MS/s"),
                        "fmt": args.fmt, "samples_per_step": batch, "air_time_s_per_step": batch / RATE,
-                       "channels": 8, "streams_per_gpu": 1, "bursts_per_step": total_bursts / max(1, args.steps * world),
-                       "x_real_time": value * 1e6 / RATE, "parallelism": f"stream-sharded x{world}"},
+                       "channels": 8, "streams_per_gpu": nstr, "sdrinrate": rate,
+                       "bursts_per_step": total_bursts / max(1, args.steps * world),
+                       "x_real_time": value * 1e6 / rate, "parallelism": f"stream-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k1_fast", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
@@ -253,7 +263,7 @@ def main():
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS"):
             out["dbg"] = rx.debug_counters(24)
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos)
+            out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos, rate=rate)
         print(json.dumps(out))
     rx.close()
     if world > 1:

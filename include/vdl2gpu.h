@@ -186,6 +186,10 @@ int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t 
 int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, int max_complex);
 /* Trigger candidates of the last push's sync scan, 6 x int32 each {nrel, r, p2err, perr, err, pfr bits}. */
 int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, int max_cands);
+/* Verify pass of the last push: first unexpected detector hit per (stream, channel slot), and the
+ * idle segments the resolver asked to have verified {lo, hi, r, pad}. */
+int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n);
+int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, int max_segs);
 /* Development cycle counters of the demodulator kernels (meaning is internal). */
 int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int n, int reset);
 /* Device build of the fixed-sequence atan2f, elementwise (host arrays). */

@@ -73,9 +73,11 @@ struct vdl2gpu {
 	int2 *d_regs = nullptr;
 	Seg *d_segs = nullptr;
 	int *d_fail = nullptr;
+	int *d_redo = nullptr;
 	ChanState *d_cs_out = nullptr;
 	int *d_skey = nullptr;
 	unsigned short *d_sidx = nullptr, *d_prim = nullptr;
+	int *d_seeds = nullptr;
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int force_serial = 0;
@@ -239,10 +241,12 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_regs);
 	(void)hipFree(h->d_segs);
 	(void)hipFree(h->d_fail);
+	(void)hipFree(h->d_redo);
 	(void)hipFree(h->d_cs_out);
 	(void)hipFree(h->d_skey);
 	(void)hipFree(h->d_sidx);
 	(void)hipFree(h->d_prim);
+	(void)hipFree(h->d_seeds);
 	(void)hipFree(h->d_dbg);
 	if (h->h_pin)
 		(void)hipHostFree(h->h_pin);
@@ -289,7 +293,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_outc, 4 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 4 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-	h->ctl_words = CTL_CAND0 + 6 * (size_t)S * VDL2_CS;
+	h->ctl_words = CTL_CAND0 + 7 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
@@ -300,10 +304,12 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_regs, (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
 	HIPCHK(h, hipMalloc(&h->d_segs, (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
 	HIPCHK(h, hipMalloc(&h->d_fail, (size_t)S * VDL2_CS * sizeof(int)));
+	HIPCHK(h, hipMalloc(&h->d_redo, (size_t)S * VDL2_CS * sizeof(int)));
 	HIPCHK(h, hipMalloc(&h->d_cs_out, (size_t)S * VDL2_CS * sizeof(ChanState)));
 	HIPCHK(h, hipMalloc(&h->d_skey, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	HIPCHK(h, hipMalloc(&h->d_sidx, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
+	HIPCHK(h, hipMalloc(&h->d_seeds, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
@@ -519,6 +525,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMemsetAsync(h->d_outc + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMemsetAsync(h->d_fail, 0x7f, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->d_redo, 0, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
 	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
@@ -611,10 +618,13 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.regs = h->d_regs;
 		k2.segs = h->d_segs;
 		k2.fail = h->d_fail;
+		k2.redo = h->d_redo;
+		k2.round = 0;
 		k2.cs_out = h->d_cs_out;
 		k2.skey = h->d_skey;
 		k2.sidx = h->d_sidx;
 		k2.prim = h->d_prim;
+		k2.seeds = h->d_seeds;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
 		hipLaunchKernelGGL(k2a_probe, dim3(h->full_scan ? tiles : tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
@@ -631,6 +641,18 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
 		hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		if (!h->full_scan && !h->force_serial) {
+			/* repair round: channels whose verify found an unlisted hit are re-sorted, re-clustered,
+			 * re-resolved and re-verified with that hit in their table; every other channel's
+			 * workgroups exit at once.  What still fails is redone serially by K2f. */
+			K2Params k2r = k2;
+			k2r.round = 1;
+			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
+			hipLaunchKernelGGL(k2b_clusters, dim3(256, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
+			hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
+			hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+			HIPCHK(h, hipGetLastError());
+		}
 		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
@@ -911,5 +933,34 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
 		HIPCHK(h, hipMemcpy(out, h->d_cands + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+/* verify result of the last push per (stream, channel slot): stream-relative position of the first
+ * detector hit the tables lacked, or >= 0x7f000000 when the push verified */
+extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
+{
+	if (!h || !out || n < h->S * VDL2_CS)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	HIPCHK(h, hipMemcpy(out, h->d_fail, (size_t)h->S * VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
+	return h->S * VDL2_CS;
+}
+
+extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, int max_segs)
+{
+	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out)
+		return VDL2GPU_EINVAL;
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	const int sc = stream * VDL2_CS + ch;
+	unsigned n = 0;
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
+	n = std::min<unsigned>(n, (unsigned)std::min(max_segs, VDL2_SEG_CAP));
+	if (n)
+		HIPCHK(h, hipMemcpy(out, h->d_segs + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
 	return (int)n;
 }

@@ -155,11 +155,15 @@ struct K2Params {
 	int test_noregion;	/* test hook: skip the region scan so that K2a-verify must catch the misses */
 	int2 *regs;		/* [S*8][REG_CAP] (lo, count) stream-relative */
 	Seg *segs;		/* [S*8][SEG_CAP] */
-	int *fail;		/* [S*8] earliest unexpected hit (stream-relative), INT_MAX = verified */
+	int *fail;		/* [S*8] earliest unexpected hit (stream-relative), >= VDL2_VERIFIED = verified */
+	int *redo;		/* [S*8] 1 = this channel is being re-resolved in the repair round */
+	int round;		/* 0 = first pass over every channel; 1 = repair pass over the channels whose
+				 * verify failed (the hits were appended to their candidate tables) */
 	ChanState *cs_out;	/* resolver result, committed by K2f */
 	int *skey;		/* [S*8][CAND_CAP] candidates sorted by time: nrel*4 + r */
 	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
+	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
 	unsigned long long *dbg;	/* diagnostics: cycle counters */
 };
 #define CTL_OUT 0
@@ -172,6 +176,7 @@ struct K2Params {
 #define CTL_NSEG0 (CTL_CAND0 + 3 * p.nstreams * VDL2_CS)
 #define CTL_NSEL0 (CTL_CAND0 + 4 * p.nstreams * VDL2_CS)
 #define CTL_NPRIM0 (CTL_CAND0 + 5 * p.nstreams * VDL2_CS)
+#define CTL_NSEED0 (CTL_CAND0 + 6 * p.nstreams * VDL2_CS)
 
 struct K3Params {
 	const float2 *src;
@@ -1219,6 +1224,10 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 #define VDL2_REG_PAD 40		/* samples scanned on either side of a probe hit */
 #define VDL2_REG_GAP 96		/* hits closer than this share a region */
 #define VDL2_SEG_CAP 4096	/* verify segments per channel per push */
+#define VDL2_VERIFIED 0x7f000000	/* fail[] values at or above this mean: nothing unexpected found */
+#define VDL2_SEED_ERR 7.0f	/* probe fit error below which a neighbourhood is scanned in every class
+				 * (the detector itself needs < 4): catches marginal events that only some
+				 * classes detect; what it still misses is caught by K2a-verify */
 
 struct K2aShared {
 	float2 xs[K2A_XMAX];
@@ -1281,9 +1290,14 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		__syncthreads();
 		for (int i = tid; i < cnt; i += K2A_THREADS) {
 			const float perr = sh.eb[i + E4 - E2], err = sh.eb[i + E4];
+			if (mode == 2 && perr < VDL2_SEED_ERR && err > perr) {
+				const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
+				if (kk < VDL2_CAND_CAP)	/* surplus seeds are simply dropped: K2a-verify covers what they would have */
+					p.seeds[(size_t)sc * VDL2_CAND_CAP + kk] = (int)(nbase + (long long)S * i - dec_base);
+			}
 			if (perr < 4.0f && err > perr) {
 				const long long n = nbase + (long long)S * i;
-				if (mode == 0) {
+				if (mode == 0 || mode == 2) {
 					if (r == skip_r && (int)(n & 1) == skip_par)
 						continue;	/* that class is the probe's: already in the table */
 					const unsigned kk = atomicAdd(cntp, 1u);
@@ -1299,7 +1313,21 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 					} else
 						*ovf = 1u;
 				} else if (n >= chk_lo && n < chk_hi) {
+					/* a detector hit the tables did not list: remember where, and list it so
+					 * that the repair round resolves the chain with it */
 					atomicMin(fail, (int)(n - dec_base));
+					const unsigned kk = atomicAdd(cntp, 1u);
+					if (kk < VDL2_CAND_CAP) {
+						Cand cd;
+						cd.nrel = (int)(n - dec_base);
+						cd.r = r;
+						cd.p2err = sh.eb[i];
+						cd.perr = perr;
+						cd.err = err;
+						cd.pfr = sh.fb[i + E4 - E2];
+						cl[kk] = cd;
+					} else
+						*ovf = 1u;
 				}
 			}
 		}
@@ -1332,7 +1360,7 @@ void k2a_probe(K2Params p)
 		return;
 	const long long left = (avail_end - n0 + 1) / 2;
 	const int nt = (int)(left < K2A_TS ? left : K2A_TS);
-	k2a_tile<2>(sh, p, sc, dec_base, n0, nt, 1u << p.cs[sc].r, 0, 0, 0, nullptr);
+	k2a_tile<2>(sh, p, sc, dec_base, n0, nt, 1u << p.cs[sc].r, 2, 0, 0, nullptr);
 }
 
 /* ---- regions around the probe's hits (one workgroup per channel) */
@@ -1345,14 +1373,14 @@ void k2r_regions(K2Params p)
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan)
 		return;
-	int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	int ncand = (int)p.ctl[CTL_NSEED0 + sc];
 	ncand = ncand > VDL2_CAND_CAP ? VDL2_CAND_CAP : ncand;
-	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	const int *seeds = p.seeds + (size_t)sc * VDL2_CAND_CAP;
 	int npow = 1;
 	while (npow < ncand)
 		npow <<= 1;
 	for (int i = tid; i < npow; i += 256)
-		key[i] = (i < ncand) ? cands[i].nrel : 0x7fffffff;
+		key[i] = (i < ncand) ? seeds[i] : 0x7fffffff;
 	__syncthreads();
 	for (int k = 2; k <= npow; k <<= 1)
 		for (int j = k >> 1; j > 0; j >>= 1) {
@@ -1435,6 +1463,8 @@ void k2a_verify(K2Params p)
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan)
 		return;
+	if (p.round > 0 && !p.redo[sc])
+		return;
 	const StreamState *ss = p.ss + s;
 	const long long dec_base = ss->dec_base;
 	const int t_lo = (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * 2 * K2A_TS;
@@ -1492,6 +1522,8 @@ void k2s_sort(K2Params p)
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial)
+		return;
+	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
 		return;
 	int ncand = (int)p.ctl[CTL_CAND0 + sc];
 	if (ncand > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] != 0)
@@ -1581,6 +1613,8 @@ void k2b_clusters(K2Params p)
 		for (int k = 0; k < nsc64; ++k) {
 			unsigned n = p.ctl[CTL_NPRIM0 + sc0 + k];
 			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
+			if (p.round > 0 && p.fail[sc0 + k] >= VDL2_VERIFIED)
+				n = 0;
 			s_pref[k] = acc;
 			acc += n;
 		}
@@ -1706,6 +1740,18 @@ void k2c_resolve(K2Params p)
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
+	if (p.round > 0) {
+		if (p.fail[sc] >= VDL2_VERIFIED)
+			return;		/* verified in the first pass: nothing to repair */
+		__syncthreads();
+		if (tid == 0) {
+			p.redo[sc] = 1;
+			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
+			p.ctl[CTL_NSEL0 + sc] = 0;
+			p.ctl[CTL_NSEG0 + sc] = 0;
+		}
+		__syncthreads();
+	}
 	const ChanState *cs = p.cs + sc;	/* input state: left untouched until K2f commits */
 	ChanState *cs_out = p.cs_out + sc;
 	unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
@@ -1930,7 +1976,7 @@ void k2f_commit(K2Params p)
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	ChanState *cs = p.cs + sc;
-	if (p.fail[sc] >= 0x7f000000) {
+	if (p.fail[sc] >= VDL2_VERIFIED) {
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.cs_out + sc);
 		uint32_t *dst = reinterpret_cast<uint32_t *>(cs);
 		for (int i = tid; i < (int)(sizeof(ChanState) / 4); i += K2_NT)

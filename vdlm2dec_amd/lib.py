@@ -25,7 +25,7 @@ EXPORTS = (
     "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
     "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
-    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands",
+    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs",
 )
 
 
@@ -122,6 +122,10 @@ def load():
     L.vdl2gpu_debug_lo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_atan2f.restype = C.c_int
     L.vdl2gpu_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2gpu_debug_fail.restype = C.c_int
+    L.vdl2gpu_debug_fail.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.vdl2gpu_debug_segs.restype = C.c_int
+    L.vdl2gpu_debug_segs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_cands.restype = C.c_int
     L.vdl2gpu_debug_cands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_counters.restype = C.c_int
