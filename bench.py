@@ -232,9 +232,9 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")))
             if args.tiles == 16 and args.fmt == "cs16" and nstr == 1 and rate == RATE:
-                traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"]["void k1_fast<1>"]
-                           + pm["WRITE_SIZE_KB_per_launch"]["void k1_fast<1>"]) * 1024.0
-        except (OSError, KeyError, ValueError):
+                fk = [k for k in pm["FETCH_SIZE_KB_per_launch"] if "k1_fast" in k][0]
+                traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"][fk] + pm["WRITE_SIZE_KB_per_launch"][fk]) * 1024.0
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         out = {
             "metric": "IQ MS/s demodulated (8 ch, 2 MS/s cs16) + CRC-pass frame parity vs ref",
