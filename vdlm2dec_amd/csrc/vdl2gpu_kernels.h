@@ -389,12 +389,17 @@ void k1_fast(K1Params p)
 	const int lane = threadIdx.x;
 	const int s = blockIdx.y;
 	const int g = blockIdx.x % K1F_ROLES;
-	const long long pp0 = p.per_lo + (long long)(blockIdx.x / K1F_ROLES) * p.per_pb;
-	long long npl = p.per_lo + p.per_n - pp0;
-	npl = npl > p.per_pb ? p.per_pb : npl;
-	if (npl <= 0)
+	/* Wave group w = blockIdx.x / ROLES handles periods per_lo + w, + w + NW, + w + 2 NW, .. (NW =
+	 * number of wave groups): at every loop iteration the whole grid reads one contiguous band of
+	 * NW periods and writes one contiguous band of each plane, which keeps HBM pages open, instead
+	 * of every wave streaming through its own distant range. */
+	const long long nw = (long long)(gridDim.x / K1F_ROLES);
+	const long long wgrp = (long long)(blockIdx.x / K1F_ROLES);
+	const long long pp0 = p.per_lo + wgrp;
+	if (wgrp >= p.per_n)
 		return;
-	const int np = (int)npl;
+	const int np = (int)((p.per_n - wgrp + nw - 1) / nw);	/* periods pp0 + q*nw, q < np */
+	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this wave's periods */
 	const int kk = lane >> 3, c = lane & 7;
 	const int k = g * 8 + kk;
 	const bool active = (k < K1F_PER_OUT) && (c < p.nbch);
@@ -441,14 +446,15 @@ void k1_fast(K1Params p)
 	for (int d = 0; d < K1F_DEPTH; ++d)
 #pragma unroll
 		for (int u = 0; u < 3; ++u)
-			rr[d][u] = k1_raw_load<FMT>(raw, sbase + (long long)K1F_PER_IN * (d < np ? d : np - 1) + li[u]);
+			rr[d][u] = k1_raw_load<FMT>(raw, sbase + pstride * (d < np ? d : np - 1) + li[u]);
 	for (int q0 = 0; q0 < np; q0 += K1F_DEPTH) {
 #pragma unroll
 		for (int d = 0; d < K1F_DEPTH; ++d) {
 			const int q = q0 + d;
 			if (q < np) {
 				/* period q: registers -> float -> LDS slice, then refill the registers
-				 * with period q+DEPTH so that DEPTH periods stay in flight */
+				 * with period q+DEPTH so that DEPTH periods stay in flight.  (A second LDS
+				 * slice to take this write off the mixer's critical path measured slower.) */
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
 					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
@@ -456,7 +462,7 @@ void k1_fast(K1Params p)
 				if (!(VAR & 2)) {
 #pragma unroll
 					for (int u = 0; u < 3; ++u)
-						rr[d][u] = k1_raw_load<FMT>(raw, sbase + (long long)K1F_PER_IN * qn + li[u]);
+						rr[d][u] = k1_raw_load<FMT>(raw, sbase + pstride * qn + li[u]);
 				}
 				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
 				if (active) {
@@ -493,7 +499,7 @@ void k1_fast(K1Params p)
 						qi = acc.y / fn;
 					}
 					if (!(VAR & 1) || qr == 12345.678f)
-						dec[(long long)q * K1F_PER_OUT] = make_float2(qr, qi);
+						dec[(long long)q * K1F_PER_OUT * nw] = make_float2(qr, qi);
 				}
 				__syncthreads();	/* reads done before the slice is overwritten */
 			}
