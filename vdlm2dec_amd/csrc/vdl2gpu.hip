@@ -82,6 +82,9 @@ struct vdl2gpu {
 	unsigned stage_cap = 0;
 	int force_serial = 0;
 	int n_cu = 256;
+	int repair_rounds = 1;		/* adapted 1..4 from how often the serial fallback was needed */
+	unsigned redos_seen = 0;
+	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
 	uint64_t total_in = 0;		/* samples per stream pushed so far */
 	uint64_t pushes = 0;
@@ -290,8 +293,8 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_recs[r], (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
 		HIPCHK(h, hipEventCreateWithFlags(&h->ring_done[r], hipEventDisableTiming));
 	}
-	HIPCHK(h, hipMalloc(&h->d_outc, 4 * sizeof(unsigned)));
-	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 4 * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMalloc(&h->d_outc, 8 * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 8 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 	h->ctl_words = CTL_CAND0 + 7 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
@@ -314,7 +317,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 4 * sizeof(unsigned), hipHostMallocDefault));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 8 * sizeof(unsigned), hipHostMallocDefault));
+	memset(h->h_pin_cnt, 0, 8 * sizeof(unsigned));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
 
@@ -610,6 +614,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.stage_cap = h->stage_cap;
 		k2.recs = h->d_recs[ring];
 		k2.outc = h->d_outc + 2 * ring;
+		k2.outc_total_redo = h->d_outc + 4;
 		k2.rec_cap = h->rec_cap;
 		k2.force_serial = h->force_serial;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
@@ -646,11 +651,13 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			 * re-resolved and re-verified with that hit in their table; every other channel's
 			 * workgroups exit at once.  What still fails is redone serially by K2f. */
 			K2Params k2r = k2;
-			k2r.round = 1;
-			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
-			hipLaunchKernelGGL(k2b_clusters, dim3(256, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
-			hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
-			hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+			for (int rr = 1; rr <= h->repair_rounds; ++rr) {
+				k2r.round = rr;
+				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2b_clusters, dim3(256, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+			}
 			HIPCHK(h, hipGetLastError());
 		}
 		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
@@ -675,6 +682,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	}
 	HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
 	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 2 * ring, h->d_outc + 2 * ring, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 4 + ring, h->d_outc + 4, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipEventRecord(h->ring_done[ring], h->stream));
 	h->ring_busy[ring] = true;
 	h->ring_push[ring] = h->pushes;
@@ -713,6 +721,18 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	const unsigned c0 = h->h_pin_cnt[2 * ring], c1 = h->h_pin_cnt[2 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
+	{
+		/* more repair rounds while pushes keep falling back to the serial machine, fewer when quiet */
+		const unsigned redos = h->h_pin_cnt[4 + ring];
+		if (redos != h->redos_seen) {
+			h->redos_seen = redos;
+			h->last_redo_push = h->ring_push[ring];
+			h->repair_rounds = std::min(4, h->repair_rounds * 2);
+		} else if (h->repair_rounds > 1 && h->ring_push[ring] > h->last_redo_push + 8) {
+			h->repair_rounds--;
+			h->last_redo_push = h->ring_push[ring];
+		}
+	}
 	if (n) {
 		if (h->ready_pos == h->ready_idx.size()) {	/* everything handed out: recycle storage */
 			h->ready.clear();

@@ -149,6 +149,7 @@ struct K2Params {
 	unsigned stage_cap;
 	vdl2gpu_burst_t *recs;	/* output ring of this push */
 	unsigned *outc;		/* [0] = records written, [1] = records dropped (ring full) */
+	unsigned *outc_total_redo;	/* running count of serial redos (host adapts the number of repair rounds) */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
 	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
@@ -2013,6 +2014,7 @@ void k2f_commit(K2Params p)
 		cs->n_defer += (unsigned long long)out.ndefer;
 		cs->n_slow += (unsigned long long)(st.pos - p0);
 		cs->n_redo += 1;
+		atomicAdd(p.outc_total_redo, 1u);
 		p.ctl[CTL_NSEL0 + sc] = 0;	/* K2d: nothing of the resolver's for this channel */
 	}
 }
