@@ -564,10 +564,18 @@ __device__ __forceinline__ float k2_fir_phase(const float2 *x, int tap0)
 }
 
 /* d8psk.c:257-289: ph[0], ph[STRIDE], ... ph[16*STRIDE] are the 17 phases one symbol apart */
+/* The reference compares the float phase step with the DOUBLE constants +-M_PI.  M_PI lies strictly
+ * between the adjacent floats 0x40490fda (3.14159250) and 0x40490fdb (3.14159274), so for a float x
+ *     (double)x > M_PI   <=>  x > 0x40490fda      and      (double)x < -M_PI  <=>  x < -0x40490fda
+ * and the comparison can be made in float without changing a single decision. */
+#define VDL2_PI_BELOW 0x40490fdau
+
 template <int STRIDE> __device__ __forceinline__ float k2_sync_metric(const float *ph, float *slope)
 {
+	const float pi_lo = __uint_as_float(VDL2_PI_BELOW);
 	float pr[17];
-	float pu = 0.0f;
+	double pud = 0.0;	/* Pu: every update goes float -> double -> float like `Pu -= 2 * M_PI`; */
+	float pu = 0.0f;	/* kept in both forms so that only the narrowing is paid per step */
 	float pv = ph[0] - d_tab(c_sw, 0);
 	float mean = pv;
 	pr[0] = pv;
@@ -576,10 +584,10 @@ template <int STRIDE> __device__ __forceinline__ float k2_sync_metric(const floa
 		const float pc = ph[STRIDE * l] - d_tab(c_sw, l);
 		const float pd = pc - pv;
 		pv = pc;
-		/* (double)pd > M_PI etc.; -1/0/+1 turns of 2*pi accumulated through double like
-		 * the reference's `Pu -= 2 * M_PI` (the product k*2pi is exact) */
-		const double k = ((double)pd > M_PI) ? -1.0 : (((double)pd < -M_PI) ? 1.0 : 0.0);
-		pu = (float)((double)pu + k * (2 * M_PI));
+		/* -1 / 0 / +1 turns; k * 2pi is exact in double, so pu + k*2pi is the reference's sum */
+		const float k = (pd > pi_lo) ? -1.0f : ((pd < -pi_lo) ? 1.0f : 0.0f);
+		pu = (float)(pud + (double)k * (2 * M_PI));
+		pud = (double)pu;
 		pr[l] = pc + pu;
 		mean += pr[l];
 	}
