@@ -18,7 +18,17 @@ static uint64_t rnd(void)
 
 static int check(float y, float x, long *bad)
 {
-	float a = atan2f(y, x), b = vdl2_atan2f(y, x);
+	static float tab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];
+	if (tab[0] == 0.0f)
+		for (int i = 0; i < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE; i++)
+			tab[i] = vdl2_atan_tab_entry(i);
+	float a = atan2f(y, x), b = vdl2_atan2f(y, x), c = vdl2_atan2f_tab(y, x, tab);
+	if (vdl2_f2u(a) != vdl2_f2u(c)) {
+		if (*bad < 10)
+			printf("MISMATCH(tab) y=%a x=%a libm=%a (%08x) ours=%a (%08x)\n", y, x, a, vdl2_f2u(a), c, vdl2_f2u(c));
+		(*bad)++;
+		return 1;
+	}
 	if (vdl2_f2u(a) != vdl2_f2u(b)) {
 		if (*bad < 10)
 			printf("MISMATCH y=%a x=%a libm=%a (%08x) ours=%a (%08x)\n", y, x, a, vdl2_f2u(a), b, vdl2_f2u(b));

@@ -609,6 +609,46 @@ template <int STRIDE> __device__ __forceinline__ float k2_sync_metric(const floa
 	return err;
 }
 
+/* Screening form of the fit error for the scan kernels.  It takes exactly the same unwrap
+ * decisions as k2_sync_metric (pc and pd are the same float operations) but counts turns and
+ * applies them as turns * 2pi in one fused step instead of rounding Pu through double after
+ * every turn, and it may fuse/reassociate the regression.  With the decisions equal, the two
+ * differ only by rounding: |Pr - Pr'| < 8e-5 per point (16 roundings of Pu at |Pu| < 128 plus
+ * one ulp), |M - M'|, 8|fr - fr'| < 1e-3, so for an exact error below 4 (every residual < 2)
+ * |err - err'| < 2 * sqrt(17 * 4) * 1.2e-3 < 0.02.  The scan therefore treats
+ * err' >= VDL2_SCREEN_ERR (4.25) as proof that the exact error is >= 4 and recomputes every
+ * instant below it, and its two neighbours, with k2_sync_metric. */
+#define VDL2_SCREEN_ERR 4.25f
+template <int STRIDE> __device__ __forceinline__ float k2_sync_metric_screen(const float *ph)
+{
+	const float pi_lo = __uint_as_float(VDL2_PI_BELOW);
+	const float two_pi = 6.28318530717958647692f;
+	float pr[17];
+	float pv = ph[0] - d_tab(c_sw, 0);
+	float turns = 0.0f, sum = pv, sl = pv * -8.0f;
+	pr[0] = pv;
+#pragma unroll
+	for (int l = 1; l < 17; ++l) {
+		const float pc = ph[STRIDE * l] - d_tab(c_sw, l);
+		const float pd = pc - pv;
+		pv = pc;
+		const float k = (fabsf(pd) > pi_lo) ? copysignf(1.0f, pd) : 0.0f;
+		turns -= k;
+		pr[l] = __fmaf_rn(turns, two_pi, pc);
+		sum += pr[l];
+		sl = __fmaf_rn(pr[l], (float)(l - 8), sl);
+	}
+	const float mean = sum * (1.0f / 17.0f);
+	const float fr = sl * (1.0f / 408.0f);
+	float err = 0.0f;
+#pragma unroll
+	for (int l = 0; l < 17; ++l) {
+		const float e = __fmaf_rn((float)(8 - l), fr, pr[l] - mean);
+		err = __fmaf_rn(e, e, err);
+	}
+	return err;
+}
+
 /* differential slice of one symbol -> Grey table index (d8psk.c:213, 323-327) */
 __device__ __forceinline__ int k2_grey_index(float p, float pprev, float df)
 {
@@ -1235,6 +1275,7 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
+#define K2A_WL 512		/* screened-in instants per tile and sub-phase before the tile falls back to exact everywhere */
 #define VDL2_REG_CAP 1024	/* probe-hit regions per channel per push */
 #define VDL2_REG_PAD 40		/* samples scanned on either side of a probe hit */
 #define VDL2_REG_GAP 96		/* hits closer than this share a region */
@@ -1249,6 +1290,9 @@ struct K2aShared {
 	float ph[K2A_TS + K2A_POFF];
 	float eb[K2A_TS + 4], fb[K2A_TS + 4];
 	float smf[72];		/* low-pass taps mflt[] (d8psk.h:28-45) */
+	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants (vdl2_math.h) */
+	int wl[K2A_WL];		/* instants whose fit error must be recomputed exactly */
+	int nwl;
 };
 
 /* mode 0: append candidates; mode 1: report the earliest hit in [chk_lo, chk_hi) to *fail.
@@ -1270,6 +1314,8 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		sh.xs[i] = x[i];
 	for (int i = tid; i < 72; i += K2A_THREADS)
 		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+		sh.atab[tid] = vdl2_atan_tab_entry(tid);
 	__syncthreads();
 	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
 	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
@@ -1293,14 +1339,34 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				const float m = mf[64];
 				acc += xq[16] * (v2f){m, m};
 			}
-			sh.ph[q] = vdl2_atan2f(acc.y, acc.x);
+			sh.ph[q] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
 		}
 		__syncthreads();
 		/* fit errors for instants -E4 .. cnt-1: eb[i] <-> instant i - E4 */
+		if (tid == 0)
+			sh.nwl = 0;
+		__syncthreads();
 		for (int i = tid; i < cnt + E4; i += K2A_THREADS) {
-			float fr;
-			sh.eb[i] = k2_sync_metric<LSTR>(&sh.ph[PH - E4 + i - 16 * LSTR], &fr);
-			sh.fb[i] = fr;
+			const float e = k2_sync_metric_screen<LSTR>(&sh.ph[PH - E4 + i - 16 * LSTR]);
+			sh.eb[i] = e;
+			if (e < VDL2_SCREEN_ERR) {
+				const int k = atomicAdd(&sh.nwl, 1);
+				if (k < K2A_WL)
+					sh.wl[k] = i;
+			}
+		}
+		__syncthreads();
+		/* exact errors (and slopes) wherever the detector test below can depend on them: a
+		 * screened-in instant as perr, the one before as p2err, the one after as err */
+		const int nwl = sh.nwl;
+		const int nex = nwl <= K2A_WL ? 3 * nwl : cnt + E4;
+		for (int k = tid; k < nex; k += K2A_THREADS) {
+			const int i = nwl <= K2A_WL ? sh.wl[k / 3] + (k % 3 - 1) * E2 : k;
+			if (i >= 0 && i < cnt + E4) {
+				float fr;
+				sh.eb[i] = k2_sync_metric<LSTR>(&sh.ph[PH - E4 + i - 16 * LSTR], &fr);
+				sh.fb[i] = fr;
+			}
 		}
 		__syncthreads();
 		for (int i = tid; i < cnt; i += K2A_THREADS) {
