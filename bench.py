@@ -261,7 +261,7 @@ def main():
             "parity": parity,
         }
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS"):
-            out["dbg"] = rx.debug_counters(24)
+            out["dbg"] = rx.debug_counters(48)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos, rate=rate)
         print(json.dumps(out))

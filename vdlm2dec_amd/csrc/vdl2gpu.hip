@@ -82,6 +82,7 @@ struct vdl2gpu {
 	unsigned stage_cap = 0;
 	int force_serial = 0;
 	int n_cu = 256;
+	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
 	int repair_rounds = 1;		/* adapted 1..4 from how often the serial fallback was needed */
 	unsigned redos_seen = 0;
 	uint64_t last_redo_push = 0;
@@ -275,6 +276,9 @@ static int create_impl(vdl2gpu_t *h)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
 			h->n_cu = prop.multiProcessorCount;
+		int occ = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k2a_probe, K2A_THREADS, 0) == hipSuccess && occ > 0)
+			h->probe_occ = occ;
 	}
 	HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	const int S = h->S, L = h->L;
@@ -632,7 +636,13 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.seeds = h->d_seeds;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
-		hipLaunchKernelGGL(k2a_probe, dim3(h->full_scan ? tiles : tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		{
+			/* as many workgroups as are resident at once, each walking its share of the channel's tiles */
+			const unsigned want = h->full_scan ? tiles : tiles / 2 + 1;
+			unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * h->S - 1) / (h->C * h->S));
+			per = per < 1 ? 1 : (per > want ? want : per);
+			hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		}
 		hipLaunchKernelGGL(k2r_regions, gch, dim3(256), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
@@ -644,7 +654,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
-		hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (!h->full_scan && !h->force_serial) {
 			/* repair round: channels whose verify found an unlisted hit are re-sorted, re-clustered,
@@ -656,7 +666,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2b_clusters, dim3(256, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
-				hipLaunchKernelGGL(k2a_verify, dim3(tiles / 2 + 1, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
 			}
 			HIPCHK(h, hipGetLastError());
 		}

@@ -1270,12 +1270,18 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
  *               the shortcut exact instead of heuristic.
  * VDL2GPU_F_FULLSCAN makes the probe cover all four sub-phases (no regions/verify needed).
  */
+#ifndef K2A_THREADS
 #define K2A_THREADS 256
+#endif
+#ifndef K2A_TS
 #define K2A_TS 1024		/* evaluation instants per tile */
+#endif
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
-#define K2A_WL 512		/* screened-in instants per tile and sub-phase before the tile falls back to exact everywhere */
+#ifndef K2A_WL
+#define K2A_WL 192		/* screened-in evaluations per tile and sub-phase; more than that and the tile is done in pieces */
+#endif
 #define VDL2_REG_CAP 1024	/* probe-hit regions per channel per push */
 #define VDL2_REG_PAD 40		/* samples scanned on either side of a probe hit */
 #define VDL2_REG_GAP 96		/* hits closer than this share a region */
@@ -1286,37 +1292,143 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 				 * classes detect; what it still misses is caught by K2a-verify */
 
 struct K2aShared {
-	float2 xs[K2A_XMAX];
-	float ph[K2A_TS + K2A_POFF];
-	float eb[K2A_TS + 4], fb[K2A_TS + 4];
-	float smf[72];		/* low-pass taps mflt[] (d8psk.h:28-45) */
+	float2 xs[K2A_XMAX + 8];	/* S = 1: samples in order; S = 2: even samples, then (at K2A_XODD) odd samples, so that
+					 * both FIR tap parities are unit-stride across lanes */
+	float ph[K2A_TS + K2A_POFF];	/* filtered phase of every instant (history first) */
+	float2 wu[K2A_TS + K2A_POFF];	/* its unit phasor, then the phasor of the symbol-spaced phase step */
+	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45) */
 	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants (vdl2_math.h) */
-	int wl[K2A_WL];		/* instants whose fit error must be recomputed exactly */
+	int wl[K2A_WL];			/* screened-in evaluations ... */
+	float we[3][K2A_WL], wf[K2A_WL];	/* ... exact fit error one evaluation earlier / there / one later, slope there */
 	int nwl;
 };
+#define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
 
-/* mode 0: append candidates; mode 1: report the earliest hit in [chk_lo, chk_hi) to *fail.
- * One sub-phase per pass: phases of all instants, barrier, fit errors, barrier, detector test.
- * The taps are read from LDS with a wave-uniform index (mflt[r], mflt[r+4], ..) so that one code
- * path serves every sub-phase and no scalar registers are spent on 4 x 17 tap constants. */
+/* Screen for the 17-point fit (the expensive part of the scan).
+ * With Pr[] the unwrapped, template-corrected phases the reference fits a line to (d8psk.c:257-289)
+ * and e[] their residuals, the phase steps satisfy D_l = Pr[l] - Pr[l-1] = fr + e_l - e_(l-1), and
+ * D_l = (P_l - P_(l-1)) - (SW_l - SW_(l-1)) modulo 2pi whatever the unwrap decided.  Hence
+ *      sum_l (D_l - mean D)^2 <= sum_l (e_l - e_(l-1))^2 <= 4 * err,
+ * and with R = |sum_l exp(j D_l)| >= sum_l cos(D_l - mean D) >= 16 - sum_l (D_l - mean D)^2 / 2:
+ *      err >= (16 - R) / 2.
+ * R needs no unwrap and no phases, only the unit phasors u = w * conj(w') of symbol-spaced FIR
+ * outputs, rotated by the 16 template steps (odd multiples of pi/8) -- 32 packed FMAs.  An instant
+ * with R <= 7.5 has err >= 4.25 > 4 (rounding in R is < 1e-4), so it can neither be the minimum
+ * the detector fires after nor matter to it; only instants with R > 7.5 (about 3 % in noise) get
+ * the exact fit.  A non-finite R counts as screened in. */
+#define VDL2_SCREEN_R2 56.25f
+__device__ __forceinline__ v2f k2_rot(v2f acc, v2f u, float cx, float cy)
+{
+	/* acc += (cx + j cy) * u */
+	acc = __builtin_elementwise_fma((v2f){cx, cx}, u, acc);
+	return __builtin_elementwise_fma((v2f){-cy, cy}, u.yx, acc);
+}
+
+
+/* detector test of one instant (d8psk.c:292) and what a hit means in each scan mode */
+template <int S> __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long dec_base, long long nbase, int i, int r, int mode,
+						  long long chk_lo, long long chk_hi, int *fail, int skip_r, int skip_par,
+						  float p2err, float perr, float err, float pfr, unsigned *cntp, unsigned *ovf, Cand *cl)
+{
+	const long long n = nbase + (long long)S * i;
+	if (mode == 2 && perr < VDL2_SEED_ERR && err > perr) {
+		const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
+		if (kk < VDL2_CAND_CAP)	/* surplus seeds are simply dropped: K2a-verify covers what they would have */
+			p.seeds[(size_t)sc * VDL2_CAND_CAP + kk] = (int)(n - dec_base);
+	}
+	if (!(perr < 4.0f && err > perr))
+		return;
+	if (mode == 0 || mode == 2) {
+		if (r == skip_r && (int)(n & 1) == skip_par)
+			return;	/* that class is the probe's: already in the table */
+	} else {
+		if (n < chk_lo || n >= chk_hi)
+			return;
+		/* a detector hit the tables did not list: remember where, and list it so that the
+		 * repair round resolves the chain with it */
+		atomicMin(fail, (int)(n - dec_base));
+	}
+	const unsigned kk = atomicAdd(cntp, 1u);
+	if (kk < VDL2_CAND_CAP) {
+		Cand cd;
+		cd.nrel = (int)(n - dec_base);
+		cd.r = r;
+		cd.p2err = p2err;
+		cd.perr = perr;
+		cd.err = err;
+		cd.pfr = pfr;
+		cl[kk] = cd;
+	} else
+		*ovf = 1u;
+}
+
+/* The samples of a tile travel HBM -> registers -> LDS.  The registers of the *next* tile of the
+ * same workgroup are loaded right after the current tile's have been parked in LDS, so that the
+ * memory latency (several thousand cycles under load) is hidden behind the current tile's arithmetic. */
+template <int S> struct K2aPre {
+	static constexpr int NL = (S * (K2A_TS - 1) + 1 + K2A_XOFF + K2A_THREADS - 1) / K2A_THREADS;
+	float2 v[NL];
+	bool loaded;
+};
+
+/* once per workgroup, before its first tile */
+__device__ __forceinline__ void k2a_tables(K2aShared &sh)
+{
+	for (int i = threadIdx.x; i < 72; i += K2A_THREADS)
+		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	if (threadIdx.x < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+		sh.atab[threadIdx.x] = vdl2_atan_tab_entry(threadIdx.x);
+}
+
+template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const K2Params &p, int sc, long long dec_base, long long nbase, int cnt)
+{
+	const float2 *x = p.dec + (size_t)sc * p.cap + (nbase - K2A_XOFF - dec_base);
+	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
+#pragma unroll
+	for (int k = 0; k < K2aPre<S>::NL; ++k) {
+		const int i = (int)threadIdx.x + k * K2A_THREADS;
+		if (i < nx)
+			pre.v[k] = x[i];
+	}
+	pre.loaded = true;
+}
+
+/* mode 0: append candidates; mode 1: report hits in [chk_lo, chk_hi) to *fail and append them;
+ * mode 2: probe (candidates + seeds).  One sub-phase per pass:
+ *   phases + unit phasors of all instants | phase-step phasors | screen -> worklist |
+ *   exact fit of the worklist | exact fit of the neighbours of the near-threshold ones | detector test. */
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
 					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail,
-					   int skip_r = -1, int skip_par = 0)
+					   K2aPre<S> &pre, long long next_nbase, int next_cnt, int skip_r = -1, int skip_par = 0)
 {
 	const int tid = threadIdx.x;
 	constexpr int PH = K2A_POFF / S;	/* phase instants of history */
 	constexpr int LSTR = 8 / S;		/* one symbol in instants */
 	constexpr int E2 = 2 / S, E4 = 4 / S;	/* previous two evaluations in instants */
-	const float2 *x = p.dec + (size_t)sc * p.cap + (nbase - K2A_XOFF - dec_base);
+	constexpr int NQ = (K2A_TS + PH + K2A_THREADS - 1) / K2A_THREADS;
+	static_assert(K2A_POFF == S * PH, "phase history must be a whole number of instants");
+	/* exp(-j (SW[l] - SW[l-1])), l = 1..16: the template steps are 1,7,5,-7,1,3,-3,-7,3,-1,5,-5,-3,-5,-1,7 (x pi/8) */
+	constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
+	constexpr float rc[16] = {C1, -C1, -S1, -C1, C1, S1, S1, -C1, S1, C1, -S1, -S1, S1, -S1, C1, -C1};
+	constexpr float rs[16] = {-S1, -S1, -C1, S1, -S1, -C1, C1, S1, -C1, S1, -C1, C1, C1, C1, S1, -S1};
 	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
+	const bool prof = p.dbg && mode == 2 && tid == 0 && (blockIdx.x & 7) == 0;
+	long long tq = prof ? clock64() : 0;
+#define K2A_STAMP(slot) do { if (prof) { const long long tn = clock64(); atomicAdd(p.dbg + 32 + (slot), (unsigned long long)(tn - tq)); tq = tn; } } while (0)
+	if (!pre.loaded)
+		k2a_fetch<S>(pre, p, sc, dec_base, nbase, cnt);
 	__syncthreads();
-	for (int i = tid; i < nx; i += K2A_THREADS)
-		sh.xs[i] = x[i];
-	for (int i = tid; i < 72; i += K2A_THREADS)
-		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
-	if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
-		sh.atab[tid] = vdl2_atan_tab_entry(tid);
+#pragma unroll
+	for (int k = 0; k < K2aPre<S>::NL; ++k) {
+		const int i = tid + k * K2A_THREADS;
+		if (i < nx)
+			sh.xs[S == 2 ? (i & 1) * K2A_XODD + (i >> 1) : i] = pre.v[k];
+	}
+	pre.loaded = false;
+	if (next_cnt > 0)
+		k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
 	__syncthreads();
+	K2A_STAMP(0);
 	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
 	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
 	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
@@ -1324,99 +1436,120 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	for (int r = 0; r < 4; ++r) {
 		if (!(rmask & (1u << r)))
 			continue;
-		/* phases of instants -PH .. cnt-1 */
-		const float *mf = &sh.smf[r];
-		const bool tap17 = (r == 0);	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
-		for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
-			const v2f *xq = reinterpret_cast<const v2f *>(&sh.xs[S * q + (K2A_POFF - S * PH)]);	/* sample (nbase + S*(q-PH)) - 16 */
-			v2f acc = {0.0f, 0.0f};
+		/* ---- phases and unit phasors of instants -PH .. cnt-1 */
+		{
+			float mf[17];	/* wave-uniform: scalar registers */
 #pragma unroll
-			for (int j = 0; j < 16; ++j) {
-				const float m = mf[4 * j];
-				acc += xq[j] * (v2f){m, m};
-			}
-			if (tap17) {
-				const float m = mf[64];
-				acc += xq[16] * (v2f){m, m};
-			}
-			sh.ph[q] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
-		}
-		__syncthreads();
-		/* fit errors for instants -E4 .. cnt-1: eb[i] <-> instant i - E4 */
-		if (tid == 0)
-			sh.nwl = 0;
-		__syncthreads();
-		for (int i = tid; i < cnt + E4; i += K2A_THREADS) {
-			const float e = k2_sync_metric_screen<LSTR>(&sh.ph[PH - E4 + i - 16 * LSTR]);
-			sh.eb[i] = e;
-			if (e < VDL2_SCREEN_ERR) {
-				const int k = atomicAdd(&sh.nwl, 1);
-				if (k < K2A_WL)
-					sh.wl[k] = i;
-			}
-		}
-		__syncthreads();
-		/* exact errors (and slopes) wherever the detector test below can depend on them: a
-		 * screened-in instant as perr, the one before as p2err, the one after as err */
-		const int nwl = sh.nwl;
-		const int nex = nwl <= K2A_WL ? 3 * nwl : cnt + E4;
-		for (int k = tid; k < nex; k += K2A_THREADS) {
-			const int i = nwl <= K2A_WL ? sh.wl[k / 3] + (k % 3 - 1) * E2 : k;
-			if (i >= 0 && i < cnt + E4) {
-				float fr;
-				sh.eb[i] = k2_sync_metric<LSTR>(&sh.ph[PH - E4 + i - 16 * LSTR], &fr);
-				sh.fb[i] = fr;
+			for (int j = 0; j < 17; ++j)	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
+				mf[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.smf[r + 4 * j])));
+			const bool tap17 = (r == 0);
+			for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
+				/* tap j multiplies sample (nbase + S*(q-PH)) - 16 + j = tile sample S*q + j */
+				const v2f *xe = reinterpret_cast<const v2f *>(&sh.xs[q]);
+				const v2f *xo = reinterpret_cast<const v2f *>(&sh.xs[K2A_XODD + q]);
+				v2f acc = {0.0f, 0.0f};
+#pragma unroll
+				for (int j = 0; j < 16; ++j) {
+					const v2f xv = (S == 2) ? ((j & 1) ? xo[j >> 1] : xe[j >> 1]) : xe[j];
+					acc += xv * (v2f){mf[j], mf[j]};
+				}
+				if (tap17)
+					acc += ((S == 2) ? xe[8] : xe[16]) * (v2f){mf[16], mf[16]};
+				sh.ph[q] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
+				const float n2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
+				v2f w = acc * __frsqrt_rn(n2);
+				if (!(n2 >= 1e-30f && n2 <= 1e30f)) {	/* atan2f(0, 0) = 0; anything else odd: screen it in */
+					const float bad = (acc.x == 0.0f && acc.y == 0.0f) ? 0.0f : __builtin_nanf("");
+					w = (v2f){1.0f + bad, bad};
+				}
+				sh.wu[q] = make_float2(w.x, w.y);
 			}
 		}
+		K2A_STAMP(1);
 		__syncthreads();
-		for (int i = tid; i < cnt; i += K2A_THREADS) {
-			const float perr = sh.eb[i + E4 - E2], err = sh.eb[i + E4];
-			if (mode == 2 && perr < VDL2_SEED_ERR && err > perr) {
-				const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
-				if (kk < VDL2_CAND_CAP)	/* surplus seeds are simply dropped: K2a-verify covers what they would have */
-					p.seeds[(size_t)sc * VDL2_CAND_CAP + kk] = (int)(nbase + (long long)S * i - dec_base);
-			}
-			if (perr < 4.0f && err > perr) {
-				const long long n = nbase + (long long)S * i;
-				if (mode == 0 || mode == 2) {
-					if (r == skip_r && (int)(n & 1) == skip_par)
-						continue;	/* that class is the probe's: already in the table */
-					const unsigned kk = atomicAdd(cntp, 1u);
-					if (kk < VDL2_CAND_CAP) {
-						Cand cd;
-						cd.nrel = (int)(n - dec_base);
-						cd.r = r;
-						cd.p2err = sh.eb[i];
-						cd.perr = perr;
-						cd.err = err;
-						cd.pfr = sh.fb[i + E4 - E2];
-						cl[kk] = cd;
-					} else
-						*ovf = 1u;
-				} else if (n >= chk_lo && n < chk_hi) {
-					/* a detector hit the tables did not list: remember where, and list it so
-					 * that the repair round resolves the chain with it */
-					atomicMin(fail, (int)(n - dec_base));
-					const unsigned kk = atomicAdd(cntp, 1u);
-					if (kk < VDL2_CAND_CAP) {
-						Cand cd;
-						cd.nrel = (int)(n - dec_base);
-						cd.r = r;
-						cd.p2err = sh.eb[i];
-						cd.perr = perr;
-						cd.err = err;
-						cd.pfr = sh.fb[i + E4 - E2];
-						cl[kk] = cd;
-					} else
-						*ovf = 1u;
+		K2A_STAMP(2);
+		/* ---- in place: wu[q] <- wu[q] * conj(wu[q - LSTR]) */
+		{
+			v2f u[NQ];
+#pragma unroll
+			for (int k = 0; k < NQ; ++k) {
+				const int q = tid + k * K2A_THREADS;
+				if (q >= LSTR && q < cnt + PH) {
+					const float2 a = sh.wu[q], b = sh.wu[q - LSTR];
+					u[k] = (v2f){__fmaf_rn(a.x, b.x, a.y * b.y), __fmaf_rn(a.y, b.x, -(a.x * b.y))};
 				}
 			}
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < NQ; ++k) {
+				const int q = tid + k * K2A_THREADS;
+				if (q >= LSTR && q < cnt + PH)
+					sh.wu[q] = make_float2(u[k].x, u[k].y);
+			}
 		}
+		K2A_STAMP(3);
+		/* ---- the instants of the tile, all at once unless the worklist overflows (pathological
+		 *      input such as a constant-phase tone): then in pieces it cannot overflow on */
+		int piece = cnt;
+		for (int c0 = 0; c0 < cnt;) {
+			const int c1 = (c0 + piece < cnt) ? c0 + piece : cnt;
+			if (tid == 0)
+				sh.nwl = 0;
+			__syncthreads();
+			/* screen the evaluation that is the `perr` of instant i: j = i + E2 */
+			for (int i = c0 + tid; i < c1; i += K2A_THREADS) {
+				const int j = i + E2;
+				const float2 *uq = &sh.wu[PH - E4 + j - 15 * LSTR];
+				v2f acc = {0.0f, 0.0f};
+#pragma unroll
+				for (int l = 0; l < 16; ++l) {
+					const float2 u = uq[l * LSTR];
+					acc = k2_rot(acc, (v2f){u.x, u.y}, rc[l], rs[l]);
+				}
+				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
+				if (!(r2 <= VDL2_SCREEN_R2)) {
+					const int k = atomicAdd(&sh.nwl, 1);
+					if (k < K2A_WL)
+						sh.wl[k] = j;
+				}
+			}
+			K2A_STAMP(4);
+			__syncthreads();
+			K2A_STAMP(5);
+			const int nwl = sh.nwl;
+			if (prof)
+				atomicAdd(p.dbg + 32 + 10, (unsigned long long)nwl);
+			if (nwl > K2A_WL) {
+				piece = K2A_WL;
+				__syncthreads();	/* everyone has read nwl before it is reset */
+				continue;
+			}
+			/* exact fit of the screened-in evaluations and of their neighbours (p2err / err of the test) */
+			for (int k = tid; k < 3 * nwl; k += K2A_THREADS) {
+				const int slot = k / 3, w = k - 3 * slot;
+				float fr;
+				sh.we[w][slot] = k2_sync_metric<LSTR>(&sh.ph[PH - E4 + sh.wl[slot] + (w - 1) * E2 - 16 * LSTR], &fr);
+				if (w == 1)
+					sh.wf[slot] = fr;
+			}
+			K2A_STAMP(6);
+			__syncthreads();
+			K2A_STAMP(7);
+			for (int k = tid; k < nwl; k += K2A_THREADS)
+				k2a_emit<S>(p, sc, dec_base, nbase, sh.wl[k] - E2, r, mode, chk_lo, chk_hi, fail, skip_r, skip_par,
+					    sh.we[0][k], sh.we[1][k], sh.we[2][k], sh.wf[k], cntp, ovf, cl);
+			c0 = c1;
+		}
+		K2A_STAMP(8);
 		__syncthreads();
+		K2A_STAMP(9);
+		if (prof)
+			atomicAdd(p.dbg + 32 + 11, 1ull);
 	}
+#undef K2A_STAMP
 }
 
-__global__ __launch_bounds__(K2A_THREADS)
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k2a_probe(K2Params p)
 {
 	__shared__ K2aShared sh;
@@ -1427,21 +1560,33 @@ void k2a_probe(K2Params p)
 	const long long avail_end = dec_base + ss->dec_fill + p.J;
 	if (p.force_serial)
 		return;
+	k2a_tables(sh);
+	/* each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its channel */
 	if (p.full_scan) {
-		const long long n0 = p.cs[sc].pos + (long long)blockIdx.x * K2A_TS;
-		if (n0 >= avail_end)
-			return;
-		const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
-		k2a_tile<1>(sh, p, sc, dec_base, n0, nt, 0xfu, 0, 0, 0, nullptr);
+		K2aPre<1> pre;
+		pre.loaded = false;
+		const long long step = (long long)gridDim.x * K2A_TS;
+		for (long long n0 = p.cs[sc].pos + (long long)blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
+			const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
+			const long long n1 = n0 + step;
+			const int nt1 = n1 < avail_end ? (int)((avail_end - n1 < K2A_TS) ? (avail_end - n1) : K2A_TS) : 0;
+			k2a_tile<1>(sh, p, sc, dec_base, n0, nt, 0xfu, 0, 0, 0, nullptr, pre, n1, nt1);
+		}
 		return;
 	}
 	/* the class the channel's detector is in right now: sub-phase r, parity of pos */
-	const long long n0 = p.cs[sc].pos + 2LL * blockIdx.x * K2A_TS;
-	if (n0 >= avail_end)
-		return;
-	const long long left = (avail_end - n0 + 1) / 2;
-	const int nt = (int)(left < K2A_TS ? left : K2A_TS);
-	k2a_tile<2>(sh, p, sc, dec_base, n0, nt, 1u << p.cs[sc].r, 2, 0, 0, nullptr);
+	K2aPre<2> pre;
+	pre.loaded = false;
+	const unsigned rmask = 1u << p.cs[sc].r;
+	const long long step = 2LL * gridDim.x * K2A_TS;
+	for (long long n0 = p.cs[sc].pos + 2LL * blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
+		const long long left = (avail_end - n0 + 1) / 2;
+		const int nt = (int)(left < K2A_TS ? left : K2A_TS);
+		const long long n1 = n0 + step;
+		const long long left1 = (avail_end - n1 + 1) / 2;
+		const int nt1 = n1 < avail_end ? (int)(left1 < K2A_TS ? left1 : K2A_TS) : 0;
+		k2a_tile<2>(sh, p, sc, dec_base, n0, nt, rmask, 2, 0, 0, nullptr, pre, n1, nt1);
+	}
 }
 
 /* ---- regions around the probe's hits (one workgroup per channel) */
@@ -1517,7 +1662,7 @@ void k2r_regions(K2Params p)
 	}
 }
 
-__global__ __launch_bounds__(K2A_THREADS)
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k2a_region(K2Params p)
 {
 	__shared__ K2aShared sh;
@@ -1527,18 +1672,28 @@ void k2a_region(K2Params p)
 		return;
 	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
 	const long long dec_base = p.ss[s].dec_base;
+	const int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
+	const int skip_r = p.cs[sc].r, skip_par = (int)(p.cs[sc].pos & 1);
+	k2a_tables(sh);
+	K2aPre<1> pre;
+	pre.loaded = false;
 	for (unsigned k = blockIdx.x; k < nreg; k += gridDim.x) {
-		const int2 rg = p.regs[(size_t)sc * VDL2_REG_CAP + k];
-		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu, 0, 0, 0, nullptr, p.cs[sc].r, (int)(p.cs[sc].pos & 1));
+		const int2 rg = regs[k];
+		const int2 rn = (k + gridDim.x < nreg) ? regs[k + gridDim.x] : make_int2(0, 0);
+		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu, 0, 0, 0, nullptr, pre, dec_base + rn.x, rn.y, skip_r, skip_par);
 	}
 }
 
-/* one tile = 2*K2A_TS samples; every verify segment overlapping it is scanned in its own class */
-__global__ __launch_bounds__(K2A_THREADS)
+/* one workgroup = K2A_VRUN tiles of 2*K2A_TS samples; every piece of a verify segment inside a tile
+ * is scanned in the segment's class */
+#define K2A_VRUN 4
+#define K2A_VITEMS 96
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k2a_verify(K2Params p)
 {
 	__shared__ K2aShared sh;
-	__shared__ int s_list[64], s_nl;
+	__shared__ int s_list[64], s_nl, s_ni;
+	__shared__ int4 s_item[K2A_VITEMS];	/* lo, hi (stream-relative samples), sub-phase */
 	const int tid = threadIdx.x;
 	const int c = blockIdx.y, s = blockIdx.z;
 	const int sc = s * VDL2_CS + c;
@@ -1548,19 +1703,20 @@ void k2a_verify(K2Params p)
 		return;
 	const StreamState *ss = p.ss + s;
 	const long long dec_base = ss->dec_base;
-	const int t_lo = (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * 2 * K2A_TS;
+	const int r_lo = (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * K2A_VRUN * 2 * K2A_TS;
 	const int t_end = (int)(ss->dec_fill + p.J);
-	if (t_lo >= t_end)
+	if (r_lo >= t_end)
 		return;
-	const int t_hi = t_lo + 2 * K2A_TS < t_end ? t_lo + 2 * K2A_TS : t_end;
+	const int r_hi = r_lo + K2A_VRUN * 2 * K2A_TS < t_end ? r_lo + K2A_VRUN * 2 * K2A_TS : t_end;
 	const int nseg = (int)p.ctl[CTL_NSEG0 + sc];
 	const Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
+	k2a_tables(sh);
 	if (tid == 0)
 		s_nl = 0;
 	__syncthreads();
 	for (int k = tid; k < nseg && k < VDL2_SEG_CAP; k += K2A_THREADS) {
 		const Seg g = segs[k];
-		if (g.lo < t_hi && g.hi > t_lo && g.hi > g.lo) {
+		if (g.lo < r_hi && g.hi > r_lo && g.hi > g.lo) {
 			const int q = atomicAdd(&s_nl, 1);
 			if (q < 64)
 				s_list[q] = k;
@@ -1568,20 +1724,38 @@ void k2a_verify(K2Params p)
 	}
 	__syncthreads();
 	const int nl = s_nl;
-	if (nl > 64) {		/* absurdly fragmented tile: give up on the tables for this channel */
+	if (tid == 0) {
+		int ni = 0;
+		for (int q = 0; q < nl && q < 64; ++q) {
+			const Seg g = segs[s_list[q]];
+			for (int t_lo = r_lo; t_lo < r_hi; t_lo += 2 * K2A_TS) {
+				const int t_hi = t_lo + 2 * K2A_TS < r_hi ? t_lo + 2 * K2A_TS : r_hi;
+				int lo = g.lo > t_lo ? g.lo : t_lo;
+				const int hi = g.hi < t_hi ? g.hi : t_hi;
+				lo += (lo ^ g.lo) & 1;		/* keep the segment's parity */
+				if (lo >= hi)
+					continue;
+				if (ni < K2A_VITEMS)
+					s_item[ni] = make_int4(lo, hi, g.r, 0);
+				++ni;
+			}
+		}
+		s_ni = ni;
+	}
+	__syncthreads();
+	const int ni = s_ni;
+	if (nl > 64 || ni > K2A_VITEMS) {	/* absurdly fragmented stretch: give up on the tables for this channel */
 		if (tid == 0)
 			atomicMin(p.fail + sc, 0);
 		return;
 	}
-	for (int q = 0; q < nl; ++q) {
-		const Seg g = segs[s_list[q]];
-		int lo = g.lo > t_lo ? g.lo : t_lo;
-		const int hi = g.hi < t_hi ? g.hi : t_hi;
-		lo += (lo ^ g.lo) & 1;		/* keep the segment's parity */
-		if (lo >= hi)
-			continue;
-		const int cnt = (hi - lo + 1) / 2;
-		k2a_tile<2>(sh, p, sc, dec_base, dec_base + lo, cnt, 1u << g.r, 1, dec_base + lo, dec_base + hi, p.fail + sc);
+	K2aPre<2> pre;
+	pre.loaded = false;
+	for (int q = 0; q < ni; ++q) {
+		const int4 it = s_item[q];
+		const int4 nx = (q + 1 < ni) ? s_item[q + 1] : make_int4(0, 0, 0, 0);
+		k2a_tile<2>(sh, p, sc, dec_base, dec_base + it.x, (it.y - it.x + 1) / 2, 1u << it.z, 1, dec_base + it.x, dec_base + it.y,
+			    p.fail + sc, pre, dec_base + nx.x, (nx.y - nx.x + 1) / 2);
 	}
 }
 
@@ -1827,6 +2001,8 @@ void k2c_resolve(K2Params p)
 		__syncthreads();
 		if (tid == 0) {
 			p.redo[sc] = 1;
+			if (p.dbg)
+				atomicAdd(p.dbg + 24, 1ull);	/* diagnostics: channel-pushes that went through a repair round */
 			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
 			p.ctl[CTL_NSEL0 + sc] = 0;
 			p.ctl[CTL_NSEG0 + sc] = 0;
