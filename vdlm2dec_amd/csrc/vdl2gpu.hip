@@ -34,7 +34,7 @@ extern "C" void sincosf(float, float *, float *);
 	} while (0)
 
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
-#define NEVX 10	/* + e[8], e[9] bracket the k1_fast launch alone */
+#define NEVX 11	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain */
 struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
@@ -83,6 +83,11 @@ struct vdl2gpu {
 	int force_serial = 0;
 	int n_cu = 256;
 	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
+	hipStream_t k1_stream = nullptr;	/* channeliser of push N+1 runs beside the demodulator of push N */
+	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
+	bool k2_rec[2] = {false, false};
+	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
+	bool k2_mid_rec = false;
 	int repair_rounds = 1;		/* adapted 1..4 from how often the serial fallback was needed */
 	unsigned redos_seen = 0;
 	uint64_t last_redo_push = 0;
@@ -213,6 +218,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	if (!h)
 		return;
 	(void)hipSetDevice(h->cfg.device);
+	if (h->k1_stream)
+		(void)hipStreamSynchronize(h->k1_stream);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
 	for (auto &pt : h->pending)
@@ -237,6 +244,16 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 			(void)hipEventDestroy(e);
 	if (h->copy_stream)
 		(void)hipStreamDestroy(h->copy_stream);
+	for (int r = 0; r < 2; ++r) {
+		if (h->k1_done[r])
+			(void)hipEventDestroy(h->k1_done[r]);
+		if (h->k2_done[r])
+			(void)hipEventDestroy(h->k2_done[r]);
+	}
+	if (h->k2_mid)
+		(void)hipEventDestroy(h->k2_mid);
+	if (h->k1_stream)
+		(void)hipStreamDestroy(h->k1_stream);
 	(void)hipFree(h->d_ctl);
 	(void)hipFree(h->d_cands);
 	(void)hipFree(h->d_clusters);
@@ -280,7 +297,11 @@ static int create_impl(vdl2gpu_t *h)
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k2a_probe, K2A_THREADS, 0) == hipSuccess && occ > 0)
 			h->probe_occ = occ;
 	}
-	HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	{
+		int prio_lo = 0, prio_hi = 0;
+		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+		HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, getenv("VDL2GPU_K2_PRIO") ? atoi(getenv("VDL2GPU_K2_PRIO")) : prio_hi));
+	}
 	const int S = h->S, L = h->L;
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
 	h->cap = VDL2_CARRY_FRAMES + jmax + 64;
@@ -300,6 +321,17 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_outc, 8 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 8 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+	{
+		/* the demodulator chain is the critical path: the channeliser only fills what it leaves idle */
+		int prio_lo = 0, prio_hi = 0;
+		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+		HIPCHK(h, hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, getenv("VDL2GPU_K1_PRIO") ? atoi(getenv("VDL2GPU_K1_PRIO")) : prio_lo));
+	}
+	for (int r = 0; r < 2; ++r) {
+		HIPCHK(h, hipEventCreateWithFlags(&h->k1_done[r], hipEventDisableTiming));
+		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
+	}
+	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid, hipEventDisableTiming));
 	h->ctl_words = CTL_CAND0 + 7 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
@@ -355,8 +387,8 @@ static int create_impl(vdl2gpu_t *h)
 	std::vector<StreamState> ss(S);
 	memset(ss.data(), 0, ss.size() * sizeof(StreamState));
 	for (auto &x : ss) {
-		x.dec_base = -VDL2_HIST;
-		x.dec_fill = VDL2_HIST;
+		x.dec_base = -VDL2_CARRY_FRAMES;	/* new output always starts at frame VDL2_CARRY_FRAMES; zeros before it */
+		x.dec_fill = VDL2_CARRY_FRAMES;
 	}
 	std::vector<ChanState> cs((size_t)S * VDL2_CS);
 	memset(cs.data(), 0, cs.size() * sizeof(ChanState));
@@ -424,8 +456,8 @@ static int harvest_timing(vdl2gpu_t *h)
 {
 	for (auto &pt : h->pending) {
 		float d[NEV - 1];
-		for (int i = 0; i + 1 < NEV; ++i)
-			HIPCHK(h, hipEventElapsedTime(&d[i], pt.e[i], pt.e[i + 1]));
+		for (int i = 0; i + 1 < NEV; ++i)	/* the demodulator chain starts at e[10], not where the channeliser ended */
+			HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : pt.e[i], pt.e[i + 1]));
 		h->tm.channelise_ms += d[0];
 		h->tm.scan_ms += d[1] + d[4];
 		h->tm.cluster_ms += d[2];
@@ -465,6 +497,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		return VDL2GPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	if (h->pending.size() >= 256) {	/* bound the event backlog */
+		HIPCHK(h, hipStreamSynchronize(h->k1_stream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		int rc = harvest_timing(h);
 		if (rc)
@@ -483,7 +516,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		const size_t per = nsamples * h->sample_bytes;
 		const size_t need = per * (size_t)h->S;
 		if (need > h->raw_bytes) {
-			HIPCHK(h, hipStreamSynchronize(h->stream));
+			HIPCHK(h, hipStreamSynchronize(h->k1_stream));
 			(void)hipFree(h->d_raw);
 			h->d_raw = nullptr;
 			h->raw_bytes = 0;
@@ -493,12 +526,12 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		for (int s = 0; s < h->S; ++s)
 			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw + (size_t)s * per,
 						 (const char *)iq + (size_t)s * stream_stride_bytes, per,
-						 hipMemcpyHostToDevice, h->stream));
+						 hipMemcpyHostToDevice, h->k1_stream));
 		/* the caller may reuse its buffer as soon as we return (the reference's producer refills
 		 * Cbuff right after the consumers pass Bar1, d8psk.c:383): wait for the copies only */
 		if (!h->copy_done)
 			HIPCHK(h, hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
-		HIPCHK(h, hipEventRecord(h->copy_done, h->stream));
+		HIPCHK(h, hipEventRecord(h->copy_done, h->k1_stream));
 		HIPCHK(h, hipEventSynchronize(h->copy_done));
 		src = h->d_raw;
 		stride = per;
@@ -530,11 +563,16 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		return rc;
 	pt.samples = nsamples;
 	pt.fast = false;
-	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipMemsetAsync(h->d_outc + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipMemsetAsync(h->d_fail, 0x7f, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
-	HIPCHK(h, hipMemsetAsync(h->d_redo, 0, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
-	HIPCHK(h, hipEventRecord(pt.e[0], h->stream));
+	/* Two streams.  The channeliser of this push only needs the plane set it writes to be free
+	 * (the demodulator of the push before last has finished with it), so it runs on its own
+	 * stream beside the demodulator chain of the previous push, whose one-workgroup-per-channel
+	 * steps leave most of the GPU idle. */
+	hipStream_t ks = h->k1_stream;
+	if (h->k2_rec[par])
+		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_done[par], 0));
+	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* start beside the previous push's resolver, not beside its scan */
+		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
+	HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
 		const size_t smem = ((size_t)(h->L + h->maxwin) * VDL2_CS + (size_t)K1_OPB * h->maxwin) * sizeof(float2);
@@ -547,10 +585,10 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			const unsigned gx = (unsigned)((jend - jbeg + 1 + per_block - 1) / per_block);
 			const dim3 grid(gx, (unsigned)h->S);
 			switch (h->cfg.fmt) {
-			case VDL2GPU_FMT_CU8: launch_k1<VDL2GPU_FMT_CU8>(q, grid, smem, h->stream); break;
-			case VDL2GPU_FMT_CS16: launch_k1<VDL2GPU_FMT_CS16>(q, grid, smem, h->stream); break;
-			case VDL2GPU_FMT_CF32: launch_k1<VDL2GPU_FMT_CF32>(q, grid, smem, h->stream); break;
-			default: launch_k1<VDL2GPU_FMT_F32R>(q, grid, smem, h->stream); break;
+			case VDL2GPU_FMT_CU8: launch_k1<VDL2GPU_FMT_CU8>(q, grid, smem, ks); break;
+			case VDL2GPU_FMT_CS16: launch_k1<VDL2GPU_FMT_CS16>(q, grid, smem, ks); break;
+			case VDL2GPU_FMT_CF32: launch_k1<VDL2GPU_FMT_CF32>(q, grid, smem, ks); break;
+			default: launch_k1<VDL2GPU_FMT_F32R>(q, grid, smem, ks); break;
 			}
 		};
 		const long long periods = J / K1F_PER_OUT;
@@ -563,7 +601,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			k1.per_n = periods - 2;
 			generic(0, K1F_PER_OUT - 1);
 			pt.fast = true;
-			HIPCHK(h, hipEventRecord(pt.e[8], h->stream));
+			HIPCHK(h, hipEventRecord(pt.e[8], ks));
 			/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of
 			 * rounds of the GPU's wave slots (5 per SIMD at this kernel's register count) */
 			{
@@ -578,27 +616,34 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			}
 			const dim3 grid((unsigned)((k1.per_n + k1.per_pb - 1) / k1.per_pb) * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
-			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 			case VDL2GPU_FMT_CS16:
 				switch (k1.variant) {	/* development ablations; 0 in production */
-				case 1: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 1>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-				case 2: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 2>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-				case 3: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 3>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-				case 4: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 4>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-				case 7: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 7>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-				default: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 0>), grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+				case 1: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 1>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				case 2: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 2>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				case 3: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 3>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				case 4: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 4>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				case 7: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 7>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				default: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 0>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
 				}
 				break;
-			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
-			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, h->stream, k1); break;
+			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 			}
-			HIPCHK(h, hipEventRecord(pt.e[9], h->stream));
+			HIPCHK(h, hipEventRecord(pt.e[9], ks));
 			generic((periods - 1) * K1F_PER_OUT, J);
 		} else
 			generic(0, J);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[1], h->stream));
+	HIPCHK(h, hipEventRecord(pt.e[1], ks));
+	HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
+	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->d_outc + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->d_fail, 0x7f, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->d_redo, 0, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
+	HIPCHK(h, hipStreamWaitEvent(h->stream, h->k1_done[par], 0));
+	HIPCHK(h, hipEventRecord(pt.e[10], h->stream));
 	{
 		K2Params k2{};
 		k2.dec = h->d_dec[par];
@@ -651,6 +696,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2b_clusters, dim3(3072, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
+		HIPCHK(h, hipEventRecord(h->k2_mid, h->stream));
+		h->k2_mid_rec = true;
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
@@ -691,6 +738,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		HIPCHK(h, hipGetLastError());
 	}
 	HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
+	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
+	h->k2_rec[par] = true;
 	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 2 * ring, h->d_outc + 2 * ring, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 4 + ring, h->d_outc + 4, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipEventRecord(h->ring_done[ring], h->stream));
@@ -707,6 +756,7 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 	if (!h)
 		return VDL2GPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
+	HIPCHK(h, hipStreamSynchronize(h->k1_stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	return harvest_timing(h);
 }

@@ -1500,12 +1500,17 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 			for (int i = c0 + tid; i < c1; i += K2A_THREADS) {
 				const int j = i + E2;
 				const float2 *uq = &sh.wu[PH - E4 + j - 15 * LSTR];
-				v2f acc = {0.0f, 0.0f};
+				float2 uu[16];
 #pragma unroll
-				for (int l = 0; l < 16; ++l) {
-					const float2 u = uq[l * LSTR];
-					acc = k2_rot(acc, (v2f){u.x, u.y}, rc[l], rs[l]);
+				for (int l = 0; l < 16; ++l)	/* all sixteen LDS reads in flight before the arithmetic */
+					uu[l] = uq[l * LSTR];
+				v2f acc = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+#pragma unroll
+				for (int l = 0; l < 16; l += 2) {
+					acc = k2_rot(acc, (v2f){uu[l].x, uu[l].y}, rc[l], rs[l]);
+					acc1 = k2_rot(acc1, (v2f){uu[l + 1].x, uu[l + 1].y}, rc[l + 1], rs[l + 1]);
 				}
+				acc += acc1;
 				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
 				if (!(r2 <= VDL2_SCREEN_R2)) {
 					const int k = atomicAdd(&sh.nwl, 1);
@@ -2326,9 +2331,14 @@ void k3_compact(K3Params p)
 		nb = end - VDL2_HIST;	/* always keep the history */
 	if (nb < base)
 		nb = base;
+	if (nb < end - VDL2_CARRY_FRAMES)
+		nb = end - VDL2_CARRY_FRAMES;	/* cannot happen: no burst is that long */
 	const long long keep = end - nb;
+	/* the carry sits right-aligned below frame VDL2_CARRY_FRAMES of the other plane set, so that the
+	 * channeliser of the next push -- which writes from that frame on -- does not depend on how
+	 * much is carried and may run while this push is still being demodulated */
 	const float2 *src = p.src + ((size_t)s * VDL2_CS + c) * p.cap + (nb - base);
-	float2 *dst = p.dst + ((size_t)s * VDL2_CS + c) * p.cap;
+	float2 *dst = p.dst + ((size_t)s * VDL2_CS + c) * p.cap + (VDL2_CARRY_FRAMES - keep);
 	for (long long i = threadIdx.x; i < keep; i += K3_THREADS)
 		dst[i] = src[i];
 }
@@ -2350,17 +2360,22 @@ __global__ void k3_rebase(K3Params p)
 	long long nb = mn - VDL2_HIST;
 	if (nb > end - VDL2_HIST)
 		nb = end - VDL2_HIST;
-	if (nb < base)
-		nb = base;
-	ss->dec_base = nb;
-	ss->dec_fill = end - nb;
+	ss->dec_base = end - VDL2_CARRY_FRAMES;	/* frame VDL2_CARRY_FRAMES = first output of the next push */
+	ss->dec_fill = VDL2_CARRY_FRAMES;
 }
 
+/* test hook: both device forms of atan2f; a disagreement between them comes back as NaN */
 __global__ void k_atan2f(const float *y, const float *x, float *out, size_t n)
 {
+	__shared__ float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];
+	if (threadIdx.x < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+		atab[threadIdx.x] = vdl2_atan_tab_entry(threadIdx.x);
+	__syncthreads();
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n)
-		out[i] = vdl2_atan2f(y[i], x[i]);
+	if (i < n) {
+		const float a = vdl2_atan2f(y[i], x[i]), b = vdl2_atan2f_tab(y[i], x[i], atab);
+		out[i] = (__float_as_uint(a) == __float_as_uint(b)) ? b : __uint_as_float(0x7fc00001u);
+	}
 }
 
 #endif
