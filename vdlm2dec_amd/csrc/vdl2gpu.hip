@@ -688,7 +688,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			per = per < 1 ? 1 : (per > want ? want : per);
 			hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		}
-		hipLaunchKernelGGL(k2r_regions, gch, dim3(256), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);

@@ -1594,10 +1594,132 @@ void k2a_probe(K2Params p)
 	}
 }
 
+/* ---- workgroup sort of up to VDL2_CAND_CAP 64-bit keys whose top bits are a time stamp.
+ * Detector events are spread over the push (a few per burst, bursts are sparse), so a bucket
+ * sort on time -- histogram, scan, scatter, then a short insertion sort inside each bucket -- needs
+ * about a dozen barriers where a bitonic network needs log^2(n)/2 = 78.  A push whose events
+ * pile up in one bucket (more than WGS_MAXB) falls back to the bitonic network.
+ *   keys[] in/out (LDS), tmp[] scratch (LDS), both VDL2_CAND_CAP long; time = key >> tshift, < range. */
+#define WGS_NBK 2048
+#define WGS_MAXB 48
+struct WgSortShared {
+	unsigned long long tmp[VDL2_CAND_CAP];
+	unsigned start[WGS_NBK + 1], cur[WGS_NBK];
+	unsigned part[64];
+	unsigned maxb;
+};
+
+template <int NT> __device__ void wg_sort_u64(unsigned long long *keys, WgSortShared &ws, int n, int tshift, unsigned range)
+{
+	const int tid = threadIdx.x;
+	int bsh = 0;
+	while ((range >> bsh) >= WGS_NBK)
+		++bsh;
+	for (int b = tid; b < WGS_NBK; b += NT)
+		ws.cur[b] = 0;
+	if (tid == 0)
+		ws.maxb = 0;
+	__syncthreads();
+	for (int i = tid; i < n; i += NT) {
+		unsigned b = (unsigned)(keys[i] >> tshift) >> bsh;
+		b = b < WGS_NBK ? b : WGS_NBK - 1;
+		const unsigned k = atomicAdd(&ws.cur[b], 1u);
+		if (k + 1 > WGS_MAXB)
+			ws.maxb = 1;
+	}
+	__syncthreads();
+	if (ws.maxb) {
+		/* crowded bucket: bitonic network over the next power of two */
+		int npow = 1;
+		while (npow < n)
+			npow <<= 1;
+		for (int i = n + tid; i < npow; i += NT)
+			keys[i] = ~0ull;
+		__syncthreads();
+		for (int k = 2; k <= npow; k <<= 1)
+			for (int j = k >> 1; j > 0; j >>= 1) {
+				for (int i = tid; i < npow; i += NT) {
+					const int l = i ^ j;
+					if (l > i) {
+						const unsigned long long a0 = keys[i], b0 = keys[l];
+						if ((a0 > b0) == ((i & k) == 0)) {
+							keys[i] = b0;
+							keys[l] = a0;
+						}
+					}
+				}
+				__syncthreads();
+			}
+		return;
+	}
+	/* exclusive scan of the bucket counts: per-thread run of WGS_NBK / NT buckets, then a scan of the run sums */
+	constexpr int RUN = (WGS_NBK + NT - 1) / NT;
+	{
+		unsigned sum = 0;
+		for (int k = 0; k < RUN; ++k) {
+			const int b = tid * RUN + k;
+			if (b < WGS_NBK)
+				sum += ws.cur[b];
+		}
+		/* wave-level inclusive scan, then the wave totals */
+		unsigned incl = sum;
+		for (int d = 1; d < 64; d <<= 1) {
+			const unsigned o = __shfl_up(incl, d, 64);
+			if ((tid & 63) >= d)
+				incl += o;
+		}
+		if ((tid & 63) == 63)
+			ws.part[tid >> 6] = incl;
+		__syncthreads();
+		unsigned base = 0;
+		for (int w = 0; w < (tid >> 6); ++w)
+			base += ws.part[w];
+		unsigned run = base + incl - sum;
+		for (int k = 0; k < RUN; ++k) {
+			const int b = tid * RUN + k;
+			if (b < WGS_NBK) {
+				const unsigned cnt = ws.cur[b];
+				ws.start[b] = run;
+				ws.cur[b] = run;
+				run += cnt;
+			}
+		}
+		if (tid == NT - 1)
+			ws.start[WGS_NBK] = run;
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += NT) {
+		const unsigned long long v = keys[i];
+		unsigned b = (unsigned)(v >> tshift) >> bsh;
+		b = b < WGS_NBK ? b : WGS_NBK - 1;
+		ws.tmp[atomicAdd(&ws.cur[b], 1u)] = v;
+	}
+	__syncthreads();
+	for (int b = tid; b < WGS_NBK; b += NT) {
+		const int lo = (int)ws.start[b], hi = (int)ws.start[b + 1];
+		for (int i = lo + 1; i < hi; ++i) {
+			const unsigned long long v = ws.tmp[i];
+			int j = i - 1;
+			while (j >= lo && ws.tmp[j] > v) {
+				ws.tmp[j + 1] = ws.tmp[j];
+				--j;
+			}
+			ws.tmp[j + 1] = v;
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += NT)
+		keys[i] = ws.tmp[i];
+	__syncthreads();
+}
+
 /* ---- regions around the probe's hits (one workgroup per channel) */
-__global__ __launch_bounds__(256)
+#define K2R_NT 1024
+__global__ __launch_bounds__(K2R_NT)
 void k2r_regions(K2Params p)
 {
+	__shared__ unsigned long long key64[VDL2_CAND_CAP];
+	__shared__ WgSortShared ws;
 	__shared__ int key[VDL2_CAND_CAP];
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
@@ -1607,26 +1729,13 @@ void k2r_regions(K2Params p)
 	int ncand = (int)p.ctl[CTL_NSEED0 + sc];
 	ncand = ncand > VDL2_CAND_CAP ? VDL2_CAND_CAP : ncand;
 	const int *seeds = p.seeds + (size_t)sc * VDL2_CAND_CAP;
-	int npow = 1;
-	while (npow < ncand)
-		npow <<= 1;
-	for (int i = tid; i < npow; i += 256)
-		key[i] = (i < ncand) ? seeds[i] : 0x7fffffff;
+	for (int i = tid; i < ncand; i += K2R_NT)
+		key64[i] = (unsigned long long)(unsigned)seeds[i];
 	__syncthreads();
-	for (int k = 2; k <= npow; k <<= 1)
-		for (int j = k >> 1; j > 0; j >>= 1) {
-			for (int i = tid; i < npow; i += 256) {
-				const int l = i ^ j;
-				if (l > i) {
-					const int a0 = key[i], b0 = key[l];
-					if ((a0 > b0) == ((i & k) == 0)) {
-						key[i] = b0;
-						key[l] = a0;
-					}
-				}
-			}
-			__syncthreads();
-		}
+	wg_sort_u64<K2R_NT>(key64, ws, ncand, 0, (unsigned)(p.ss[s].dec_fill + p.J));
+	for (int i = tid; i < ncand; i += K2R_NT)
+		key[i] = (int)key64[i];
+	__syncthreads();
 	{
 		/* every run of hits closer than VDL2_REG_GAP becomes a region (order is irrelevant) */
 		__shared__ int s_nreg;
@@ -1637,7 +1746,7 @@ void k2r_regions(K2Params p)
 		if (tid == 0)
 			s_nreg = 0;
 		__syncthreads();
-		for (int i = tid; i < ncand; i += 256) {
+		for (int i = tid; i < ncand; i += K2R_NT) {
 			if (i > 0 && key[i] - key[i - 1] <= VDL2_REG_GAP)
 				continue;	/* not the first hit of its run */
 			int j = i;
@@ -1777,6 +1886,7 @@ __global__ __launch_bounds__(K2S_NT)
 void k2s_sort(K2Params p)
 {
 	__shared__ unsigned long long sbuf[VDL2_CAND_CAP];
+	__shared__ WgSortShared ws;
 	__shared__ int s_np;
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
@@ -1790,29 +1900,12 @@ void k2s_sort(K2Params p)
 		return;		/* tables unusable: the resolver runs serially */
 	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
 	Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
-	int npow = 1;
-	while (npow < ncand)
-		npow <<= 1;
-	for (int i = tid; i < npow; i += K2S_NT)
-		sbuf[i] = (i < ncand) ? (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i
-				      : ~0ull;
+	for (int i = tid; i < ncand; i += K2S_NT)
+		sbuf[i] = (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i;
 	if (tid == 0)
 		s_np = 0;
 	__syncthreads();
-	for (int k = 2; k <= npow; k <<= 1)
-		for (int j = k >> 1; j > 0; j >>= 1) {
-			for (int i = tid; i < npow; i += K2S_NT) {
-				const int l = i ^ j;
-				if (l > i) {
-					const unsigned long long a0 = sbuf[i], b0 = sbuf[l];
-					if ((a0 > b0) == ((i & k) == 0)) {
-						sbuf[i] = b0;
-						sbuf[l] = a0;
-					}
-				}
-			}
-			__syncthreads();
-		}
+	wg_sort_u64<K2S_NT>(sbuf, ws, ncand, 18, (unsigned)(p.ss[s].dec_fill + p.J));
 	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
 	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
 	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
