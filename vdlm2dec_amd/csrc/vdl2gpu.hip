@@ -68,6 +68,7 @@ struct vdl2gpu {
 	unsigned rec_cap = 0;
 	Cand *d_cands = nullptr;
 	Cluster *d_clusters = nullptr;
+	int2 *d_clhead = nullptr;
 	BurstDesc *d_stage = nullptr;
 	unsigned *d_sel_list = nullptr;
 	int2 *d_regs = nullptr;
@@ -257,6 +258,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_ctl);
 	(void)hipFree(h->d_cands);
 	(void)hipFree(h->d_clusters);
+	(void)hipFree(h->d_clhead);
 	(void)hipFree(h->d_stage);
 	(void)hipFree(h->d_sel_list);
 	(void)hipFree(h->d_regs);
@@ -337,6 +339,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
 	HIPCHK(h, hipMalloc(&h->d_clusters, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
+	HIPCHK(h, hipMalloc(&h->d_clhead, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int2)));
 	h->stage_cap = (unsigned)S * VDL2_CS * VDL2_CAND_CAP * VDL2_CL_MAXB + 65536u;	/* static slots + dynamic tail */
 	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
 	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
@@ -657,6 +660,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.pn = h->d_pn;
 		k2.cands = h->d_cands;
 		k2.clusters = h->d_clusters;
+		k2.clhead = h->d_clhead;
 		k2.ctl = h->d_ctl;
 		k2.stage = h->d_stage;
 		k2.sel_list = h->d_sel_list;

@@ -102,6 +102,15 @@ struct Cluster {
 	ChanState saved;	/* CL_NONSTEADY: explicit state to continue from */
 };
 
+/* resolver's view of a cluster: x = n_s - dec_base, y = status | r_s << 2 | nslots << 4 | ntrig << 8 | nrej << 16 | nburst << 24 */
+__device__ __forceinline__ int2 cl_pack(int n_s_rel, int status, int r_s, int nslots, int ntrig, int nrej, int nburst)
+{
+	ntrig = ntrig > 255 ? 255 : ntrig;
+	nrej = nrej > 255 ? 255 : nrej;
+	nburst = nburst > 255 ? 255 : nburst;
+	return make_int2(n_s_rel, status | (r_s << 2) | (nslots << 4) | (ntrig << 8) | (nrej << 16) | (nburst << 24));
+}
+
 struct BurstDesc {		/* a burst found by a cluster; payload decoded later if it is on the real chain */
 	long long nstar;	/* stream time of the sync trigger */
 	int sc;			/* stream*8 + channel */
@@ -142,6 +151,7 @@ struct K2Params {
 	const uint8_t *pn;
 	Cand *cands;		/* [S*8][CAND_CAP] */
 	Cluster *clusters;	/* [S*8][CAND_CAP] */
+	int2 *clhead;		/* [S*8][CAND_CAP] what the resolver needs of every cluster, 8 bytes: see cl_pack() */
 	unsigned *ctl;		/* [0]=out count [1]=out overflow [2]=stage count [3]=k2b ticket [4]=stage overflow
 				 * [8 + S*8 ...] cand counts, then cand overflow flags */
 	BurstDesc *stage;	/* burst descriptors of all clusters */
@@ -1927,8 +1937,10 @@ void k2s_sort(K2Params p)
 		}
 		if (primary)
 			prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
-		else
+		else {
 			clusters[idx].status = CL_INVALID;
+			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
+		}
 	}
 	__syncthreads();
 	if (tid == 0)
@@ -2040,6 +2052,8 @@ void k2b_clusters(K2Params p)
 			cl->ntrig = out.ntrig;
 			cl->nrej = out.nrej;
 			cl->nburst = out.nburst;
+			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] =
+			    cl_pack((int)(st.pos - cx.dec_base), status, st.r, cl->nslots, out.ntrig, out.nrej, out.nburst);
 		}
 		__syncthreads();
 	}
@@ -2088,6 +2102,7 @@ void k2c_resolve(K2Params p)
 	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
 	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
 	__shared__ uint8_t ssel[VDL2_CAND_CAP];		/* visited by the real chain */
+	__shared__ int2 shead[VDL2_CAND_CAP];		/* cl_pack() of every candidate's cluster, by sorted rank */
 	__shared__ int s_walk[4];
 	__shared__ int s_cnt[4];
 	const int tid = threadIdx.x;
@@ -2141,19 +2156,24 @@ void k2c_resolve(K2Params p)
 	/* 1. candidates sorted by time (K2s) */
 	const long long pos_in = st.pos;
 	const long long tk0 = wall_clock64();
-	for (int i = tid; i < ncand; i += K2_NT) {
-		skey[i] = p.skey[(size_t)sc * VDL2_CAND_CAP + i];
-		sidx[i] = p.sidx[(size_t)sc * VDL2_CAND_CAP + i];
+	{
+		const int2 *head = p.clhead + (size_t)sc * VDL2_CAND_CAP;
+		for (int i = tid; i < ncand; i += K2_NT) {
+			const int idx = p.sidx[(size_t)sc * VDL2_CAND_CAP + i];
+			skey[i] = p.skey[(size_t)sc * VDL2_CAND_CAP + i];
+			sidx[i] = (unsigned short)idx;
+			shead[i] = head[idx];
+		}
 	}
 	__syncthreads();
 	const long long tk1 = wall_clock64();
 	/* 2. successor table */
 	for (int j = tid; j < ncand; j += K2_NT) {
-		const Cluster *cl = clusters + sidx[j];
-		const int status = cl->status;
+		const int2 hd = shead[j];
+		const int status = hd.y & 3;
 		int nx = -1;
 		if (status == CL_STEADY)
-			nx = k2c_next(skey, ncand, j + 1, (int)(cl->n_s - cx.dec_base), cl->r_s);
+			nx = k2c_next(skey, ncand, j + 1, hd.x, (hd.y >> 2) & 3);
 		sstat[j] = (uint8_t)status;
 		snext[j] = (nx < 0) ? (unsigned short)K2C_NOCAND : (unsigned short)nx;
 		ssel[j] = 0;
@@ -2208,9 +2228,8 @@ void k2c_resolve(K2Params p)
 		const int cur = s_walk[0], last = s_walk[1], why = s_walk[2];
 		__syncthreads();
 		if (last >= 0) {
-			const Cluster *cl = clusters + sidx[last];
-			st.pos = cl->n_s;
-			st.r = cl->r_s;
+			st.pos = cx.dec_base + shead[last].x;
+			st.r = (shead[last].y >> 2) & 3;
 		}
 		if (!why) {
 			/* idle to the end of the data: next evaluation is the first one past it */
@@ -2257,7 +2276,8 @@ void k2c_resolve(K2Params p)
 		for (int j = tid; j < ncand; j += K2_NT)
 			if (ssel[j]) {
 				const Cluster *cl = clusters + sidx[j];
-				const int ns = cl->nslots;
+				const int2 hd = shead[j];
+				const int ns = (hd.y >> 4) & 15;
 				for (int i = 0; i < ns; ++i) {
 					const unsigned q = atomicAdd(nsel, 1u);
 					if (q < VDL2_SEL_CAP)
@@ -2265,18 +2285,20 @@ void k2c_resolve(K2Params p)
 					else
 						atomicAdd(p.outc + 1, 1u);
 				}
-				a += cl->ntrig;
-				b += cl->nrej;
-				d += cl->nburst;
-				if (lazy && sstat[j] == CL_STEADY && (cl->r_s != r_probe || (int)(cl->n_s & 1) != par_probe)) {
+				a += (hd.y >> 8) & 255;
+				b += (hd.y >> 16) & 255;
+				d += (hd.y >> 24) & 255;
+				const int r_s = (hd.y >> 2) & 3;
+				const long long n_s = cx.dec_base + hd.x;
+				if (lazy && sstat[j] == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe)) {
 					/* after this cluster the chain idles in class (r_s, parity of n_s) until
 					 * the successor's trigger (or the end of the data) */
 					const unsigned q = atomicAdd(nseg, 1u);
 					if (q < VDL2_SEG_CAP) {
 						Seg g;
-						g.lo = (int)(cl->n_s - cx.dec_base);
+						g.lo = hd.x;
 						g.hi = (snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2);
-						g.r = cl->r_s;
+						g.r = r_s;
 						g.pad = 0;
 						segs[q] = g;
 					} else
