@@ -39,6 +39,7 @@ struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
 	bool fast;
+	bool staged;
 };
 
 struct vdl2gpu {
@@ -84,12 +85,13 @@ struct vdl2gpu {
 	int force_serial = 0;
 	int n_cu = 256;
 	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
+	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown) */
 	hipStream_t k1_stream = nullptr;	/* channeliser of push N+1 runs beside the demodulator of push N */
 	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
 	bool k2_rec[2] = {false, false};
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
 	bool k2_mid_rec = false;
-	int repair_rounds = 1;		/* adapted 1..4 from how often the serial fallback was needed */
+	int repair_rounds = 0;		/* adapted 0..4 from how often the serial fallback was needed */
 	unsigned redos_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -103,7 +105,8 @@ struct vdl2gpu {
 	std::vector<uint32_t> ready_idx;	/* hand-out order: indices into `ready`, consumed from ready_pos */
 	size_t ready_pos = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
-	unsigned *h_pin_cnt = nullptr;
+	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [4*ring + {0,1,2}] */
+	unsigned *d_pin_cnt = nullptr;	/* its device address */
 	unsigned pin_recs = 0;
 	std::string err;
 };
@@ -353,11 +356,16 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	HIPCHK(h, hipMalloc(&h->d_seeds, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
+	if (getenv("VDL2GPU_NO_STAGE_EVENTS"))
+		h->stage_events = false;
+	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
+		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 8 * sizeof(unsigned), hipHostMallocDefault));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 8 * sizeof(unsigned), hipHostMallocMapped));
 	memset(h->h_pin_cnt, 0, 8 * sizeof(unsigned));
+	HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pin_cnt, h->h_pin_cnt, 0));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
 
@@ -458,9 +466,12 @@ static int get_events(vdl2gpu_t *h, PushTiming &pt)
 static int harvest_timing(vdl2gpu_t *h)
 {
 	for (auto &pt : h->pending) {
-		float d[NEV - 1];
-		for (int i = 0; i + 1 < NEV; ++i)	/* the demodulator chain starts at e[10], not where the channeliser ended */
+		float d[NEV - 1] = {0};
+		for (int i = 0; i + 1 < NEV; ++i) {	/* the demodulator chain starts at e[10], not where the channeliser ended */
+			if (i > 0 && !pt.staged)
+				break;
 			HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : pt.e[i], pt.e[i + 1]));
+		}
 		h->tm.channelise_ms += d[0];
 		h->tm.scan_ms += d[1] + d[4];
 		h->tm.cluster_ms += d[2];
@@ -566,6 +577,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		return rc;
 	pt.samples = nsamples;
 	pt.fast = false;
+	pt.staged = h->stage_events;
 	/* Two streams.  The channeliser of this push only needs the plane set it writes to be free
 	 * (the demodulator of the push before last has finished with it), so it runs on its own
 	 * stream beside the demodulator chain of the previous push, whose one-workgroup-per-channel
@@ -641,12 +653,19 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	}
 	HIPCHK(h, hipEventRecord(pt.e[1], ks));
 	HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
-	HIPCHK(h, hipMemsetAsync(h->d_ctl + CTL_STAGE, 0, (h->ctl_words - CTL_STAGE) * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipMemsetAsync(h->d_outc + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipMemsetAsync(h->d_fail, 0x7f, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
-	HIPCHK(h, hipMemsetAsync(h->d_redo, 0, (size_t)h->S * VDL2_CS * sizeof(int), h->stream));
+	{
+		KInitParams ki{};
+		ki.ctl = h->d_ctl + CTL_STAGE;
+		ki.ctl_words = (int)(h->ctl_words - CTL_STAGE);
+		ki.outc = h->d_outc + 2 * ring;
+		ki.fail = h->d_fail;
+		ki.redo = h->d_redo;
+		ki.nsc = h->S * VDL2_CS;
+		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, h->stream, ki);
+	}
 	HIPCHK(h, hipStreamWaitEvent(h->stream, h->k1_done[par], 0));
-	HIPCHK(h, hipEventRecord(pt.e[10], h->stream));
+	if (h->stage_events)
+		HIPCHK(h, hipEventRecord(pt.e[10], h->stream));
 	{
 		K2Params k2{};
 		k2.dec = h->d_dec[par];
@@ -696,14 +715,17 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
+		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
 		hipLaunchKernelGGL(k2b_clusters, dim3(3072, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
 		HIPCHK(h, hipEventRecord(h->k2_mid, h->stream));
 		h->k2_mid_rec = true;
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
 		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
@@ -721,12 +743,14 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			}
 			HIPCHK(h, hipGetLastError());
 		}
+		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
+	if (h->stage_events)
+		HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
 	{
 		K3Params k3{};
 		k3.src = h->d_dec[par];
@@ -736,16 +760,18 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k3.J = J;
 		k3.ss = h->d_ss;
 		k3.cs = h->d_cs;
+		k3.outc = h->d_outc;
+		k3.host_cnt = h->d_pin_cnt + 4 * ring;
+		k3.ring = ring;
 		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
+	if (h->stage_events)
+		HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
 	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
 	h->k2_rec[par] = true;
-	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 2 * ring, h->d_outc + 2 * ring, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(h, hipMemcpyAsync(h->h_pin_cnt + 4 + ring, h->d_outc + 4, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipEventRecord(h->ring_done[ring], h->stream));
 	h->ring_busy[ring] = true;
 	h->ring_push[ring] = h->pushes;
@@ -782,17 +808,17 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		}
 	}
 	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
-	const unsigned c0 = h->h_pin_cnt[2 * ring], c1 = h->h_pin_cnt[2 * ring + 1];
+	const unsigned c0 = h->h_pin_cnt[4 * ring], c1 = h->h_pin_cnt[4 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
 	{
 		/* more repair rounds while pushes keep falling back to the serial machine, fewer when quiet */
-		const unsigned redos = h->h_pin_cnt[4 + ring];
+		const unsigned redos = h->h_pin_cnt[4 * ring + 2];
 		if (redos != h->redos_seen) {
 			h->redos_seen = redos;
 			h->last_redo_push = h->ring_push[ring];
-			h->repair_rounds = std::min(4, h->repair_rounds * 2);
-		} else if (h->repair_rounds > 1 && h->ring_push[ring] > h->last_redo_push + 8) {
+			h->repair_rounds = std::min(4, std::max(1, h->repair_rounds * 2));
+		} else if (h->repair_rounds > 0 && h->ring_push[ring] > h->last_redo_push + 8) {
 			h->repair_rounds--;
 			h->last_redo_push = h->ring_push[ring];
 		}

@@ -197,6 +197,17 @@ struct K3Params {
 	long long J;
 	StreamState *ss;
 	const ChanState *cs;
+	const unsigned *outc;	/* device counters: [2*ring] records, [2*ring+1] dropped, [4] serial redos so far */
+	unsigned *host_cnt;	/* the same three, in pinned host memory, for this push's ring */
+	int ring;
+};
+
+struct KInitParams {		/* per-push reset of the demodulator's control words */
+	unsigned *ctl;
+	int ctl_words;
+	unsigned *outc;		/* 2 words of this push's ring */
+	int *fail, *redo;
+	int nsc;
 };
 
 /* ---- constant data tables (d8psk.h:20-249) as bit patterns ------------- */
@@ -2458,12 +2469,30 @@ void k3_compact(K3Params p)
 		dst[i] = src[i];
 }
 
-/* runs after k3_compact (same stream): publish the new time base */
+/* one launch instead of four memsets */
+__global__ void k_push_init(KInitParams p)
+{
+	for (int i = threadIdx.x; i < p.ctl_words; i += blockDim.x)
+		p.ctl[i] = 0u;
+	for (int i = threadIdx.x; i < p.nsc; i += blockDim.x) {
+		p.fail[i] = 0x7f7f7f7f;
+		p.redo[i] = 0;
+	}
+	if (threadIdx.x < 2)
+		p.outc[threadIdx.x] = 0u;
+}
+
+/* runs after k3_compact (same stream): publish the new time base and hand the push's counters to the host */
 __global__ void k3_rebase(K3Params p)
 {
 	const int s = blockIdx.x;
 	if (threadIdx.x != 0)
 		return;
+	if (s == 0) {
+		p.host_cnt[0] = p.outc[2 * p.ring];
+		p.host_cnt[1] = p.outc[2 * p.ring + 1];
+		p.host_cnt[2] = p.outc[4];
+	}
 	StreamState *ss = p.ss + s;
 	long long mn = 0x7fffffffffffffffLL;
 	for (int k = 0; k < p.nbch; ++k) {
