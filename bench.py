@@ -104,8 +104,8 @@ def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0, rate: i
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--tiles", type=int, default=16, help="tiles of 4.2 MS per step (batch = tiles*4.2 MS)")
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
     ap.add_argument("--rate", type=int, default=RATE, help="SDRINRATE (config 3: 10000000)")

@@ -717,7 +717,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
-		hipLaunchKernelGGL(k2b_clusters, dim3(3072, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));

@@ -745,8 +745,12 @@ __device__ __forceinline__ void burst_timing(int clk0, int *j0, int *rb)
  * their phases itself (and the one before, for the differential slice): differential slice +
  * Grey soft tables + descramble + hard decision (d8psk.c:54-65, 119, 168, 211-217, 321-331),
  * then the column-major de-interleave as a closed-form scatter (d8psk.c:127-147, 176-197). */
+/* sph: optional LDS buffer of VDL2_MAXSYM floats.  With it every symbol phase is computed once by
+ * one lane and the byte lanes read them from LDS; without it (serial stretches of the resolver, which
+ * have no LDS to spare) each byte lane computes the four or five phases it needs itself. */
+#define VDL2_MAXSYM 5456	/* symbols 7 .. (25 + 8 * 2040 - 1) / 3 */
 template <int NT> __device__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
-						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg)
+						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph = nullptr)
 {
 	const int tid = threadIdx.x;
 	int j0, rb;
@@ -758,14 +762,20 @@ template <int NT> __device__ void burst_payload(vdl2gpu_burst_t *rec, const floa
 		w[i] = 0u;
 	__syncthreads();
 	const float2 *xs0 = x0 + (nsym0 - 16);
+	if (sph) {
+		const int kmax = (25 + 8 * (g.ND + g.NF) - 1) / 3;
+		for (int k = 7 + tid; k <= kmax; k += NT)
+			sph[k - 7] = k2_fir_phase(xs0 + 8LL * k, rb);
+		__syncthreads();
+	}
 	for (int b = tid; b < g.ND + g.NF; b += NT) {
 		const int q0 = 25 + 8 * b;
 		const int k0 = q0 / 3;	/* >= 8: never needs P1 */
 		int q = q0;
 		unsigned byte = 0;
-		float pprev = k2_fir_phase(xs0 + 8LL * (k0 - 1), rb);
+		float pprev = sph ? sph[k0 - 8] : k2_fir_phase(xs0 + 8LL * (k0 - 1), rb);
 		for (int k = k0; q < q0 + 8; ++k) {
-			const float pk = k2_fir_phase(xs0 + 8LL * k, rb);
+			const float pk = sph ? sph[k - 7] : k2_fir_phase(xs0 + 8LL * k, rb);
 			const int idx = k2_grey_index(pk, pprev, df);
 			pprev = pk;
 			for (int i = q - 3 * k; i < 3 && q < q0 + 8; ++i, ++q) {
@@ -1964,7 +1974,10 @@ void k2s_sort(K2Params p)
  * machine through the burst (and any burst that follows before the detector is
  * history-free again) and record where and how the idle search resumes.
  */
-__global__ __launch_bounds__(K2B_NT, 3)
+#ifndef K2B_WAVES
+#define K2B_WAVES 4
+#endif
+__global__ __launch_bounds__(K2B_NT) __attribute__((amdgpu_waves_per_eu(K2B_WAVES, 8)))
 void k2b_clusters(K2Params p)
 {
 	__shared__ MachSharedT<K2B_NT> sh;
@@ -2405,10 +2418,14 @@ void k2f_commit(K2Params p)
  * selected burst descriptor, one lane per byte.
  */
 #define K2D_NT 256
-__global__ __launch_bounds__(K2D_NT)
+#ifndef K2D_WAVES
+#define K2D_WAVES 2
+#endif
+__global__ __launch_bounds__(K2D_NT) __attribute__((amdgpu_waves_per_eu(K2D_WAVES, 8)))
 void k2d_payload(K2Params p)
 {
 	__shared__ unsigned s_slot;
+	__shared__ float sph[VDL2_MAXSYM];
 	const int sc = blockIdx.y;
 	unsigned n = p.ctl[CTL_NSEL0 + sc];
 	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
@@ -2428,7 +2445,7 @@ void k2d_payload(K2Params p)
 			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
-			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc]);
+			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph);
 		}
 		__syncthreads();
 	}
