@@ -1310,6 +1310,7 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
+#define K2A_WL2 32		/* survivors of both screens whose exact phases fit in LDS at once */
 #ifndef K2A_WL
 #define K2A_WL 192		/* screened-in evaluations per tile and sub-phase; more than that and the tile is done in pieces */
 #endif
@@ -1325,29 +1326,37 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 struct K2aShared {
 	float2 xs[K2A_XMAX + 8];	/* S = 1: samples in order; S = 2: even samples, then (at K2A_XODD) odd samples, so that
 					 * both FIR tap parities are unit-stride across lanes */
-	float ph[K2A_TS + K2A_POFF];	/* filtered phase of every instant (history first) */
-	float2 wu[K2A_TS + K2A_POFF];	/* its unit phasor, then the phasor of the symbol-spaced phase step */
+	float2 wu[K2A_TS + K2A_POFF];	/* unit phasor of every filtered sample (history first), then in place the phasor
+					 * of the symbol-spaced phase step */
 	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45) */
 	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants (vdl2_math.h) */
-	int wl[K2A_WL];			/* screened-in evaluations ... */
-	float we[3][K2A_WL], wf[K2A_WL];	/* ... exact fit error one evaluation earlier / there / one later, slope there */
-	int nwl;
+	int wl[K2A_WL];			/* evaluations the first screen lets through ... */
+	int wl2[K2A_WL];		/* ... and the second */
+	float sph[K2A_WL2][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
+	float we[3][K2A_WL2], wf[K2A_WL2];	/* their exact fit errors, and the slope at the middle one */
+	int nwl, nwl2;
 };
 #define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
 
-/* Screen for the 17-point fit (the expensive part of the scan).
+/* Screens for the 17-point fit (the expensive part of the scan).
  * With Pr[] the unwrapped, template-corrected phases the reference fits a line to (d8psk.c:257-289)
- * and e[] their residuals, the phase steps satisfy D_l = Pr[l] - Pr[l-1] = fr + e_l - e_(l-1), and
+ * and e[] their residuals, the lag-1 phase steps satisfy D_l = Pr[l] - Pr[l-1] = fr + e_l - e_(l-1), and
  * D_l = (P_l - P_(l-1)) - (SW_l - SW_(l-1)) modulo 2pi whatever the unwrap decided.  Hence
  *      sum_l (D_l - mean D)^2 <= sum_l (e_l - e_(l-1))^2 <= 4 * err,
  * and with R = |sum_l exp(j D_l)| >= sum_l cos(D_l - mean D) >= 16 - sum_l (D_l - mean D)^2 / 2:
  *      err >= (16 - R) / 2.
- * R needs no unwrap and no phases, only the unit phasors u = w * conj(w') of symbol-spaced FIR
- * outputs, rotated by the 16 template steps (odd multiples of pi/8) -- 32 packed FMAs.  An instant
- * with R <= 7.5 has err >= 4.25 > 4 (rounding in R is < 1e-4), so it can neither be the minimum
- * the detector fires after nor matter to it; only instants with R > 7.5 (about 3 % in noise) get
- * the exact fit.  A non-finite R counts as screened in. */
-#define VDL2_SCREEN_R2 56.25f
+ * The same argument on the 15 lag-2 steps Pr[l+2] - Pr[l] gives err >= (15 - R2) / 2.
+ * Neither needs the unwrap or even a phase: exp(j D_l) = c_l * u_l with u = w * conj(w') the unit
+ * phasor of two symbol-spaced FIR outputs and c_l the template step (an odd multiple of pi/8), and
+ * the lag-2 phasors are products of neighbouring lag-1 ones.  An evaluation with R <= 7.5 or
+ * R2 <= 6.5 has err >= 4.25 > 4 (the rounding in R, R2 is < 1e-4), so it can neither be the minimum
+ * the detector fires after nor matter to it.  Every evaluation gets the first screen (32 packed
+ * FMAs, passes ~2 % of noise), its survivors the second (passes ~6 % of those), and only what
+ * survives both -- sync words, and about one noise evaluation in a thousand -- gets atan2f, the
+ * exact unwrap and the exact fit, together with its two neighbours.  Non-finite values count as
+ * surviving. */
+#define VDL2_SCREEN_R2 56.25f	/* R^2: (16 - 7.5) / 2 = 4.25 */
+#define VDL2_SCREEN_R22 42.25f	/* R2^2: (15 - 6.5) / 2 = 4.25 */
 __device__ __forceinline__ v2f k2_rot(v2f acc, v2f u, float cx, float cy)
 {
 	/* acc += (cx + j cy) * u */
@@ -1426,8 +1435,27 @@ template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const
 
 /* mode 0: append candidates; mode 1: report hits in [chk_lo, chk_hi) to *fail and append them;
  * mode 2: probe (candidates + seeds).  One sub-phase per pass:
- *   phases + unit phasors of all instants | phase-step phasors | screen -> worklist |
- *   exact fit of the worklist | exact fit of the neighbours of the near-threshold ones | detector test. */
+ *   FIR + unit phasor of every instant | phase-step phasors | first screen -> worklist |
+ *   second screen of the worklist | exact phases of the survivors | exact fits | detector test. */
+/* filtered sample of tile instant q (sub-phase taps mf[], 17th tap only for r == 0): d8psk.c:219-228 */
+template <int S> __device__ __forceinline__ v2f k2a_fir(const K2aShared &sh, int q, const float (&mf)[17], bool tap17)
+{
+	/* tap j multiplies sample (nbase + S*(q-PH)) - 16 + j = tile sample S*q + j */
+	const v2f *xe = reinterpret_cast<const v2f *>(&sh.xs[q]);
+	const v2f *xo = reinterpret_cast<const v2f *>(&sh.xs[K2A_XODD + q]);
+	v2f xv[17];
+#pragma unroll
+	for (int j = 0; j < 17; ++j)	/* every LDS read in flight before the first multiply */
+		xv[j] = (S == 2) ? ((j & 1) ? xo[j >> 1] : xe[j >> 1]) : xe[j];
+	v2f acc = {0.0f, 0.0f};
+#pragma unroll
+	for (int j = 0; j < 16; ++j)
+		acc += xv[j] * (v2f){mf[j], mf[j]};
+	if (tap17)
+		acc += xv[16] * (v2f){mf[16], mf[16]};
+	return acc;
+}
+
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
 					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail,
 					   K2aPre<S> &pre, long long next_nbase, int next_cnt, int skip_r = -1, int skip_par = 0)
@@ -1467,34 +1495,21 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	for (int r = 0; r < 4; ++r) {
 		if (!(rmask & (1u << r)))
 			continue;
-		/* ---- phases and unit phasors of instants -PH .. cnt-1 */
-		{
-			float mf[17];	/* wave-uniform: scalar registers */
+		float mf[17];	/* wave-uniform: scalar registers */
 #pragma unroll
-			for (int j = 0; j < 17; ++j)	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
-				mf[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.smf[r + 4 * j])));
-			const bool tap17 = (r == 0);
-			for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
-				/* tap j multiplies sample (nbase + S*(q-PH)) - 16 + j = tile sample S*q + j */
-				const v2f *xe = reinterpret_cast<const v2f *>(&sh.xs[q]);
-				const v2f *xo = reinterpret_cast<const v2f *>(&sh.xs[K2A_XODD + q]);
-				v2f acc = {0.0f, 0.0f};
-#pragma unroll
-				for (int j = 0; j < 16; ++j) {
-					const v2f xv = (S == 2) ? ((j & 1) ? xo[j >> 1] : xe[j >> 1]) : xe[j];
-					acc += xv * (v2f){mf[j], mf[j]};
-				}
-				if (tap17)
-					acc += ((S == 2) ? xe[8] : xe[16]) * (v2f){mf[16], mf[16]};
-				sh.ph[q] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
-				const float n2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-				v2f w = acc * __frsqrt_rn(n2);
-				if (!(n2 >= 1e-30f && n2 <= 1e30f)) {	/* atan2f(0, 0) = 0; anything else odd: screen it in */
-					const float bad = (acc.x == 0.0f && acc.y == 0.0f) ? 0.0f : __builtin_nanf("");
-					w = (v2f){1.0f + bad, bad};
-				}
-				sh.wu[q] = make_float2(w.x, w.y);
+		for (int j = 0; j < 17; ++j)	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
+			mf[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.smf[r + 4 * j])));
+		const bool tap17 = (r == 0);
+		/* ---- unit phasors of the filtered samples of instants -PH .. cnt-1 */
+		for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
+			const v2f acc = k2a_fir<S>(sh, q, mf, tap17);
+			const float n2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
+			v2f w = acc * __frsqrt_rn(n2);
+			if (!(n2 >= 1e-30f && n2 <= 1e30f)) {	/* atan2f(0, 0) = 0; anything else odd: let it through */
+				const float bad = (acc.x == 0.0f && acc.y == 0.0f) ? 0.0f : __builtin_nanf("");
+				w = (v2f){1.0f + bad, bad};
 			}
+			sh.wu[q] = make_float2(w.x, w.y);
 		}
 		K2A_STAMP(1);
 		__syncthreads();
@@ -1502,14 +1517,18 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		/* ---- in place: wu[q] <- wu[q] * conj(wu[q - LSTR]) */
 		{
 			v2f u[NQ];
+			float2 a[NQ], b[NQ];
+			const int qmax = cnt + PH - 1;
 #pragma unroll
-			for (int k = 0; k < NQ; ++k) {
-				const int q = tid + k * K2A_THREADS;
-				if (q >= LSTR && q < cnt + PH) {
-					const float2 a = sh.wu[q], b = sh.wu[q - LSTR];
-					u[k] = (v2f){__fmaf_rn(a.x, b.x, a.y * b.y), __fmaf_rn(a.y, b.x, -(a.x * b.y))};
-				}
+			for (int k = 0; k < NQ; ++k) {	/* clamped, unpredicated: all reads in flight together */
+				int q = tid + k * K2A_THREADS;
+				q = q < LSTR ? LSTR : (q > qmax ? qmax : q);
+				a[k] = sh.wu[q];
+				b[k] = sh.wu[q - LSTR];
 			}
+#pragma unroll
+			for (int k = 0; k < NQ; ++k)
+				u[k] = (v2f){__fmaf_rn(a[k].x, b[k].x, a[k].y * b[k].y), __fmaf_rn(a[k].y, b[k].x, -(a[k].x * b[k].y))};
 			__syncthreads();
 #pragma unroll
 			for (int k = 0; k < NQ; ++k) {
@@ -1525,9 +1544,9 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		for (int c0 = 0; c0 < cnt;) {
 			const int c1 = (c0 + piece < cnt) ? c0 + piece : cnt;
 			if (tid == 0)
-				sh.nwl = 0;
+				sh.nwl = sh.nwl2 = 0;
 			__syncthreads();
-			/* screen the evaluation that is the `perr` of instant i: j = i + E2 */
+			/* first screen, of the evaluation that is the `perr` of instant i: j = i + E2 */
 			for (int i = c0 + tid; i < c1; i += K2A_THREADS) {
 				const int j = i + E2;
 				const float2 *uq = &sh.wu[PH - E4 + j - 15 * LSTR];
@@ -1560,20 +1579,53 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				__syncthreads();	/* everyone has read nwl before it is reset */
 				continue;
 			}
-			/* exact fit of the screened-in evaluations and of their neighbours (p2err / err of the test) */
-			for (int k = tid; k < 3 * nwl; k += K2A_THREADS) {
-				const int slot = k / 3, w = k - 3 * slot;
-				float fr;
-				sh.we[w][slot] = k2_sync_metric<LSTR>(&sh.ph[PH - E4 + sh.wl[slot] + (w - 1) * E2 - 16 * LSTR], &fr);
-				if (w == 1)
-					sh.wf[slot] = fr;
+			/* second screen: lag-2 steps as products of neighbouring rotated lag-1 phasors */
+			for (int k = tid; k < nwl; k += K2A_THREADS) {
+				const int j = sh.wl[k];
+				const float2 *uq = &sh.wu[PH - E4 + j - 15 * LSTR];
+				v2f v[16];
+#pragma unroll
+				for (int l = 0; l < 16; ++l) {
+					const float2 u = uq[l * LSTR];
+					v[l] = k2_rot((v2f){0.0f, 0.0f}, (v2f){u.x, u.y}, rc[l], rs[l]);
+				}
+				v2f acc = {0.0f, 0.0f};
+#pragma unroll
+				for (int l = 0; l < 15; ++l)
+					acc = k2_rot(acc, v[l], v[l + 1].x, v[l + 1].y);
+				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
+				if (!(r2 <= VDL2_SCREEN_R22))
+					sh.wl2[atomicAdd(&sh.nwl2, 1)] = j;
+			}
+			__syncthreads();
+			const int nwl2 = sh.nwl2;
+			if (prof)
+				atomicAdd(p.dbg + 32 + 12, (unsigned long long)nwl2);
+			for (int b0 = 0; b0 < nwl2; b0 += K2A_WL2) {
+				const int nb = (nwl2 - b0 < K2A_WL2) ? nwl2 - b0 : K2A_WL2;
+				/* exact phases (d8psk.c:229) of the 3 x 17 instants each survivor's fits need */
+				for (int t = tid; t < 51 * nb; t += K2A_THREADS) {
+					const int slot = t / 51, rem = t - 51 * slot, w = rem / 17, l = rem - 17 * w;
+					const int q = PH - E4 + sh.wl2[b0 + slot] + (w - 1) * E2 - (16 - l) * LSTR;
+					const v2f acc = k2a_fir<S>(sh, q, mf, tap17);
+					sh.sph[slot][w][l] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
+				}
+				__syncthreads();
+				/* exact fits: p2err / perr / err of the detector test */
+				for (int k = tid; k < 3 * nb; k += K2A_THREADS) {
+					const int slot = k / 3, w = k - 3 * slot;
+					float fr;
+					sh.we[w][slot] = k2_sync_metric<1>(&sh.sph[slot][w][0], &fr);
+					if (w == 1)
+						sh.wf[slot] = fr;
+				}
+				__syncthreads();
+				for (int k = tid; k < nb; k += K2A_THREADS)
+					k2a_emit<S>(p, sc, dec_base, nbase, sh.wl2[b0 + k] - E2, r, mode, chk_lo, chk_hi, fail, skip_r, skip_par,
+						    sh.we[0][k], sh.we[1][k], sh.we[2][k], sh.wf[k], cntp, ovf, cl);
+				__syncthreads();
 			}
 			K2A_STAMP(6);
-			__syncthreads();
-			K2A_STAMP(7);
-			for (int k = tid; k < nwl; k += K2A_THREADS)
-				k2a_emit<S>(p, sc, dec_base, nbase, sh.wl[k] - E2, r, mode, chk_lo, chk_hi, fail, skip_r, skip_par,
-					    sh.we[0][k], sh.we[1][k], sh.we[2][k], sh.wf[k], cntp, ovf, cl);
 			c0 = c1;
 		}
 		K2A_STAMP(8);
