@@ -1310,7 +1310,8 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
-#define K2A_WL2 32		/* survivors of both screens whose exact phases fit in LDS at once */
+#define K2A_WL2 24		/* survivors of both screens whose exact phases fit in LDS at once */
+#define K2A_DEF 320		/* survivors collected before they are worked off; must hold one more tile pass (K2A_WL) */
 #ifndef K2A_WL
 #define K2A_WL 192		/* screened-in evaluations per tile and sub-phase; more than that and the tile is done in pieces */
 #endif
@@ -1323,6 +1324,12 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 				 * (the detector itself needs < 4): catches marginal events that only some
 				 * classes detect; what it still misses is caught by K2a-verify */
 
+struct K2aDef {			/* an evaluation that needs the exact fit */
+	int n;			/* its instant, stream-relative (samples) */
+	int r;			/* FIR sub-phase */
+	int lo, hi;		/* verify: only hits in [lo, hi) count */
+};
+
 struct K2aShared {
 	float2 xs[K2A_XMAX + 8];	/* S = 1: samples in order; S = 2: even samples, then (at K2A_XODD) odd samples, so that
 					 * both FIR tap parities are unit-stride across lanes */
@@ -1330,11 +1337,12 @@ struct K2aShared {
 					 * of the symbol-spaced phase step */
 	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45) */
 	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants (vdl2_math.h) */
-	int wl[K2A_WL];			/* evaluations the first screen lets through ... */
-	int wl2[K2A_WL];		/* ... and the second */
+	int wl[K2A_WL];			/* evaluations of the current tile the first screen lets through */
+	K2aDef dl[K2A_DEF];		/* survivors of both screens, collected over tiles until there are enough to
+					 * give every lane an exact phase to compute (k2a_flush) */
 	float sph[K2A_WL2][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
 	float we[3][K2A_WL2], wf[K2A_WL2];	/* their exact fit errors, and the slope at the middle one */
-	int nwl, nwl2;
+	int nwl, ndl;
 };
 #define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
 
@@ -1366,11 +1374,10 @@ __device__ __forceinline__ v2f k2_rot(v2f acc, v2f u, float cx, float cy)
 
 
 /* detector test of one instant (d8psk.c:292) and what a hit means in each scan mode */
-template <int S> __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long dec_base, long long nbase, int i, int r, int mode,
+__device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long dec_base, long long n, int r, int mode,
 						  long long chk_lo, long long chk_hi, int *fail, int skip_r, int skip_par,
 						  float p2err, float perr, float err, float pfr, unsigned *cntp, unsigned *ovf, Cand *cl)
 {
-	const long long n = nbase + (long long)S * i;
 	if (mode == 2 && perr < VDL2_SEED_ERR && err > perr) {
 		const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
 		if (kk < VDL2_CAND_CAP)	/* surplus seeds are simply dropped: K2a-verify covers what they would have */
@@ -1418,6 +1425,9 @@ __device__ __forceinline__ void k2a_tables(K2aShared &sh)
 		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
 	if (threadIdx.x < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
 		sh.atab[threadIdx.x] = vdl2_atan_tab_entry(threadIdx.x);
+	if (threadIdx.x == 0)
+		sh.ndl = 0;
+	__syncthreads();
 }
 
 template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const K2Params &p, int sc, long long dec_base, long long nbase, int cnt)
@@ -1437,6 +1447,62 @@ template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const
  * mode 2: probe (candidates + seeds).  One sub-phase per pass:
  *   FIR + unit phasor of every instant | phase-step phasors | first screen -> worklist |
  *   second screen of the worklist | exact phases of the survivors | exact fits | detector test. */
+/* Work off the collected survivors: exact phases (FIR from the channel plane in HBM/L2 -- the tile
+ * they came from has left LDS -- then atan2f, d8psk.c:219-229), exact fits (d8psk.c:257-289) of the
+ * evaluation and its two neighbours, detector test (d8psk.c:292).  Every lane has work: 51 phases
+ * per survivor. */
+__device__ void k2a_flush(K2aShared &sh, const K2Params &p, int sc, long long dec_base, int mode, int *fail, int skip_r, int skip_par)
+{
+	const int tid = threadIdx.x;
+	__syncthreads();
+	const int nd = sh.ndl;
+	const float2 *x0 = p.dec + (size_t)sc * p.cap;	/* x0[n] = sample at stream-relative time n */
+	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
+	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
+	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	for (int b0 = 0; b0 < nd; b0 += K2A_WL2) {
+		const int nb = (nd - b0 < K2A_WL2) ? nd - b0 : K2A_WL2;
+		for (int t = tid; t < 51 * nb; t += K2A_THREADS) {
+			const int slot = t / 51, rem = t - 51 * slot, w = rem / 17, l = rem - 17 * w;
+			const K2aDef d = sh.dl[b0 + slot];
+			const float2 *x = x0 + (d.n + (w - 1) * 2 - 8 * (16 - l) - 16);
+			float2 xv[17];
+#pragma unroll
+			for (int j = 0; j < 17; ++j)
+				xv[j] = x[j];
+			v2f acc = {0.0f, 0.0f};
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const float m = sh.smf[d.r + 4 * j];
+				acc += (v2f){xv[j].x, xv[j].y} * (v2f){m, m};
+			}
+			if (d.r == 0) {	/* mflt[r + 64] exists only for r == 0 */
+				const float m = sh.smf[64];
+				acc += (v2f){xv[16].x, xv[16].y} * (v2f){m, m};
+			}
+			sh.sph[slot][w][l] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
+		}
+		__syncthreads();
+		for (int k = tid; k < 3 * nb; k += K2A_THREADS) {
+			const int slot = k / 3, w = k - 3 * slot;
+			float fr;
+			sh.we[w][slot] = k2_sync_metric<1>(&sh.sph[slot][w][0], &fr);
+			if (w == 1)
+				sh.wf[slot] = fr;
+		}
+		__syncthreads();
+		for (int k = tid; k < nb; k += K2A_THREADS) {
+			const K2aDef d = sh.dl[b0 + k];
+			k2a_emit(p, sc, dec_base, dec_base + d.n + 2, d.r, mode, dec_base + d.lo, dec_base + d.hi, fail, skip_r, skip_par,
+				 sh.we[0][k], sh.we[1][k], sh.we[2][k], sh.wf[k], cntp, ovf, cl);
+		}
+		__syncthreads();
+	}
+	if (tid == 0)
+		sh.ndl = 0;
+	__syncthreads();
+}
+
 /* filtered sample of tile instant q (sub-phase taps mf[], 17th tap only for r == 0): d8psk.c:219-228 */
 template <int S> __device__ __forceinline__ v2f k2a_fir(const K2aShared &sh, int q, const float (&mf)[17], bool tap17)
 {
@@ -1488,9 +1554,6 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
 	__syncthreads();
 	K2A_STAMP(0);
-	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
-	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
-	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
 #pragma unroll 1
 	for (int r = 0; r < 4; ++r) {
 		if (!(rmask & (1u << r)))
@@ -1544,8 +1607,9 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		for (int c0 = 0; c0 < cnt;) {
 			const int c1 = (c0 + piece < cnt) ? c0 + piece : cnt;
 			if (tid == 0)
-				sh.nwl = sh.nwl2 = 0;
+				sh.nwl = 0;
 			__syncthreads();
+			const int ndl0 = sh.ndl;	/* nobody appends between this barrier and the next */
 			/* first screen, of the evaluation that is the `perr` of instant i: j = i + E2 */
 			for (int i = c0 + tid; i < c1; i += K2A_THREADS) {
 				const int j = i + E2;
@@ -1579,6 +1643,8 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				__syncthreads();	/* everyone has read nwl before it is reset */
 				continue;
 			}
+			if (ndl0 + nwl > K2A_DEF)	/* no room for this pass's survivors: work the list off first */
+				k2a_flush(sh, p, sc, dec_base, mode, fail, skip_r, skip_par);
 			/* second screen: lag-2 steps as products of neighbouring rotated lag-1 phasors */
 			for (int k = tid; k < nwl; k += K2A_THREADS) {
 				const int j = sh.wl[k];
@@ -1594,36 +1660,14 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				for (int l = 0; l < 15; ++l)
 					acc = k2_rot(acc, v[l], v[l + 1].x, v[l + 1].y);
 				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-				if (!(r2 <= VDL2_SCREEN_R22))
-					sh.wl2[atomicAdd(&sh.nwl2, 1)] = j;
-			}
-			__syncthreads();
-			const int nwl2 = sh.nwl2;
-			if (prof)
-				atomicAdd(p.dbg + 32 + 12, (unsigned long long)nwl2);
-			for (int b0 = 0; b0 < nwl2; b0 += K2A_WL2) {
-				const int nb = (nwl2 - b0 < K2A_WL2) ? nwl2 - b0 : K2A_WL2;
-				/* exact phases (d8psk.c:229) of the 3 x 17 instants each survivor's fits need */
-				for (int t = tid; t < 51 * nb; t += K2A_THREADS) {
-					const int slot = t / 51, rem = t - 51 * slot, w = rem / 17, l = rem - 17 * w;
-					const int q = PH - E4 + sh.wl2[b0 + slot] + (w - 1) * E2 - (16 - l) * LSTR;
-					const v2f acc = k2a_fir<S>(sh, q, mf, tap17);
-					sh.sph[slot][w][l] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
+				if (!(r2 <= VDL2_SCREEN_R22)) {
+					K2aDef d;
+					d.n = (int)(nbase - dec_base) + S * (j - E4);
+					d.r = r;
+					d.lo = (mode == 1) ? (int)(chk_lo - dec_base) : 0;
+					d.hi = (mode == 1) ? (int)(chk_hi - dec_base) : 0;
+					sh.dl[atomicAdd(&sh.ndl, 1)] = d;
 				}
-				__syncthreads();
-				/* exact fits: p2err / perr / err of the detector test */
-				for (int k = tid; k < 3 * nb; k += K2A_THREADS) {
-					const int slot = k / 3, w = k - 3 * slot;
-					float fr;
-					sh.we[w][slot] = k2_sync_metric<1>(&sh.sph[slot][w][0], &fr);
-					if (w == 1)
-						sh.wf[slot] = fr;
-				}
-				__syncthreads();
-				for (int k = tid; k < nb; k += K2A_THREADS)
-					k2a_emit<S>(p, sc, dec_base, nbase, sh.wl2[b0 + k] - E2, r, mode, chk_lo, chk_hi, fail, skip_r, skip_par,
-						    sh.we[0][k], sh.we[1][k], sh.we[2][k], sh.wf[k], cntp, ovf, cl);
-				__syncthreads();
 			}
 			K2A_STAMP(6);
 			c0 = c1;
@@ -1660,6 +1704,7 @@ void k2a_probe(K2Params p)
 			const int nt1 = n1 < avail_end ? (int)((avail_end - n1 < K2A_TS) ? (avail_end - n1) : K2A_TS) : 0;
 			k2a_tile<1>(sh, p, sc, dec_base, n0, nt, 0xfu, 0, 0, 0, nullptr, pre, n1, nt1);
 		}
+		k2a_flush(sh, p, sc, dec_base, 0, nullptr, -1, 0);
 		return;
 	}
 	/* the class the channel's detector is in right now: sub-phase r, parity of pos */
@@ -1675,6 +1720,7 @@ void k2a_probe(K2Params p)
 		const int nt1 = n1 < avail_end ? (int)(left1 < K2A_TS ? left1 : K2A_TS) : 0;
 		k2a_tile<2>(sh, p, sc, dec_base, n0, nt, rmask, 2, 0, 0, nullptr, pre, n1, nt1);
 	}
+	k2a_flush(sh, p, sc, dec_base, 2, nullptr, -1, 0);
 }
 
 /* ---- workgroup sort of up to VDL2_CAND_CAP 64-bit keys whose top bits are a time stamp.
@@ -1879,12 +1925,13 @@ void k2a_region(K2Params p)
 		const int2 rn = (k + gridDim.x < nreg) ? regs[k + gridDim.x] : make_int2(0, 0);
 		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu, 0, 0, 0, nullptr, pre, dec_base + rn.x, rn.y, skip_r, skip_par);
 	}
+	k2a_flush(sh, p, sc, dec_base, 0, nullptr, skip_r, skip_par);
 }
 
 /* one workgroup = K2A_VRUN tiles of 2*K2A_TS samples; every piece of a verify segment inside a tile
  * is scanned in the segment's class */
 #define K2A_VRUN 4
-#define K2A_VITEMS 96
+#define K2A_VITEMS 64
 __global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k2a_verify(K2Params p)
 {
@@ -1954,6 +2001,7 @@ void k2a_verify(K2Params p)
 		k2a_tile<2>(sh, p, sc, dec_base, dec_base + it.x, (it.y - it.x + 1) / 2, 1u << it.z, 1, dec_base + it.x, dec_base + it.y,
 			    p.fail + sc, pre, dec_base + nx.x, (nx.y - nx.x + 1) / 2);
 	}
+	k2a_flush(sh, p, sc, dec_base, 1, p.fail + sc, -1, 0);
 }
 
 /* ====================================================================== K2s
