@@ -2391,23 +2391,31 @@ void k2c_resolve(K2Params p)
 	}
 	__syncthreads();
 	const long long tk3 = wall_clock64();
-	/* 4. publish the visited clusters */
+	/* 4. publish the visited clusters: list positions come from LDS counters seeded with what the
+	 *    serial stretches and the walk already listed; the global counters are written once */
 	if (tid < 4)
 		s_cnt[tid] = 0;
+	if (tid == 0) {
+		s_walk[0] = (int)*nsel;
+		s_walk[1] = (int)*nseg;
+	}
 	__syncthreads();
 	{
 		int a = 0, b = 0, d = 0;
 		for (int j = tid; j < ncand; j += K2_NT)
 			if (ssel[j]) {
-				const Cluster *cl = clusters + sidx[j];
 				const int2 hd = shead[j];
 				const int ns = (hd.y >> 4) & 15;
-				for (int i = 0; i < ns; ++i) {
-					const unsigned q = atomicAdd(nsel, 1u);
-					if (q < VDL2_SEL_CAP)
-						sel[q] = (unsigned)cl->slots[i];
-					else
-						atomicAdd(p.outc + 1, 1u);
+				/* K2b's descriptors sit in static slots: (candidate index) * VDL2_CL_MAXB + burst */
+				const unsigned slot0 = (unsigned)(((size_t)sc * VDL2_CAND_CAP + sidx[j]) * VDL2_CL_MAXB);
+				if (ns) {
+					const unsigned q = (unsigned)atomicAdd(&s_walk[0], ns);
+					for (int i = 0; i < ns; ++i) {
+						if (q + i < VDL2_SEL_CAP)
+							sel[q + i] = slot0 + i;
+						else
+							atomicAdd(p.outc + 1, 1u);
+					}
 				}
 				a += (hd.y >> 8) & 255;
 				b += (hd.y >> 16) & 255;
@@ -2417,7 +2425,7 @@ void k2c_resolve(K2Params p)
 				if (lazy && sstat[j] == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe)) {
 					/* after this cluster the chain idles in class (r_s, parity of n_s) until
 					 * the successor's trigger (or the end of the data) */
-					const unsigned q = atomicAdd(nseg, 1u);
+					const unsigned q = (unsigned)atomicAdd(&s_walk[1], 1);
 					if (q < VDL2_SEG_CAP) {
 						Seg g;
 						g.lo = hd.x;
@@ -2435,6 +2443,11 @@ void k2c_resolve(K2Params p)
 			atomicAdd(&s_cnt[1], b);
 		if (d)
 			atomicAdd(&s_cnt[2], d);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		*nsel = (unsigned)s_walk[0];
+		*nseg = (unsigned)s_walk[1];
 	}
 	__syncthreads();
 	if (steady_end) {
