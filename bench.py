@@ -220,9 +220,11 @@ def main():
         k2c_ms = tm["resolve_ms"] / max(1, tm["pushes"])
         k3_ms = tm["other_ms"] / max(1, tm["pushes"])
         # dominant full-rate kernel: k1_fast (all whole 1 ms periods but the first and last of a push)
+        # (a push may split it into two launches that run beside different stretches of the previous push's
+        #  demodulator: bytes and time are per launch, averaged over all launches, like rocprof's average)
         fast_ms = tm["channelise_fast_ms"] / max(1, tm["fast_pushes"])
         fast_samples = (batch * 21 // 500 // 84 - 2) * 2000 * nstr
-        alg_bytes = float(fast_samples) * sample_bytes
+        alg_bytes = float(fast_samples) * sample_bytes * tm["pushes"] / max(1, tm["fast_pushes"])
         achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
         value = world * nstr * batch * args.steps / dt / 1e6
         # HBM traffic of the same kernel from the committed PMC passes of this very command

@@ -127,8 +127,8 @@ typedef struct {
 	double cluster_ms;	/* K2b burst clusters */
 	double resolve_ms;	/* K2c resolver + K2d gather */
 	double other_ms;	/* compaction / bookkeeping kernels */
-	double channelise_fast_ms;	/* the k1_fast launch alone (2 MS/s path), over fast_pushes pushes */
-	uint64_t fast_pushes;
+	double channelise_fast_ms;	/* the k1_fast launches alone (2 MS/s path): sum over fast_pushes launches */
+	uint64_t fast_pushes;	/* number of k1_fast launches (a push may split its channeliser into two) */
 	uint64_t pushes;
 	uint64_t samples;	/* input samples per stream covered by the sums */
 } vdl2gpu_timing_t;

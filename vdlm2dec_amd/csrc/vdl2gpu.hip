@@ -34,12 +34,13 @@ extern "C" void sincosf(float, float *, float *);
 	} while (0)
 
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
-#define NEVX 11	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain */
+#define NEVX 13	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain */
 struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
 	bool fast;
 	bool staged;
+	int fast_parts;		/* k1_fast launches of this push: e[11]..e[12] (if two) and e[8]..e[9] */
 };
 
 struct vdl2gpu {
@@ -89,6 +90,8 @@ struct vdl2gpu {
 	hipStream_t k1_stream = nullptr;	/* channeliser of push N+1 runs beside the demodulator of push N */
 	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
 	bool k2_rec[2] = {false, false};
+	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
+	double k1_split = 0.25;		/* share of the channeliser launched at k2_mid_a, the rest at k2_mid */
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
 	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted 0..4 from how often the serial fallback was needed */
@@ -256,6 +259,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	}
 	if (h->k2_mid)
 		(void)hipEventDestroy(h->k2_mid);
+	if (h->k2_mid_a)
+		(void)hipEventDestroy(h->k2_mid_a);
 	if (h->k1_stream)
 		(void)hipStreamDestroy(h->k1_stream);
 	(void)hipFree(h->d_ctl);
@@ -337,6 +342,9 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
 	}
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid, hipEventDisableTiming));
+	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid_a, hipEventDisableTiming));
+	if (getenv("VDL2GPU_K1_SPLIT"))
+		h->k1_split = atof(getenv("VDL2GPU_K1_SPLIT"));
 	h->ctl_words = CTL_CAND0 + 7 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
@@ -482,7 +490,12 @@ static int harvest_timing(vdl2gpu_t *h)
 			float f = 0;
 			HIPCHK(h, hipEventElapsedTime(&f, pt.e[8], pt.e[9]));
 			h->tm.channelise_fast_ms += f;
-			h->tm.fast_pushes++;
+			h->tm.fast_pushes++;	/* counts k1_fast launches */
+			if (pt.fast_parts > 1) {
+				HIPCHK(h, hipEventElapsedTime(&f, pt.e[11], pt.e[12]));
+				h->tm.channelise_fast_ms += f;
+				h->tm.fast_pushes++;
+			}
 		}
 		h->tm.pushes++;
 		h->tm.samples += pt.samples;
@@ -585,8 +598,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	hipStream_t ks = h->k1_stream;
 	if (h->k2_rec[par])
 		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_done[par], 0));
-	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* start beside the previous push's resolver, not beside its scan */
-		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
+	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* start beside the previous push's candidate sort, not beside its scan */
+		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid_a, 0));
 	HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
@@ -612,40 +625,56 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			/* whole 1 ms periods in the middle on the register-resident fast path; the first
 			 * period (carried partial window) and the tail on the general kernel */
 			k1.variant = getenv("VDL2GPU_K1_VARIANT") ? atoi(getenv("VDL2GPU_K1_VARIANT")) : 0;
-			k1.per_lo = 1;
-			k1.per_n = periods - 2;
 			generic(0, K1F_PER_OUT - 1);
 			pt.fast = true;
-			HIPCHK(h, hipEventRecord(pt.e[8], ks));
-			/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of
-			 * rounds of the GPU's wave slots (5 per SIMD at this kernel's register count) */
-			{
-				const double work = (double)k1.per_n * K1F_ROLES * h->S;
-				const double slots = (double)h->n_cu * 4 * 5;
-				double rounds = std::ceil(work / (slots * K1F_PB));
-				if (rounds < 1)
-					rounds = 1;
-				long long pb = (long long)std::ceil(work / (slots * rounds));
-				pb = std::max<long long>(8, std::min<long long>(pb, 64));
-				k1.per_pb = (int)pb;
-			}
-			const dim3 grid((unsigned)((k1.per_n + k1.per_pb - 1) / k1.per_pb) * K1F_ROLES, (unsigned)h->S);
-			switch (h->cfg.fmt) {
-			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-			case VDL2GPU_FMT_CS16:
-				switch (k1.variant) {	/* development ablations; 0 in production */
-				case 1: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 1>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case 2: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 2>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case 3: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 3>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case 4: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 4>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case 7: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 7>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				default: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 0>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+			auto launch_fast = [&](long long per_lo, long long per_n, hipEvent_t ev0, hipEvent_t ev1) {
+				k1.per_lo = per_lo;
+				k1.per_n = per_n;
+				(void)hipEventRecord(ev0, ks);
+				/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of
+				 * rounds of the GPU's wave slots (5 per SIMD at this kernel's register count) */
+				{
+					const double work = (double)k1.per_n * K1F_ROLES * h->S;
+					const double slots = (double)h->n_cu * 4 * 5;
+					double rounds = std::ceil(work / (slots * K1F_PB));
+					if (rounds < 1)
+						rounds = 1;
+					long long pb = (long long)std::ceil(work / (slots * rounds));
+					pb = std::max<long long>(8, std::min<long long>(pb, 64));
+					k1.per_pb = (int)pb;
 				}
-				break;
-			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				const dim3 grid((unsigned)((k1.per_n + k1.per_pb - 1) / k1.per_pb) * K1F_ROLES, (unsigned)h->S);
+				switch (h->cfg.fmt) {
+				case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				case VDL2GPU_FMT_CS16:
+					switch (k1.variant) {	/* development ablations; 0 in production */
+					case 1: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 1>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+					case 2: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 2>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+					case 3: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 3>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+					case 4: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 4>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+					case 7: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 7>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+					default: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 0>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
+					}
+					break;
+				case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+				}
+				(void)hipEventRecord(ev1, ks);
+			};
+			/* Two launches, placed beside the two stretches of the previous push's demodulator chain
+			 * that run one workgroup per channel (candidate sort; resolver) and leave the GPU idle */
+			const long long per_all = periods - 2;
+			long long per_a = (long long)((double)per_all * h->k1_split);
+			per_a = (h->k2_mid_rec && per_all >= 64) ? std::min(per_a, per_all - 1) : 0;
+			pt.fast_parts = 0;
+			if (per_a > 0) {
+				launch_fast(1, per_a, pt.e[11], pt.e[12]);
+				pt.fast_parts++;
 			}
-			HIPCHK(h, hipEventRecord(pt.e[9], ks));
+			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* the rest beside the previous push's resolver */
+				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
+			launch_fast(1 + per_a, per_all - per_a, pt.e[8], pt.e[9]);
+			pt.fast_parts++;
 			generic((periods - 1) * K1F_PER_OUT, J);
 		} else
 			generic(0, J);
@@ -714,6 +743,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipEventRecord(h->k2_mid_a, h->stream));
 		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
