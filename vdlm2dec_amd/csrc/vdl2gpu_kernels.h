@@ -1353,11 +1353,12 @@ struct K2aShared {
  *      sum_l (D_l - mean D)^2 <= sum_l (e_l - e_(l-1))^2 <= 4 * err,
  * and with R = |sum_l exp(j D_l)| >= sum_l cos(D_l - mean D) >= 16 - sum_l (D_l - mean D)^2 / 2:
  *      err >= (16 - R) / 2.
- * The same argument on the 15 lag-2 steps Pr[l+2] - Pr[l] gives err >= (15 - R2) / 2.
+ * The same argument on the 15 lag-2 steps Pr[l+2] - Pr[l] gives err >= (15 - R2) / 2, and on the
+ * 14 lag-3 steps err >= (14 - R3) / 2.
  * Neither needs the unwrap or even a phase: exp(j D_l) = c_l * u_l with u = w * conj(w') the unit
  * phasor of two symbol-spaced FIR outputs and c_l the template step (an odd multiple of pi/8), and
- * the lag-2 phasors are products of neighbouring lag-1 ones.  An evaluation with R <= 7.5 or
- * R2 <= 6.5 has err >= 4.25 > 4 (the rounding in R, R2 is < 1e-4), so it can neither be the minimum
+ * the lag-2 and lag-3 phasors are products of neighbouring lag-1 ones.  An evaluation with R <= 7.5,
+ * R2 <= 6.5 or R3 <= 5.5 has err >= 4.25 > 4 (the rounding in R, R2 is < 1e-4), so it can neither be the minimum
  * the detector fires after nor matter to it.  Every evaluation gets the first screen (32 packed
  * FMAs, passes ~2 % of noise), its survivors the second (passes ~6 % of those), and only what
  * survives both -- sync words, and about one noise evaluation in a thousand -- gets atan2f, the
@@ -1365,6 +1366,7 @@ struct K2aShared {
  * surviving. */
 #define VDL2_SCREEN_R2 56.25f	/* R^2: (16 - 7.5) / 2 = 4.25 */
 #define VDL2_SCREEN_R22 42.25f	/* R2^2: (15 - 6.5) / 2 = 4.25 */
+#define VDL2_SCREEN_R32 30.25f	/* R3^2: (14 - 5.5) / 2 = 4.25 */
 __device__ __forceinline__ v2f k2_rot(v2f acc, v2f u, float cx, float cy)
 {
 	/* acc += (cx + j cy) * u */
@@ -1655,12 +1657,17 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 					const float2 u = uq[l * LSTR];
 					v[l] = k2_rot((v2f){0.0f, 0.0f}, (v2f){u.x, u.y}, rc[l], rs[l]);
 				}
-				v2f acc = {0.0f, 0.0f};
+				v2f acc = {0.0f, 0.0f}, acc3 = {0.0f, 0.0f};
 #pragma unroll
-				for (int l = 0; l < 15; ++l)
-					acc = k2_rot(acc, v[l], v[l + 1].x, v[l + 1].y);
+				for (int l = 0; l < 15; ++l) {
+					const v2f p2 = k2_rot((v2f){0.0f, 0.0f}, v[l], v[l + 1].x, v[l + 1].y);	/* lag-2 step l */
+					acc += p2;
+					if (l < 14)	/* third screen: lag-3 steps, 14 of them */
+						acc3 = k2_rot(acc3, p2, v[l + 2].x, v[l + 2].y);
+				}
 				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-				if (!(r2 <= VDL2_SCREEN_R22)) {
+				const float r3 = __fmaf_rn(acc3.x, acc3.x, acc3.y * acc3.y);
+				if (!(r2 <= VDL2_SCREEN_R22) && !(r3 <= VDL2_SCREEN_R32)) {
 					K2aDef d;
 					d.n = (int)(nbase - dec_base) + S * (j - E4);
 					d.r = r;
