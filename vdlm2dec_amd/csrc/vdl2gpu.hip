@@ -95,7 +95,7 @@ struct vdl2gpu {
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
 	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted 0..4 from how often the serial fallback was needed */
-	unsigned redos_seen = 0;
+	unsigned redos_seen = 0, repairs_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
 	uint64_t total_in = 0;		/* samples per stream pushed so far */
@@ -766,6 +766,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			K2Params k2r = k2;
 			for (int rr = 1; rr <= h->repair_rounds; ++rr) {
 				k2r.round = rr;
+				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2a_region, dim3(32, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2b_clusters, dim3(256, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
@@ -842,16 +844,21 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
 	{
-		/* more repair rounds while pushes keep falling back to the serial machine, fewer when quiet */
-		const unsigned redos = h->h_pin_cnt[4 * ring + 2];
+		/* repair rounds only cost launches while nothing fails, so: none until the first verify
+		 * failure shows up (as a serial redo), then as many as it takes to get rid of the serial
+		 * redos, and back down one at a time after long quiet stretches */
+		const unsigned redos = h->h_pin_cnt[4 * ring + 2], repairs = h->h_pin_cnt[4 * ring + 3];
 		if (redos != h->redos_seen) {
 			h->redos_seen = redos;
 			h->last_redo_push = h->ring_push[ring];
-			h->repair_rounds = std::min(4, std::max(1, h->repair_rounds * 2));
-		} else if (h->repair_rounds > 0 && h->ring_push[ring] > h->last_redo_push + 8) {
+			h->repair_rounds = std::min(4, h->repair_rounds + 1);
+		} else if (repairs != h->repairs_seen) {
+			h->last_redo_push = h->ring_push[ring];	/* the rounds are earning their keep */
+		} else if (h->repair_rounds > 0 && h->ring_push[ring] > h->last_redo_push + 256) {
 			h->repair_rounds--;
 			h->last_redo_push = h->ring_push[ring];
 		}
+		h->repairs_seen = repairs;
 	}
 	if (n) {
 		if (h->ready_pos == h->ready_idx.size()) {	/* everything handed out: recycle storage */

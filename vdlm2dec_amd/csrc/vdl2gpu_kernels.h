@@ -1393,9 +1393,14 @@ __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long de
 	} else {
 		if (n < chk_lo || n >= chk_hi)
 			return;
-		/* a detector hit the tables did not list: remember where, and list it so that the
-		 * repair round resolves the chain with it */
+		/* a detector hit the tables did not list: remember where, and make it a seed so that the
+		 * repair round scans its neighbourhood in every class (that finds this hit again, and
+		 * whatever else the detector does around it) */
 		atomicMin(fail, (int)(n - dec_base));
+		const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
+		if (kk < VDL2_CAND_CAP)
+			p.seeds[(size_t)sc * VDL2_CAND_CAP + kk] = (int)(n - dec_base);
+		return;
 	}
 	const unsigned kk = atomicAdd(cntp, 1u);
 	if (kk < VDL2_CAND_CAP) {
@@ -1862,6 +1867,8 @@ void k2r_regions(K2Params p)
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan)
 		return;
+	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
+		return;		/* repair round: only channels whose verify pass found something */
 	int ncand = (int)p.ctl[CTL_NSEED0 + sc];
 	ncand = ncand > VDL2_CAND_CAP ? VDL2_CAND_CAP : ncand;
 	const int *seeds = p.seeds + (size_t)sc * VDL2_CAND_CAP;
@@ -1906,6 +1913,7 @@ void k2r_regions(K2Params p)
 		if (tid == 0) {
 			const int n = s_nreg;
 			p.ctl[CTL_NREG0 + sc] = (unsigned)(n > VDL2_REG_CAP ? VDL2_REG_CAP : n);
+			p.ctl[CTL_NSEED0 + sc] = 0;	/* the seed list now collects what K2a-verify finds */
 			if (n > VDL2_REG_CAP)
 				p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 1u;	/* tables unusable -> serial */
 		}
@@ -1918,7 +1926,9 @@ void k2a_region(K2Params p)
 	__shared__ K2aShared sh;
 	const int c = blockIdx.y, s = blockIdx.z;
 	const int sc = s * VDL2_CS + c;
-	if (p.force_serial || p.full_scan || p.test_noregion)
+	if (p.force_serial || p.full_scan || (p.test_noregion && p.round == 0))
+		return;
+	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
 		return;
 	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
 	const long long dec_base = p.ss[s].dec_base;
@@ -2245,8 +2255,9 @@ void k2c_resolve(K2Params p)
 		__syncthreads();
 		if (tid == 0) {
 			p.redo[sc] = 1;
+			atomicAdd(p.outc_total_redo + 1, 1u);	/* channel-pushes that went through a repair round */
 			if (p.dbg)
-				atomicAdd(p.dbg + 24, 1ull);	/* diagnostics: channel-pushes that went through a repair round */
+				atomicAdd(p.dbg + 24, 1ull);
 			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
 			p.ctl[CTL_NSEL0 + sc] = 0;
 			p.ctl[CTL_NSEG0 + sc] = 0;
@@ -2629,6 +2640,7 @@ __global__ void k3_rebase(K3Params p)
 		p.host_cnt[0] = p.outc[2 * p.ring];
 		p.host_cnt[1] = p.outc[2 * p.ring + 1];
 		p.host_cnt[2] = p.outc[4];
+		p.host_cnt[3] = p.outc[5];
 	}
 	StreamState *ss = p.ss + s;
 	long long mn = 0x7fffffffffffffffLL;
