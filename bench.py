@@ -190,8 +190,16 @@ def main():
     rx.sync()
     fence()
     dt = time.perf_counter() - t0
-    tm = rx.timing()
+    tm = rx.timing(reset=True)
     st = rx.stats()
+    # outside the timed region: the same hand-off a few times with nothing else on the GPU (each push
+    # finished before the next starts), to tell what the channeliser does alone from what it does
+    # while it shares the GPU with the previous push's demodulator (the timed region above)
+    for _ in range(4):
+        rx.push_device(dbatch.data_ptr(), batch, stride_bytes)
+        rx.sync()
+        drain(None, ready_only=False)
+    tm_iso = rx.timing(reset=True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -252,7 +260,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_fast", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
-                         "note": "algorithmic bytes = 4 B per cs16 input sample, read once for all 8 channels; the "
+                         "alone": (lambda ms, by: {"avg_launch_ms": ms, "achieved": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                                                   "frac": (by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0,
+                                                   "how": "4 pushes after the timed region, each synchronised before the next: "
+                                                          "no other kernel on the GPU"})(
+                             tm_iso["channelise_fast_ms"] / max(1, tm_iso["fast_pushes"]),
+                             float(fast_samples) * sample_bytes * tm_iso["pushes"] / max(1, tm_iso["fast_pushes"])),
+                         "note": "live: HIP events around the k1_fast launches inside the timed region, where they run beside the "
+                                 "previous push's demodulator kernels on a second stream (two launches per push); "
+                                 "algorithmic bytes = 4 B per cs16 input sample, read once for all 8 channels; the "
                                  "kernel also writes the 84 kS/s planes (2.7 B per input sample), which is "
                                  "intermediate traffic, not algorithmic (SURVEY.md 8d)"},
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
