@@ -167,6 +167,30 @@ const char *vdl2gpu_strerror(int code);
  * `msgblk` must point at sizeof(msgblk_t) zeroed bytes (calloc, as vdlm2.c:201). */
 int vdl2gpu_burst_to_msgblk(const vdl2gpu_burst_t *b, void *msgblk, size_t msgblk_size);
 
+/* ---- block path: what the reference's blk_thread does with a msgblk_t ----
+ * vdlm2.c:84-161 -- RS(255,249) of every row (rs.c), HDLC bit un-stuffing, flag hunt, check_frame()
+ * (length >= 13, FCS-16 of crc.c) -- for a whole batch of bursts in one kernel.  One record per
+ * frame the reference would pass to out(msgblk_t*, unsigned char *hdata, int l) (vdlm2.h:134):
+ * data[0..len) is hdata, the other fields are the msgblk_t's.  Frames come out ordered by
+ * (block, seq).  At the rates this library demodulates at, the reference's single blk_thread is
+ * the bottleneck; a shim can call this instead of decodeVdlm2() and go to out(). */
+#define VDL2GPU_MAXFRAME 2000
+typedef struct {
+	int32_t stream, chn, Fr;	/* of the burst the frame came in */
+	int32_t nbrow, nlbyte;
+	int32_t len;			/* l of out(): opening flag .. closing flag */
+	int32_t block;			/* index of the burst in the batch */
+	int32_t seq;			/* 0 for the burst's first frame, ... */
+	float df, ppm;
+	int64_t trig_dec, end_dec;
+	uint8_t data[VDL2GPU_MAXFRAME];	/* hdata[0..len) */
+} vdl2gpu_frame_t;
+/* Decode `n` bursts (host array, e.g. straight from vdl2gpu_poll) into CRC-clean frames.
+ * Returns the number of frames (<= max_frames; more are dropped and counted in *dropped if given)
+ * or a negative error. */
+int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks, int n,
+			  vdl2gpu_frame_t *frames, int max_frames, int *dropped);
+
 /* d8psk.c:39-52; the host path keeps calling it (out.c:429-432, outxid.c:122). */
 unsigned int reversebits(const unsigned int bits, const int n);
 

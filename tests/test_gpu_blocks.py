@@ -1,0 +1,91 @@
+"""Block path on the GPU: vdl2gpu_decode_blocks == the reference's blk_thread
+(vdlm2.c:84-161, rs.c, crc.c) as restated by the oracle, frame for frame, byte for byte."""
+import json
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import scenarios as S
+from vdlm2dec_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rx():
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    return Receiver(2_000_000, plan_channels(S.FC, [-50000]), fmt="cu8", max_push=4096)
+
+
+def _want(oracle, blocks):
+    out = []
+    for i, (nbrow, nlbyte, data) in enumerate(blocks):
+        out += [(i, f) for f in oracle.frames_of_block(nbrow, nlbyte, data)]
+    return out
+
+
+def test_golden_blocks_give_the_reference_frames(built, oracle):
+    """msgblk_t records of the real reference (tests/golden) -> the frames its own out() received."""
+    blocks, frames = [], []
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.json"))):
+        meta = json.load(open(path))
+        for c in meta["channels"]:
+            for b in c["blocks"]:
+                blocks.append((b["nbrow"], b["nlbyte"], bytes.fromhex(b["data"])))
+            frames += c["frames"]
+    with _rx() as rx:
+        got = rx.decode_blocks(blocks)
+    assert [f.hex() for _, f in got] == frames and len(frames) >= 20
+    assert got == _want(oracle, blocks)
+
+
+def _tx_block(rng, info_len, nerr_rows=()):
+    """One transmitted burst as the demodulator would hand it over, optionally with byte errors."""
+    info = bytes(rng.integers(0, 256, info_len, dtype=np.uint8).tolist())
+    nbrow, nlbyte, data = synth.received_rows(synth.hdlc_payload(synth.avlc_frame(info)))
+    data = bytearray(data)
+    for r, nerr in nerr_rows:
+        if r < nbrow:
+            span = 249 if r < nbrow - 1 else max(nerr, nlbyte)
+            for pos in rng.choice(span, size=nerr, replace=False):
+                data[r * 255 + int(pos)] ^= int(rng.integers(1, 256))
+    return nbrow, nlbyte, bytes(data)
+
+
+def test_corrected_uncorrectable_and_random_rows(built, oracle):
+    """Everything rs() can meet: clean rows, 1..3 byte errors (corrected), 4+ (miscorrected or given
+    up half way -- the partially applied corrections must agree too), every FEC-shortening regime,
+    and rows of pure noise."""
+    rng = np.random.default_rng(77)
+    blocks = []
+    for n in (1, 2, 3, 10, 28, 31, 60, 66, 70, 120, 247, 250, 400, 497, 900, 1500, 1900):
+        blocks.append(_tx_block(rng, n))
+        for nerr in (1, 2, 3, 4, 5, 7):
+            blocks.append(_tx_block(rng, n, [(0, nerr)]))
+            blocks.append(_tx_block(rng, n, [(r, nerr) for r in range(8)]))
+    for _ in range(200):
+        nbrow = int(rng.integers(1, 9))
+        blocks.append((nbrow, int(rng.integers(0, 250)), bytes(rng.integers(0, 256, 8 * 255, dtype=np.uint8).tolist())))
+    for fill in (0x00, 0xff, 0x7e, 0x3f, 0xfc):       # degenerate streams: all stuffing / all flags
+        blocks.append((8, 249, bytes([fill]) * (8 * 255)))
+    want = _want(oracle, blocks)
+    with _rx() as rx:
+        got = rx.decode_blocks(blocks)
+    assert got == want
+    assert len(want) >= 80
+
+
+def test_decoded_stream_to_frames_end_to_end(built, oracle):
+    """IQ -> bursts (demodulator kernels) -> frames (block kernel), all on the GPU, against
+    IQ -> oracle demodulator -> oracle block path."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = S.eight_channels(seed=340)
+    raw = synth.synth_stream(spec, "cs16")
+    ob = sorted(oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC), key=lambda b: (b.chn, b.end_dec))
+    want = [(b.chn, f) for b in ob for f in oracle.frames_of_block(b.nbrow, b.nlbyte, b.data)]
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 21) as rx:
+        bursts = sorted(rx.run(raw), key=lambda b: (b.chn, b.end_dec))
+        got = [(bursts[i].chn, f) for i, f in rx.decode_blocks(bursts)]
+    assert got == want and len(want) >= 8

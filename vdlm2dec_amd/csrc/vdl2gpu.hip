@@ -12,6 +12,7 @@
  *         vdl2gpu.hip -o libvdl2gpu.so
  */
 #include "vdl2gpu_kernels.h"
+#include "vdl2gpu_blocks.h"
 
 #include <algorithm>
 #include <cmath>
@@ -920,6 +921,68 @@ static int hand_out(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 		out[i] = h->ready[h->ready_idx[h->ready_pos + i]];
 	h->ready_pos += (size_t)n;
 	return n;
+}
+
+/* ---------------------------------------------------------------- block path */
+extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks, int n,
+				     vdl2gpu_frame_t *frames, int max_frames, int *dropped)
+{
+	if (!h || n < 0 || max_frames < 0 || (n > 0 && !blocks) || (max_frames > 0 && !frames))
+		return VDL2GPU_EINVAL;
+	if (dropped)
+		*dropped = 0;
+	if (n == 0 || max_frames == 0)
+		return 0;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	vdl2gpu_burst_t *d_blk = nullptr;
+	vdl2gpu_frame_t *d_fr = nullptr;
+	unsigned *d_cnt = nullptr;
+	auto cleanup = [&]() {
+		(void)hipFree(d_blk);
+		(void)hipFree(d_fr);
+		(void)hipFree(d_cnt);
+	};
+	hipError_t e = hipMalloc(&d_blk, (size_t)n * sizeof(vdl2gpu_burst_t));
+	if (e == hipSuccess)
+		e = hipMalloc(&d_fr, (size_t)max_frames * sizeof(vdl2gpu_frame_t));
+	if (e == hipSuccess)
+		e = hipMalloc(&d_cnt, 2 * sizeof(unsigned));
+	if (e == hipSuccess)
+		e = hipMemcpy(d_blk, blocks, (size_t)n * sizeof(vdl2gpu_burst_t), hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+		e = hipMemset(d_cnt, 0, 2 * sizeof(unsigned));
+	unsigned cnt[2] = {0, 0};
+	if (e == hipSuccess) {
+		K4Params k4{};
+		k4.recs = d_blk;
+		k4.nrecs_dev = nullptr;
+		k4.nrecs = (unsigned)n;
+		k4.rec_cap = (unsigned)n;
+		k4.frames = d_fr;
+		k4.nframes = d_cnt;
+		k4.frame_cap = (unsigned)max_frames;
+		const unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
+		hipLaunchKernelGGL(k4_frames, dim3(grid), dim3(K4_NT), 0, h->copy_stream, k4);
+		e = hipGetLastError();
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(h->copy_stream);
+	}
+	if (e == hipSuccess)
+		e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+	const int nf = (int)std::min<unsigned>(cnt[0], (unsigned)max_frames);
+	if (e == hipSuccess && nf > 0)
+		e = hipMemcpy(frames, d_fr, (size_t)nf * sizeof(vdl2gpu_frame_t), hipMemcpyDeviceToHost);
+	cleanup();
+	if (e != hipSuccess) {
+		h->err = std::string("vdl2gpu_decode_blocks: ") + hipGetErrorString(e);
+		return VDL2GPU_EHIP;
+	}
+	if (dropped)
+		*dropped = (int)cnt[1];
+	std::sort(frames, frames + nf, [](const vdl2gpu_frame_t &a, const vdl2gpu_frame_t &b) {
+		return a.block != b.block ? a.block < b.block : a.seq < b.seq;
+	});
+	return nf;
 }
 
 extern "C" int vdl2gpu_pending(vdl2gpu_t *h)

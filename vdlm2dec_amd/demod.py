@@ -152,6 +152,28 @@ class Receiver:
             out += self.poll()
         return out
 
+    # ------------------------------------------------------------------ block path
+    def decode_blocks(self, blocks: Sequence, max_frames: int = 0) -> List[Tuple[int, bytes]]:
+        """blk_thread for a batch (vdlm2.c:84-161): (index of the block, hdata) of every frame the
+        reference would pass to out().  ``blocks``: Burst objects or (nbrow, nlbyte, data) tuples."""
+        n = len(blocks)
+        if n == 0:
+            return []
+        arr = (_lib.BurstT * n)()
+        for i, b in enumerate(blocks):
+            nbrow, nlbyte, data = (b.nbrow, b.nlbyte, b.data) if hasattr(b, "nbrow") else b
+            arr[i].nbrow, arr[i].nlbyte = nbrow, nlbyte
+            C.memmove(C.addressof(arr[i].data), bytes(data), min(len(data), 8 * 255))
+            if hasattr(b, "chn"):
+                arr[i].stream, arr[i].chn, arr[i].Fr = b.stream, b.chn, b.Fr
+        cap = max_frames or 4 * n
+        out = (_lib.FrameT * cap)()
+        dropped = C.c_int(0)
+        nf = self._check(self.L.vdl2gpu_decode_blocks(self.h, arr, n, out, cap, C.byref(dropped)))
+        if dropped.value:
+            raise _lib.Vdl2GpuError(f"{dropped.value} frames dropped: raise max_frames")
+        return [(out[i].block, bytes(out[i].data[:out[i].len])) for i in range(nf)]
+
     # ------------------------------------------------------------------ bookkeeping
     def stats(self) -> dict:
         st = _lib.StatsT()

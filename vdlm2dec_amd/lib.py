@@ -24,7 +24,7 @@ F_TEST_NOREGION = 8
 EXPORTS = (
     "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
     "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
-    "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
+    "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "vdl2gpu_decode_blocks", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
     "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs",
 )
 
@@ -45,6 +45,13 @@ class BurstT(C.Structure):
                 ("nlbyte", C.c_int32), ("df", C.c_float), ("ppm", C.c_float),
                 ("trig_dec", C.c_int64), ("end_dec", C.c_int64), ("trig_sample", C.c_int64),
                 ("end_sample", C.c_int64), ("data", (C.c_uint8 * 255) * 8)]
+
+
+class FrameT(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("chn", C.c_int32), ("Fr", C.c_int32), ("nbrow", C.c_int32),
+                ("nlbyte", C.c_int32), ("len", C.c_int32), ("block", C.c_int32), ("seq", C.c_int32),
+                ("df", C.c_float), ("ppm", C.c_float), ("trig_dec", C.c_int64), ("end_dec", C.c_int64),
+                ("data", C.c_uint8 * 2000)]
 
 
 class StatsT(C.Structure):
@@ -109,6 +116,9 @@ def load():
     L.vdl2gpu_strerror.argtypes = [C.c_int]
     L.vdl2gpu_burst_to_msgblk.restype = C.c_int
     L.vdl2gpu_burst_to_msgblk.argtypes = [C.POINTER(BurstT), C.c_void_p, C.c_size_t]
+    L.vdl2gpu_decode_blocks.restype = C.c_int
+    L.vdl2gpu_decode_blocks.argtypes = [C.c_void_p, C.POINTER(BurstT), C.c_int, C.POINTER(FrameT), C.c_int,
+                                        C.POINTER(C.c_int)]
     L.reversebits.restype = C.c_uint
     L.reversebits.argtypes = [C.c_uint, C.c_int]
     L.vdl2gpu_lo_table.restype = C.c_int

@@ -234,6 +234,25 @@ def burst_bits(payload: bytes, corrupt: Optional[dict] = None) -> np.ndarray:
     return bits
 
 
+def received_rows(payload: bytes):
+    """(nbrow, nlbyte, data[8*255]) of the msgblk_t an error-free receiver builds from burst_bits(payload)
+    (d8psk.c:117-206): bytes that are not transmitted -- the tail of the last row and the FEC bytes the
+    shortening drops -- stay zero."""
+    length_bits = 8 * len(payload)
+    nbrow, nlbyte, rows_fec, nfec_last = fec_layout(length_bits)
+    rows = np.zeros((8, 255), dtype=np.uint8)
+    flat = np.frombuffer(payload, dtype=np.uint8)
+    for r in range(nbrow):
+        chunk = flat[r * ROW_DATA:(r + 1) * ROW_DATA]
+        rows[r, :len(chunk)] = chunk
+        par = rs_parity(rows[r, :ROW_DATA].tolist())
+        if r < nbrow - 1:
+            rows[r, ROW_DATA:] = par
+        elif rows_fec == nbrow:
+            rows[r, ROW_DATA:ROW_DATA + nfec_last] = par[:nfec_last]
+    return nbrow, nlbyte, rows.tobytes()
+
+
 def burst_increments(bits: np.ndarray, n_ramp: int = 4) -> np.ndarray:
     """Phase increments (x pi/4) for ramp + reference + unique word + data symbols."""
     pad = (-len(bits)) % 3
