@@ -18,6 +18,12 @@
  * is copied into that channel's `ch->blk` and handed to the unchanged decodeVdlm2()
  * (vdlm2.c:189), so RS / HDLC / CRC / ACARS / output run exactly as before.
  *
+ * With -DVDL2GPU_FRAMES the block path runs on the GPU as well (vdl2gpu_decode_blocks: RS, HDLC
+ * un-stuffing, FCS for a whole batch of bursts in one kernel) and the shim goes straight to
+ * out(msgblk_t*, unsigned char *hdata, int l) (vdlm2.h:134, called by check_frame, vdlm2.c:60):
+ * then vdlm2.c, rs.c and crc.c drop out of the build too.  At the rates the GPU front end
+ * demodulates at, the reference's single blk_thread cannot keep up.
+ *
  * This file contains no DSP.  It is compiled against the reference's own vdlm2.h.
  */
 #include <stdio.h>
@@ -38,6 +44,30 @@ int initD8psk(channel_t *ch)
 	return 0;		/* all detector state lives on the GPU */
 }
 
+#ifdef VDL2GPU_FRAMES
+static void deliver(vdl2gpu_t *h)
+{
+	static vdl2gpu_burst_t b[64];
+	static vdl2gpu_frame_t f[128];
+	static msgblk_t blk;	/* what out() reads of it: chn, Fr, tv, ppm, nbrow, nlbyte */
+	int n, nf, i;
+	while ((n = vdl2gpu_poll(h, b, 64)) > 0) {
+		nf = vdl2gpu_decode_blocks(h, b, n, f, 128, NULL);
+		for (i = 0; i < nf; i++) {
+			memset(&blk, 0, sizeof blk);
+			vdl2gpu_burst_to_msgblk(&b[f[i].block], &blk, sizeof blk);
+			gettimeofday(&blk.tv, NULL);
+			out(&blk, f[i].data, f[i].len);
+		}
+		if (nf < 0)
+			fprintf(stderr, "vdl2gpu_decode_blocks: %s\n", vdl2gpu_strerror(nf));
+		if (n < 64)
+			break;
+	}
+	if (n < 0)
+		fprintf(stderr, "vdl2gpu_poll: %s\n", vdl2gpu_strerror(n));
+}
+#else
 static void deliver(vdl2gpu_t *h)
 {
 	static vdl2gpu_burst_t b[64];
@@ -57,6 +87,8 @@ static void deliver(vdl2gpu_t *h)
 		fprintf(stderr, "vdl2gpu_poll: %s\n", vdl2gpu_strerror(n));
 }
 
+#endif
+
 void *rcv_thread(void *arg)
 {
 	thread_param_t *param = (thread_param_t *) arg;
@@ -68,7 +100,9 @@ void *rcv_thread(void *arg)
 	while (g_ready != param->chn)	/* initVdlm2 of channel 0 creates the block thread */
 		sched_yield();
 	initD8psk(ch);
-	initVdlm2(ch);
+#ifndef VDL2GPU_FRAMES
+	initVdlm2(ch);		/* block queue + blk_thread of the unchanged host path */
+#endif
 	__sync_fetch_and_add(&g_ready, 1);
 
 	if (param->chn == 0) {

@@ -112,6 +112,7 @@ void __wrap_viterbi_add(float V, int n)
 }
 #endif
 
+#ifndef VDL2GPU_FRAMES
 extern void __real_decodeVdlm2(channel_t * ch);
 void __wrap_decodeVdlm2(channel_t * ch)
 {
@@ -138,6 +139,7 @@ void __wrap_free(void *p)
 	__real_free(p);
 	__sync_fetch_and_add(&n_freed, 1);
 }
+#endif
 
 void out(msgblk_t * blk, unsigned char *hdata, int l)
 {
