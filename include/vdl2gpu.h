@@ -88,6 +88,7 @@ typedef struct {
 #define VDL2GPU_F_KEEP_DEC 1u	/* keep each push's decimated stream for vdl2gpu_debug_dec() */
 #define VDL2GPU_F_FULLSCAN 4u	/* scan all four FIR sub-phases everywhere instead of probe + regions + verify */
 #define VDL2GPU_F_TEST_NOREGION 8u	/* test hook: drop the region scan; the verify pass must then redo channels serially */
+#define VDL2GPU_F_FRAMES 16u	/* run the block path (RS, HDLC, FCS) on every push's bursts as well: vdl2gpu_poll_frames() */
 #define VDL2GPU_F_SERIAL 2u	/* diagnostics: skip the parallel sync tables, one serial machine per channel */
 
 /* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */
@@ -190,6 +191,11 @@ typedef struct {
  * or a negative error. */
 int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks, int n,
 			  vdl2gpu_frame_t *frames, int max_frames, int *dropped);
+/* With VDL2GPU_F_FRAMES the same kernel runs on every push's burst records where they lie in device
+ * memory, right behind the demodulator.  Collect the frames of everything pushed so far (waits like
+ * vdl2gpu_poll; the bursts themselves stay available through vdl2gpu_poll).  Frames come out ordered
+ * by (end_dec, stream, chn, seq); `block` is meaningless here.  Returns the count or a negative error. */
+int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max);
 
 /* d8psk.c:39-52; the host path keeps calling it (out.c:429-432, outxid.c:122). */
 unsigned int reversebits(const unsigned int bits, const int n);

@@ -89,3 +89,22 @@ def test_decoded_stream_to_frames_end_to_end(built, oracle):
         bursts = sorted(rx.run(raw), key=lambda b: (b.chn, b.end_dec))
         got = [(bursts[i].chn, f) for i, f in rx.decode_blocks(bursts)]
     assert got == want and len(want) >= 8
+
+
+def test_block_path_in_the_pipeline(built, oracle):
+    """frames=True: the block kernel runs on every push's records in device memory; frames arrive
+    through vdl2gpu_poll_frames, the bursts are still there for vdl2gpu_poll."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = S.eight_channels(seed=341)
+    raw = synth.synth_stream(spec, "cs16")
+    ob = sorted(oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC), key=lambda b: (b.end_dec, b.chn))
+    want = [(0, b.chn, f) for b in ob for f in oracle.frames_of_block(b.nbrow, b.nlbyte, b.data)]
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 19, frames=True) as rx:
+        bursts, frames = [], []
+        per = 4
+        for s0 in range(0, spec.nsamples, 1 << 19):
+            rx.push(raw[2 * s0:2 * (s0 + (1 << 19))])
+            frames += rx.poll_frames()
+            bursts += rx.poll()
+    assert sorted(frames) == sorted(want) and len(want) >= 8
+    assert sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in bursts) == sorted(b.key() for b in ob)

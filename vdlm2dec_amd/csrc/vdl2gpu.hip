@@ -108,8 +108,16 @@ struct vdl2gpu {
 	std::vector<vdl2gpu_burst_t> ready;	/* fetched, not yet handed out (storage order) */
 	std::vector<uint32_t> ready_idx;	/* hand-out order: indices into `ready`, consumed from ready_pos */
 	size_t ready_pos = 0;
+	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
+	bool frames_on = false;
+	vdl2gpu_frame_t *d_frames[2] = {nullptr, nullptr};
+	unsigned *d_fcnt = nullptr;	/* [2*ring] frames written, [2*ring+1] dropped */
+	unsigned frame_cap = 0;
+	std::vector<vdl2gpu_frame_t> fready;
+	size_t fready_pos = 0;
+	uint64_t frames_dropped = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
-	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [4*ring + {0,1,2}] */
+	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [8*ring + {0..5}] */
 	unsigned *d_pin_cnt = nullptr;	/* its device address */
 	unsigned pin_recs = 0;
 	std::string err;
@@ -246,6 +254,9 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_pn);
 	(void)hipFree(h->d_recs[0]);
 	(void)hipFree(h->d_recs[1]);
+	(void)hipFree(h->d_frames[0]);
+	(void)hipFree(h->d_frames[1]);
+	(void)hipFree(h->d_fcnt);
 	(void)hipFree(h->d_outc);
 	for (auto &e : h->ring_done)
 		if (e)
@@ -372,8 +383,16 @@ static int create_impl(vdl2gpu_t *h)
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 8 * sizeof(unsigned), hipHostMallocMapped));
-	memset(h->h_pin_cnt, 0, 8 * sizeof(unsigned));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 16 * sizeof(unsigned), hipHostMallocMapped));
+	memset(h->h_pin_cnt, 0, 16 * sizeof(unsigned));
+	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
+	if (h->frames_on) {
+		h->frame_cap = std::min<unsigned>(h->rec_cap, 16384u);
+		for (int r = 0; r < 2; ++r)
+			HIPCHK(h, hipMalloc(&h->d_frames[r], (size_t)h->frame_cap * sizeof(vdl2gpu_frame_t)));
+		HIPCHK(h, hipMalloc(&h->d_fcnt, 4 * sizeof(unsigned)));
+		HIPCHK(h, hipMemsetAsync(h->d_fcnt, 0, 4 * sizeof(unsigned), h->stream));
+	}
 	HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pin_cnt, h->h_pin_cnt, 0));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
@@ -781,6 +800,19 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
 		hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		if (h->frames_on) {
+			/* block path on the records where they lie (vdlm2.c:84-161) */
+			K4Params k4{};
+			k4.recs = h->d_recs[ring];
+			k4.nrecs_dev = h->d_outc + 2 * ring;
+			k4.rec_cap = h->rec_cap;
+			k4.frames = h->d_frames[ring];
+			k4.nframes = h->d_fcnt + 2 * ring;
+			k4.frame_cap = h->frame_cap;
+			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
+			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->stream, k4);
+			HIPCHK(h, hipGetLastError());
+		}
 	}
 	if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
@@ -794,7 +826,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k3.ss = h->d_ss;
 		k3.cs = h->d_cs;
 		k3.outc = h->d_outc;
-		k3.host_cnt = h->d_pin_cnt + 4 * ring;
+		k3.host_cnt = h->d_pin_cnt + 8 * ring;
+		k3.fcnt = h->frames_on ? h->d_fcnt + 2 * ring : nullptr;
 		k3.ring = ring;
 		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
@@ -841,14 +874,14 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		}
 	}
 	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
-	const unsigned c0 = h->h_pin_cnt[4 * ring], c1 = h->h_pin_cnt[4 * ring + 1];
+	const unsigned c0 = h->h_pin_cnt[8 * ring], c1 = h->h_pin_cnt[8 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
 	{
 		/* repair rounds only cost launches while nothing fails, so: none until the first verify
 		 * failure shows up (as a serial redo), then as many as it takes to get rid of the serial
 		 * redos, and back down one at a time after long quiet stretches */
-		const unsigned redos = h->h_pin_cnt[4 * ring + 2], repairs = h->h_pin_cnt[4 * ring + 3];
+		const unsigned redos = h->h_pin_cnt[8 * ring + 2], repairs = h->h_pin_cnt[8 * ring + 3];
 		if (redos != h->redos_seen) {
 			h->redos_seen = redos;
 			h->last_redo_push = h->ring_push[ring];
@@ -894,6 +927,40 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 				return a.stream < b.stream;
 			return a.chn < b.chn;
 		});
+	}
+	if (h->frames_on) {
+		const unsigned nf = std::min(h->h_pin_cnt[8 * ring + 4], h->frame_cap);
+		h->frames_dropped += h->h_pin_cnt[8 * ring + 5];
+		if (nf) {
+			if (h->fready_pos == h->fready.size()) {
+				h->fready.clear();
+				h->fready_pos = 0;
+			}
+			const size_t old = h->fready.size();
+			h->fready.resize(old + nf);
+			const unsigned per = (unsigned)(((size_t)h->pin_recs * sizeof(vdl2gpu_burst_t)) / sizeof(vdl2gpu_frame_t));
+			for (unsigned done = 0; done < nf; done += per) {
+				const unsigned m = std::min(per, nf - done);
+				HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_frames[ring] + done, (size_t)m * sizeof(vdl2gpu_frame_t),
+							 hipMemcpyDeviceToHost, h->copy_stream));
+				HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+				memcpy(h->fready.data() + old + done, h->h_pin, (size_t)m * sizeof(vdl2gpu_frame_t));
+			}
+			for (size_t i = old; i < h->fready.size(); ++i) {
+				vdl2gpu_frame_t &f = h->fready[i];
+				f.ppm = (float)((double)(10500.0f * f.df) / (2.0 * M_PI * (double)f.Fr) * 1e6);	/* d8psk.c:302 */
+				f.block = -1;
+			}
+			std::sort(h->fready.begin() + old, h->fready.end(), [](const vdl2gpu_frame_t &a, const vdl2gpu_frame_t &b) {
+				if (a.end_dec != b.end_dec)
+					return a.end_dec < b.end_dec;
+				if (a.stream != b.stream)
+					return a.stream < b.stream;
+				if (a.chn != b.chn)
+					return a.chn < b.chn;
+				return a.seq < b.seq;
+			});
+		}
 	}
 	h->ring_busy[ring] = false;
 	return 0;
@@ -983,6 +1050,25 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		return a.block != b.block ? a.block < b.block : a.seq < b.seq;
 	});
 	return nf;
+}
+
+extern "C" int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max)
+{
+	if (!h || (max > 0 && !out) || max < 0)
+		return VDL2GPU_EINVAL;
+	if (!h->frames_on) {
+		h->err = "vdl2gpu_poll_frames needs VDL2GPU_F_FRAMES";
+		return VDL2GPU_EINVAL;
+	}
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	int rc = harvest_all(h, true);
+	if (rc)
+		return rc;
+	const int n = std::min<int>(max, (int)(h->fready.size() - h->fready_pos));
+	for (int i = 0; i < n; ++i)
+		out[i] = h->fready[h->fready_pos + i];
+	h->fready_pos += (size_t)n;
+	return n;
 }
 
 extern "C" int vdl2gpu_pending(vdl2gpu_t *h)

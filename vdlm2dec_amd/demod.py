@@ -57,7 +57,8 @@ def plan_channels(fc: int, offsets: Sequence[int]) -> List[ThreadParam]:
 class Receiver:
     def __init__(self, sdrinrate: int, channels: Sequence[ThreadParam] | Sequence[Sequence[ThreadParam]],
                  fmt: str = "cu8", max_push: int = 1 << 22, device: int = 0, sdrclk: int = 0,
-                 max_bursts: int = 0, keep_dec: bool = False, serial: bool = False, full_scan: bool = False, flags: int = 0):
+                 max_bursts: int = 0, keep_dec: bool = False, serial: bool = False, full_scan: bool = False,
+                 frames: bool = False, flags: int = 0):
         self.L = _lib.load()
         if channels and isinstance(channels[0], ThreadParam):
             channels = [list(channels)]
@@ -83,7 +84,7 @@ class Receiver:
         cfg.max_push = max_push
         cfg.device = device
         cfg.max_bursts = max_bursts
-        cfg.flags = (_lib.F_KEEP_DEC if keep_dec else 0) | (_lib.F_SERIAL if serial else 0) | (_lib.F_FULLSCAN if full_scan else 0) | flags
+        cfg.flags = (_lib.F_KEEP_DEC if keep_dec else 0) | (_lib.F_SERIAL if serial else 0) | (_lib.F_FULLSCAN if full_scan else 0) | (_lib.F_FRAMES if frames else 0) | flags
         self.max_push = max_push
         self.h = C.c_void_p()
         rc = self.L.vdl2gpu_create(C.byref(cfg), C.byref(self.h))
@@ -173,6 +174,16 @@ class Receiver:
         if dropped.value:
             raise _lib.Vdl2GpuError(f"{dropped.value} frames dropped: raise max_frames")
         return [(out[i].block, bytes(out[i].data[:out[i].len])) for i in range(nf)]
+
+    def poll_frames(self, max_frames: int = 4096) -> List[Tuple[int, int, bytes]]:
+        """(stream, chn, hdata) of every frame of everything pushed so far (needs frames=True)."""
+        out = []
+        buf = (_lib.FrameT * max_frames)()
+        while True:
+            n = self._check(self.L.vdl2gpu_poll_frames(self.h, buf, max_frames))
+            out += [(buf[i].stream, buf[i].chn, bytes(buf[i].data[:buf[i].len])) for i in range(n)]
+            if n < max_frames:
+                return out
 
     # ------------------------------------------------------------------ bookkeeping
     def stats(self) -> dict:
