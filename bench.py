@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
     ap.add_argument("--rate", type=int, default=RATE, help="SDRINRATE (config 3: 10000000)")
     ap.add_argument("--streams", type=int, default=1, help="independent wideband streams per GPU (config 4: 8)")
+    ap.add_argument("--frames", action="store_true",
+                    help="also run the block path (RS, HDLC, FCS: SURVEY 8f-1) on every push's bursts and collect the frames")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -141,13 +143,16 @@ def main():
     sample_bytes = 4 if args.fmt == "cs16" else 2
     stride_bytes = dbatch.stride(0) * dbatch.element_size()
 
-    rx = Receiver(rate, [plan_channels(FC, fos)] * nstr, fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18)
+    rx = Receiver(rate, [plan_channels(FC, fos)] * nstr, fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18,
+                  frames=args.frames)
     first = []
     nbursts = 0
 
     from vdlm2dec_amd import lib as _lib
     from vdlm2dec_amd.demod import Burst
     rawbuf = (_lib.BurstT * 16384)()
+    framebuf = (_lib.FrameT * 4096)() if args.frames else None
+    nframes = [0]
 
     def drain(collect, ready_only):
         nonlocal nbursts
@@ -161,6 +166,14 @@ def main():
                                          b.end_dec, b.trig_sample, b.end_sample, bytes(b.data)))
             if n < 16384:
                 break
+        if args.frames:
+            while True:
+                m = (rx.L.vdl2gpu_poll_frames_ready if ready_only else rx.L.vdl2gpu_poll_frames)(rx.h, framebuf, 4096)
+                if m < 0:
+                    raise RuntimeError("vdl2gpu_poll_frames failed")
+                nframes[0] += m
+                if m < 4096:
+                    break
 
     def step(collect=None, pipelined=False):
         # one hand-off of resident samples + delivery of decoded msgblk records to the host.
@@ -278,8 +291,11 @@ def main():
                                            "candidates", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,
         }
+        if args.frames:
+            out["frames"] = {"collected": nframes[0], "note": "k4_frames ran on every push's records (VDL2GPU_F_FRAMES); "
+                             "frames are collected like the bursts: what is ready after every push, everything before the clock stops"}
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS"):
-            out["dbg"] = rx.debug_counters(48)
+            out["dbg"] = rx.debug_counters(64)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos, rate=rate)
         print(json.dumps(out))

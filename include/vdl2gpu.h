@@ -196,6 +196,8 @@ int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks, int n,
  * vdl2gpu_poll; the bursts themselves stay available through vdl2gpu_poll).  Frames come out ordered
  * by (end_dec, stream, chn, seq); `block` is meaningless here.  Returns the count or a negative error. */
 int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max);
+/* Same, but never waits (like vdl2gpu_poll_ready). */
+int vdl2gpu_poll_frames_ready(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max);
 
 /* d8psk.c:39-52; the host path keeps calling it (out.c:429-432, outxid.c:122). */
 unsigned int reversebits(const unsigned int bits, const int n);

@@ -113,7 +113,10 @@ struct vdl2gpu {
 	vdl2gpu_frame_t *d_frames[2] = {nullptr, nullptr};
 	unsigned *d_fcnt = nullptr;	/* [2*ring] frames written, [2*ring+1] dropped */
 	unsigned frame_cap = 0;
-	std::vector<vdl2gpu_frame_t> fready;
+	hipStream_t blk_stream = nullptr;	/* the block kernel runs beside the next push's demodulator */
+	hipEvent_t recs_done = nullptr, frames_done[2] = {nullptr, nullptr};
+	std::vector<vdl2gpu_frame_t> fready;	/* storage order */
+	std::vector<uint32_t> fready_idx;	/* hand-out order, consumed from fready_pos */
 	size_t fready_pos = 0;
 	uint64_t frames_dropped = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
@@ -257,6 +260,15 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_frames[0]);
 	(void)hipFree(h->d_frames[1]);
 	(void)hipFree(h->d_fcnt);
+	if (h->blk_stream) {
+		(void)hipStreamSynchronize(h->blk_stream);
+		(void)hipStreamDestroy(h->blk_stream);
+	}
+	if (h->recs_done)
+		(void)hipEventDestroy(h->recs_done);
+	for (auto &e : h->frames_done)
+		if (e)
+			(void)hipEventDestroy(e);
 	(void)hipFree(h->d_outc);
 	for (auto &e : h->ring_done)
 		if (e)
@@ -391,6 +403,10 @@ static int create_impl(vdl2gpu_t *h)
 		for (int r = 0; r < 2; ++r)
 			HIPCHK(h, hipMalloc(&h->d_frames[r], (size_t)h->frame_cap * sizeof(vdl2gpu_frame_t)));
 		HIPCHK(h, hipMalloc(&h->d_fcnt, 4 * sizeof(unsigned)));
+		HIPCHK(h, hipStreamCreateWithFlags(&h->blk_stream, hipStreamNonBlocking));
+		HIPCHK(h, hipEventCreateWithFlags(&h->recs_done, hipEventDisableTiming));
+		for (int r = 0; r < 2; ++r)
+			HIPCHK(h, hipEventCreateWithFlags(&h->frames_done[r], hipEventDisableTiming));
 		HIPCHK(h, hipMemsetAsync(h->d_fcnt, 0, 4 * sizeof(unsigned), h->stream));
 	}
 	HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pin_cnt, h->h_pin_cnt, 0));
@@ -801,7 +817,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->frames_on) {
-			/* block path on the records where they lie (vdlm2.c:84-161) */
+			/* block path on the records where they lie (vdlm2.c:84-161), on its own stream: nothing
+			 * further down this push's chain needs the frames */
 			K4Params k4{};
 			k4.recs = h->d_recs[ring];
 			k4.nrecs_dev = h->d_outc + 2 * ring;
@@ -809,9 +826,14 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			k4.frames = h->d_frames[ring];
 			k4.nframes = h->d_fcnt + 2 * ring;
 			k4.frame_cap = h->frame_cap;
-			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 2 * ring, 0, 2 * sizeof(unsigned), h->stream));
-			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->stream, k4);
+			k4.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
+			HIPCHK(h, hipEventRecord(h->recs_done, h->stream));
+			HIPCHK(h, hipStreamWaitEvent(h->blk_stream, h->recs_done, 0));
+			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 2 * ring, 0, 2 * sizeof(unsigned), h->blk_stream));
+			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->blk_stream, k4);
+			hipLaunchKernelGGL(k4_publish, dim3(1), dim3(64), 0, h->blk_stream, h->d_fcnt + 2 * ring, h->d_pin_cnt + 8 * ring);
 			HIPCHK(h, hipGetLastError());
+			HIPCHK(h, hipEventRecord(h->frames_done[ring], h->blk_stream));
 		}
 	}
 	if (h->stage_events)
@@ -827,7 +849,6 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k3.cs = h->d_cs;
 		k3.outc = h->d_outc;
 		k3.host_cnt = h->d_pin_cnt + 8 * ring;
-		k3.fcnt = h->frames_on ? h->d_fcnt + 2 * ring : nullptr;
 		k3.ring = ring;
 		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
@@ -873,7 +894,18 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			return VDL2GPU_EHIP;
 		}
 	}
+	if (h->frames_on && !blocking) {
+		const hipError_t q = hipEventQuery(h->frames_done[ring]);
+		if (q == hipErrorNotReady)
+			return 1;
+		if (q != hipSuccess) {
+			h->err = std::string("hipEventQuery: ") + hipGetErrorString(q);
+			return VDL2GPU_EHIP;
+		}
+	}
 	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
+	if (h->frames_on)
+		HIPCHK(h, hipEventSynchronize(h->frames_done[ring]));
 	const unsigned c0 = h->h_pin_cnt[8 * ring], c1 = h->h_pin_cnt[8 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
@@ -932,8 +964,9 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		const unsigned nf = std::min(h->h_pin_cnt[8 * ring + 4], h->frame_cap);
 		h->frames_dropped += h->h_pin_cnt[8 * ring + 5];
 		if (nf) {
-			if (h->fready_pos == h->fready.size()) {
+			if (h->fready_pos == h->fready_idx.size()) {
 				h->fready.clear();
+				h->fready_idx.clear();
 				h->fready_pos = 0;
 			}
 			const size_t old = h->fready.size();
@@ -946,12 +979,16 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 				HIPCHK(h, hipStreamSynchronize(h->copy_stream));
 				memcpy(h->fready.data() + old + done, h->h_pin, (size_t)m * sizeof(vdl2gpu_frame_t));
 			}
+			const size_t iold = h->fready_idx.size();
 			for (size_t i = old; i < h->fready.size(); ++i) {
 				vdl2gpu_frame_t &f = h->fready[i];
 				f.ppm = (float)((double)(10500.0f * f.df) / (2.0 * M_PI * (double)f.Fr) * 1e6);	/* d8psk.c:302 */
 				f.block = -1;
+				h->fready_idx.push_back((uint32_t)i);
 			}
-			std::sort(h->fready.begin() + old, h->fready.end(), [](const vdl2gpu_frame_t &a, const vdl2gpu_frame_t &b) {
+			const vdl2gpu_frame_t *fd = h->fready.data();
+			std::sort(h->fready_idx.begin() + iold, h->fready_idx.end(), [fd](uint32_t x, uint32_t y) {
+				const vdl2gpu_frame_t &a = fd[x], &b = fd[y];
 				if (a.end_dec != b.end_dec)
 					return a.end_dec < b.end_dec;
 				if (a.stream != b.stream)
@@ -1028,11 +1065,29 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		k4.frames = d_fr;
 		k4.nframes = d_cnt;
 		k4.frame_cap = (unsigned)max_frames;
-		const unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
+		unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
+		if (getenv("VDL2GPU_DEBUG_BLOCKS") && atoi(getenv("VDL2GPU_DEBUG_BLOCKS")) > 1)
+			grid = (unsigned)h->n_cu * 8;
+		hipEvent_t ev0 = nullptr, ev1 = nullptr;
+		const bool timeit = getenv("VDL2GPU_DEBUG_BLOCKS") != nullptr;
+		if (timeit) {
+			(void)hipEventCreate(&ev0);
+			(void)hipEventCreate(&ev1);
+			(void)hipEventRecord(ev0, h->copy_stream);
+		}
 		hipLaunchKernelGGL(k4_frames, dim3(grid), dim3(K4_NT), 0, h->copy_stream, k4);
 		e = hipGetLastError();
+		if (timeit)
+			(void)hipEventRecord(ev1, h->copy_stream);
 		if (e == hipSuccess)
 			e = hipStreamSynchronize(h->copy_stream);
+		if (timeit) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, ev0, ev1);
+			fprintf(stderr, "k4_frames: %d blocks, grid %u, %.3f ms\n", n, grid, ms);
+			(void)hipEventDestroy(ev0);
+			(void)hipEventDestroy(ev1);
+		}
 	}
 	if (e == hipSuccess)
 		e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
@@ -1052,7 +1107,7 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 	return nf;
 }
 
-extern "C" int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max)
+static int poll_frames_impl(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max, bool blocking)
 {
 	if (!h || (max > 0 && !out) || max < 0)
 		return VDL2GPU_EINVAL;
@@ -1061,14 +1116,24 @@ extern "C" int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max)
 		return VDL2GPU_EINVAL;
 	}
 	HIPCHK(h, hipSetDevice(h->cfg.device));
-	int rc = harvest_all(h, true);
+	int rc = harvest_all(h, blocking);
 	if (rc)
 		return rc;
-	const int n = std::min<int>(max, (int)(h->fready.size() - h->fready_pos));
+	const int n = std::min<int>(max, (int)(h->fready_idx.size() - h->fready_pos));
 	for (int i = 0; i < n; ++i)
-		out[i] = h->fready[h->fready_pos + i];
+		out[i] = h->fready[h->fready_idx[h->fready_pos + i]];
 	h->fready_pos += (size_t)n;
 	return n;
+}
+
+extern "C" int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max)
+{
+	return poll_frames_impl(h, out, max, true);
+}
+
+extern "C" int vdl2gpu_poll_frames_ready(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max)
+{
+	return poll_frames_impl(h, out, max, false);
 }
 
 extern "C" int vdl2gpu_pending(vdl2gpu_t *h)

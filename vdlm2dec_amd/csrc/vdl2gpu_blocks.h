@@ -35,6 +35,7 @@ struct K4Params {
 	vdl2gpu_frame_t *frames;
 	unsigned *nframes;		/* [0] frames written, [1] frames dropped (ring full) */
 	unsigned frame_cap;
+	unsigned long long *dbg;	/* diagnostics: stage cycle counters, or nullptr */
 };
 
 struct K4Shared {
@@ -48,7 +49,13 @@ struct K4Shared {
 	int kept[K4_NT + 1];			/* exclusive prefix of kept bits */
 	unsigned char lor[K4_NT + 1];		/* exclusive prefix OR of the lanes' bytes */
 	int eras[6];
-	int ctl[8];
+	int ctl[16];
+	/* Berlekamp-Massey work arrays live here, not in (scratch-backed) private arrays */
+	uint8_t lam[8], syn[8], bpoly[8], tpoly[8], omg[8], root[8], reg[8], loc[8];
+	int rs_deg, rs_count;
+	unsigned short crc_adv[16];	/* FCS state advanced over one lane's worth of zero bytes, per state bit */
+	unsigned short crc_in[K4_NT + 1];	/* running FCS at the start of each lane's bytes */
+	unsigned short crc_own[K4_NT];	/* FCS (from zero) of each lane's bytes */
 };
 
 __device__ __forceinline__ int k4_m255(int x)
@@ -60,15 +67,14 @@ __device__ __forceinline__ int k4_m255(int x)
 	return x;
 }
 
-/* rs.c:81-291 for one row, by one lane; syn[] are the six syndromes (values, not logs).
- * Returns the number of corrected positions or -1; eras[] in/out like the reference. */
-__device__ int k4_rs_finish(K4Shared &sh, uint8_t *data, const uint8_t *synv, int *eras_pos, int no_eras)
+/* rs.c:81-291 for one row whose syndromes are not all zero, in three parts.
+ * k4_rs_bm (one lane): erasure locator and Berlekamp-Massey in the reference's update order; leaves
+ * lambda in index form and its degree in LDS. */
+__device__ void k4_rs_bm(K4Shared &sh, const unsigned *synv, const int *eras_pos, int no_eras)
 {
-	enum { NR = 6, NNN = 255, FIRST = 120 };
+	enum { NR = 6, NNN = 255 };
 	const uint8_t *gexp = sh.gexp, *glog = sh.glog;
-	uint8_t lam[NR + 1], syn[NR], bpoly[NR + 1], tpoly[NR + 1], omg[NR + 1];
-	uint8_t root[NR], reg[NR + 1], loc[NR];
-	int count = 0;
+	uint8_t *lam = sh.lam, *syn = sh.syn, *bpoly = sh.bpoly, *tpoly = sh.tpoly;
 	for (int i = 0; i < NR; i++)
 		syn[i] = glog[synv[i]];	/* index form, NOLOG for zero */
 	for (int i = 0; i <= NR; i++)
@@ -121,25 +127,54 @@ __device__ int k4_rs_finish(K4Shared &sh, uint8_t *data, const uint8_t *synv, in
 		if (lam[i] != K4_NOLOG)
 			deg = i;
 	}
-	/* Chien search */
-	for (int i = 1; i <= NR; i++)
-		reg[i] = lam[i];
-	for (int i = 1, k = 0; i <= NNN; i++, k = k4_m255(k + 1)) {
-		uint8_t q = 1;
-		for (int j = deg; j > 0; j--)
-			if (reg[j] != K4_NOLOG) {
-				reg[j] = (uint8_t)k4_m255(reg[j] + j);
-				q ^= gexp[reg[j]];
+	sh.rs_deg = deg;
+	sh.rs_count = 0;
+}
+
+/* Chien search, all lanes: position i (1..255) is a root when 1 + sum_j lambda_j alpha^(i j) = 0.  The
+ * reference walks i upwards and stops at the deg-th root; a polynomial of degree deg has no more, so
+ * listing all roots in the order of i is the same list. */
+__device__ void k4_rs_chien(K4Shared &sh, int lane)
+{
+	const int deg = sh.rs_deg;
+	for (int t = 0; t < 4; ++t) {
+		const int i = 1 + lane + 64 * t;
+		bool isroot = false;
+		if (i <= 255) {
+			unsigned q = 1;
+			for (int j = 1; j <= deg; ++j) {
+				const unsigned l = sh.lam[j];
+				if (l != K4_NOLOG)
+					q ^= sh.gexp[(l + (unsigned)(i * j)) % 255u];
 			}
-		if (q)
-			continue;
-		root[count] = (uint8_t)i;
-		loc[count] = (uint8_t)k;
-		if (++count == deg)
-			break;
+			isroot = (q == 0);
+		}
+		const unsigned long long m = __ballot(isroot);
+		if (isroot) {
+			const int pos = sh.rs_count + __popcll(m & ((1ull << lane) - 1ull));
+			if (pos < 6) {
+				sh.root[pos] = (uint8_t)i;
+				sh.loc[pos] = (uint8_t)((i - 1) % 255);
+			}
+		}
+		__syncthreads();
+		if (lane == 0)
+			sh.rs_count += __popcll(m);
+		__syncthreads();
 	}
+}
+
+/* Omega and Forney (one lane), last root first; a zero denominator abandons the row with the
+ * corrections made so far, like the reference.  eras[] in/out like the reference. */
+__device__ void k4_rs_forney(K4Shared &sh, uint8_t *data, int *eras_pos)
+{
+	enum { NR = 6, NNN = 255, FIRST = 120 };
+	const uint8_t *gexp = sh.gexp, *glog = sh.glog;
+	const uint8_t *lam = sh.lam, *syn = sh.syn, *root = sh.root, *loc = sh.loc;
+	uint8_t *omg = sh.omg;
+	const int deg = sh.rs_deg, count = sh.rs_count;
 	if (deg != count)
-		return -1;
+		return;
 	int dego = 0;
 	for (int i = 0; i < NR; i++) {
 		uint8_t tmp = 0;
@@ -151,7 +186,6 @@ __device__ int k4_rs_finish(K4Shared &sh, uint8_t *data, const uint8_t *synv, in
 		omg[i] = glog[tmp];
 	}
 	omg[NR] = K4_NOLOG;
-	/* Forney, last root first; a zero denominator abandons the row with the corrections made so far */
 	for (int j = count - 1; j >= 0; j--) {
 		uint8_t num1 = 0;
 		for (int i = dego; i >= 0; i--)
@@ -164,13 +198,12 @@ __device__ int k4_rs_finish(K4Shared &sh, uint8_t *data, const uint8_t *synv, in
 			if (lam[i + 1] != K4_NOLOG)
 				den ^= gexp[k4_m255(lam[i + 1] + i * root[j])];
 		if (den == 0)
-			return -1;
+			return;
 		if (num1)
 			data[loc[j]] ^= gexp[k4_m255(glog[num1] + glog[num2] + NNN - glog[den])];
 	}
 	for (int i = 0; i < count; i++)
 		eras_pos[i] = loc[i];
-	return count;
 }
 
 __global__ __launch_bounds__(K4_NT)
@@ -178,6 +211,8 @@ void k4_frames(K4Params p)
 {
 	__shared__ K4Shared sh;
 	const int lane = threadIdx.x;
+	const bool prof = p.dbg && lane == 0;
+	long long tq = prof ? clock64() : 0;
 	/* tables: GF(256)/0x187 (rs.c:17-79), FCS-16 reflected 0x8408 (crc.c) */
 	if (lane == 0) {
 		unsigned x = 1;
@@ -201,8 +236,13 @@ void k4_frames(K4Params p)
 	__syncthreads();
 	unsigned nrecs = p.nrecs_dev ? *p.nrecs_dev : p.nrecs;
 	nrecs = nrecs > p.rec_cap ? p.rec_cap : nrecs;
+#define K4_STAMP(slot) do { if (prof) { const long long tn = clock64(); atomicAdd(p.dbg + 48 + (slot), (unsigned long long)(tn - tq)); tq = tn; } } while (0)
+	K4_STAMP(0);
 	for (unsigned ib = blockIdx.x; ib < nrecs; ib += gridDim.x) {
 		const vdl2gpu_burst_t *rec = p.recs + ib;
+		const long long tb0 = prof ? clock64() : 0;
+		if (prof)
+			tq = tb0;
 		const int nbrow = rec->nbrow, nlbyte = rec->nlbyte;
 		if (nbrow < 1 || nbrow > VDL2GPU_MAXROWS || nlbyte < 0 || nlbyte > 249)
 			continue;
@@ -218,6 +258,7 @@ void k4_frames(K4Params p)
 		if (lane < 6)
 			sh.eras[lane] = 0;
 		__syncthreads();
+		K4_STAMP(1);
 		/* ---- RS per row (rows in order: eras_pos[] carries over, vdlm2.c:104-113) */
 		int nby = 0;
 		for (int r = 0; r < nbrow; ++r) {
@@ -258,17 +299,20 @@ void k4_frames(K4Params p)
 					syn[i] ^= __shfl_xor(syn[i], d, 64);
 			const unsigned any = syn[0] | syn[1] | syn[2] | syn[3] | syn[4] | syn[5];
 			__syncthreads();
-			if (any && lane == 0) {
-				uint8_t sv[6];
-				for (int i = 0; i < 6; ++i)
-					sv[i] = (uint8_t)syn[i];
-				k4_rs_finish(sh, sh.row[r], sv, sh.eras, nera);
+			if (any) {	/* wave-uniform: every lane holds the reduced syndromes */
+				if (lane == 0)
+					k4_rs_bm(sh, syn, sh.eras, nera);
+				__syncthreads();
+				k4_rs_chien(sh, lane);
+				if (lane == 0)
+					k4_rs_forney(sh, sh.row[r], sh.eras);
 			}
 			__syncthreads();
 			for (int i = lane; i < by; i += K4_NT)
 				sh.src[nby + i] = sh.row[r][i];
 			nby += by;
 		}
+		K4_STAMP(2);
 		for (int i = lane; i < (K4_MAXBY + 8) / 4 + 2; i += K4_NT)
 			sh.dst[i] = 0u;
 		__syncthreads();
@@ -356,6 +400,7 @@ void k4_frames(K4Params p)
 				atomicOr(&sh.dst[w], acc);
 		}
 		__syncthreads();
+		K4_STAMP(3);
 		const int nb = sh.kept[K4_NT] >> 3;	/* whole un-stuffed bytes */
 		const uint8_t *B = reinterpret_cast<const uint8_t *>(sh.dst);
 		/* ---- first flag: the byte at which the OR of all bytes so far equals 0x7e (vdlm2.c:129-133) */
@@ -411,19 +456,64 @@ void k4_frames(K4Params p)
 			continue;
 		}
 		/* ---- hdata[] = 0x7e, B[m1], B[m1+1], ...; every later 0x7e closes a candidate frame
-		 *      hdata[0..k] whose FCS runs over hdata[1..k-1] (check_frame, vdlm2.c:38-61) */
+		 *      hdata[0..k] whose FCS runs over hdata[1..k-1] (check_frame, vdlm2.c:38-61).  All candidates
+		 *      start at m1, so one running FCS serves -- computed lane-parallel: the FCS is linear, the state
+		 *      at the start of a lane's bytes is (state one lane earlier, advanced over per2 zero bytes)
+		 *      xor (FCS from zero of that lane's bytes). */
+		K4_STAMP(4);
+		if (lane < 16) {	/* the advance map, one state bit per lane */
+			unsigned c = 1u << lane;
+			for (int i = 0; i < per2; ++i)
+				c = (c >> 8) ^ sh.crc_tab[c & 0xffu];
+			sh.crc_adv[lane] = (unsigned short)c;
+		}
+		const int L1 = m1 / per2;	/* lane that holds m1 (per2 >= 1 since nb > m1) */
+		{
+			unsigned c = (lane == L1) ? 0xffffu : 0u;
+			for (int i = (lane == L1) ? m1 : c0; i < c1; ++i)
+				c = (c >> 8) ^ sh.crc_tab[(c ^ B[i]) & 0xffu];
+			sh.crc_own[lane] = (unsigned short)c;
+		}
+		if (lane == 0)
+			sh.ctl[1] = 0;	/* number of frames */
+		__syncthreads();
 		if (lane == 0) {
-			unsigned crc = 0xffffu;
-			int nf = 0;
-			for (int q = m1; q < nb; ++q) {
-				const unsigned v = B[q];
-				if (v == 0x7eu && (q - m1 + 2) >= 13 && crc == 0xf0b8u && nf < 6)
-					sh.ctl[2 + nf++] = q;
-				crc = (crc >> 8) ^ sh.crc_tab[(crc ^ v) & 0xffu];
+			unsigned st = sh.crc_own[L1];	/* state after lane L1's bytes (from 0xffff at m1) */
+			for (int l = L1 + 1; l < K4_NT; ++l) {
+				sh.crc_in[l] = (unsigned short)st;
+				unsigned adv = 0;
+				for (int b = 0; b < 16; ++b)
+					if (st & (1u << b))
+						adv ^= sh.crc_adv[b];
+				st = adv ^ sh.crc_own[l];	/* exact for whole lanes; the last lane's state is not needed */
 			}
-			sh.ctl[1] = nf;
 		}
 		__syncthreads();
+		if (lane >= L1) {
+			unsigned c = (lane == L1) ? 0xffffu : sh.crc_in[lane];
+			for (int q = (lane == L1) ? m1 : c0; q < c1; ++q) {
+				const unsigned v = B[q];
+				if (v == 0x7eu && (q - m1 + 2) >= 13 && c == 0xf0b8u) {
+					const int k = atomicAdd(&sh.ctl[1], 1);
+					if (k < 12)
+						sh.ctl[2 + k] = q;
+				}
+				c = (c >> 8) ^ sh.crc_tab[(c ^ v) & 0xffu];
+			}
+		}
+		__syncthreads();
+		if (lane == 0) {	/* frames in stream order (there is almost never more than one) */
+			int nf0 = sh.ctl[1] < 12 ? sh.ctl[1] : 12;
+			for (int i = 1; i < nf0; ++i)
+				for (int j = i; j > 0 && sh.ctl[2 + j] < sh.ctl[1 + j]; --j) {
+					const int t = sh.ctl[2 + j];
+					sh.ctl[2 + j] = sh.ctl[1 + j];
+					sh.ctl[1 + j] = t;
+				}
+			sh.ctl[1] = nf0;
+		}
+		__syncthreads();
+		K4_STAMP(5);
 		const int nf = sh.ctl[1];
 		for (int f = 0; f < nf; ++f) {
 			const int q = sh.ctl[2 + f];
@@ -461,6 +551,27 @@ void k4_frames(K4Params p)
 			__syncthreads();
 		}
 		__syncthreads();
+		K4_STAMP(6);
+		if (prof) {
+			atomicAdd(p.dbg + 48 + 7, 1ull);
+			const unsigned long long tot = (unsigned long long)(tq - tb0);
+			atomicMax(p.dbg + 48 + 8, tot);
+			if (tot > 400000ull) {
+				atomicAdd(p.dbg + 48 + 9, 1ull);
+				p.dbg[48 + 10] = ((unsigned long long)nbrow << 32) | (unsigned)nlbyte;
+				p.dbg[48 + 11] = (unsigned long long)sh.kept[K4_NT];
+			}
+		}
+	}
+#undef K4_STAMP
+}
+
+/* runs behind k4_frames on its stream: hand the frame counters of the push to the host (mapped memory) */
+__global__ void k4_publish(const unsigned *fcnt, unsigned *host_cnt)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		host_cnt[4] = fcnt[0];
+		host_cnt[5] = fcnt[1];
 	}
 }
 

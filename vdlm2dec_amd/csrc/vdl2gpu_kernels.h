@@ -198,8 +198,7 @@ struct K3Params {
 	StreamState *ss;
 	const ChanState *cs;
 	const unsigned *outc;	/* device counters: [2*ring] records, [2*ring+1] dropped, [4] serial redos so far */
-	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring: + [4] frames, [5] frames dropped */
-	const unsigned *fcnt;	/* block path in the pipeline (VDL2GPU_F_FRAMES): its two counters, else nullptr */
+	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4], [5]: frame counters, written by k4_publish) */
 	int ring;
 };
 
@@ -2642,8 +2641,6 @@ __global__ void k3_rebase(K3Params p)
 		p.host_cnt[1] = p.outc[2 * p.ring + 1];
 		p.host_cnt[2] = p.outc[4];
 		p.host_cnt[3] = p.outc[5];
-		p.host_cnt[4] = p.fcnt ? p.fcnt[0] : 0u;
-		p.host_cnt[5] = p.fcnt ? p.fcnt[1] : 0u;
 	}
 	StreamState *ss = p.ss + s;
 	long long mn = 0x7fffffffffffffffLL;
