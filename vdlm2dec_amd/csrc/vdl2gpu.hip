@@ -334,7 +334,7 @@ static int create_impl(vdl2gpu_t *h)
 	{
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, getenv("VDL2GPU_K2_PRIO") ? atoi(getenv("VDL2GPU_K2_PRIO")) : prio_hi));
+		HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
 	}
 	const int S = h->S, L = h->L;
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
@@ -359,7 +359,7 @@ static int create_impl(vdl2gpu_t *h)
 		/* the demodulator chain is the critical path: the channeliser only fills what it leaves idle */
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, getenv("VDL2GPU_K1_PRIO") ? atoi(getenv("VDL2GPU_K1_PRIO")) : prio_lo));
+		HIPCHK(h, hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, prio_lo));
 	}
 	for (int r = 0; r < 2; ++r) {
 		HIPCHK(h, hipEventCreateWithFlags(&h->k1_done[r], hipEventDisableTiming));
@@ -388,8 +388,6 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	HIPCHK(h, hipMalloc(&h->d_seeds, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
-	if (getenv("VDL2GPU_NO_STAGE_EVENTS"))
-		h->stage_events = false;
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
 		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
@@ -660,7 +658,6 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		if (fast) {
 			/* whole 1 ms periods in the middle on the register-resident fast path; the first
 			 * period (carried partial window) and the tail on the general kernel */
-			k1.variant = getenv("VDL2GPU_K1_VARIANT") ? atoi(getenv("VDL2GPU_K1_VARIANT")) : 0;
 			generic(0, K1F_PER_OUT - 1);
 			pt.fast = true;
 			auto launch_fast = [&](long long per_lo, long long per_n, hipEvent_t ev0, hipEvent_t ev1) {
@@ -682,16 +679,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 				const dim3 grid((unsigned)((k1.per_n + k1.per_pb - 1) / k1.per_pb) * K1F_ROLES, (unsigned)h->S);
 				switch (h->cfg.fmt) {
 				case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case VDL2GPU_FMT_CS16:
-					switch (k1.variant) {	/* development ablations; 0 in production */
-					case 1: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 1>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-					case 2: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 2>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-					case 3: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 3>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-					case 4: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 4>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-					case 7: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 7>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-					default: hipLaunchKernelGGL((k1_fast<VDL2GPU_FMT_CS16, 0>), grid, dim3(K1F_THREADS), 0, ks, k1); break;
-					}
-					break;
+				case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CS16>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 				case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 				default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 				}
@@ -1065,29 +1053,11 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		k4.frames = d_fr;
 		k4.nframes = d_cnt;
 		k4.frame_cap = (unsigned)max_frames;
-		unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
-		if (getenv("VDL2GPU_DEBUG_BLOCKS") && atoi(getenv("VDL2GPU_DEBUG_BLOCKS")) > 1)
-			grid = (unsigned)h->n_cu * 8;
-		hipEvent_t ev0 = nullptr, ev1 = nullptr;
-		const bool timeit = getenv("VDL2GPU_DEBUG_BLOCKS") != nullptr;
-		if (timeit) {
-			(void)hipEventCreate(&ev0);
-			(void)hipEventCreate(&ev1);
-			(void)hipEventRecord(ev0, h->copy_stream);
-		}
+		const unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
 		hipLaunchKernelGGL(k4_frames, dim3(grid), dim3(K4_NT), 0, h->copy_stream, k4);
 		e = hipGetLastError();
-		if (timeit)
-			(void)hipEventRecord(ev1, h->copy_stream);
 		if (e == hipSuccess)
 			e = hipStreamSynchronize(h->copy_stream);
-		if (timeit) {
-			float ms = 0;
-			(void)hipEventElapsedTime(&ms, ev0, ev1);
-			fprintf(stderr, "k4_frames: %d blocks, grid %u, %.3f ms\n", n, grid, ms);
-			(void)hipEventDestroy(ev0);
-			(void)hipEventDestroy(ev1);
-		}
 	}
 	if (e == hipSuccess)
 		e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);

@@ -133,7 +133,6 @@ struct K1Params {
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
 	long long per_lo, per_n;	/* fast kernel: whole 84-output periods [per_lo, per_lo+per_n) */
 	int per_pb;		/* periods per wavefront (chosen so that the waves fill the GPU evenly) */
-	int variant;		/* development only: 1 = skip stores, 2 = skip refills, 4 = skip mixing */
 	const float2 *lo;	/* [S][8][L] */
 	float2 *dec;		/* this push's planes, [S][8][cap] */
 	long long cap;
@@ -403,7 +402,7 @@ template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<F
 	}
 }
 
-template <int FMT, int VAR = 0> __global__ __launch_bounds__(K1F_THREADS)
+template <int FMT> __global__ __launch_bounds__(K1F_THREADS)
 void k1_fast(K1Params p)
 {
 	typedef typename K1Raw<FMT>::T raw_t;
@@ -481,11 +480,9 @@ void k1_fast(K1Params p)
 				for (int u = 0; u < 3; ++u)
 					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
 				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
-				if (!(VAR & 2)) {
 #pragma unroll
-					for (int u = 0; u < 3; ++u)
-						rr[d][u] = k1_raw_load<FMT>(raw, sbase + pstride * qn + li[u]);
-				}
+				for (int u = 0; u < 3; ++u)
+					rr[d][u] = k1_raw_load<FMT>(raw, sbase + pstride * qn + li[u]);
 				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
 				if (active) {
 					const v2f *xp = reinterpret_cast<const v2f *>(&xs[off]);
@@ -502,7 +499,7 @@ void k1_fast(K1Params p)
 						}
 					} else {
 #pragma unroll
-						for (int t = (VAR & 4) ? 22 : 0; t < 23; ++t)
+						for (int t = 0; t < 23; ++t)
 							k1_cmac(acc, xp[t], w[t]);
 						if (nwin == 24)
 							k1_cmac(acc, xp[23], w[23]);
@@ -520,8 +517,7 @@ void k1_fast(K1Params p)
 						qr = acc.x / fn;
 						qi = acc.y / fn;
 					}
-					if (!(VAR & 1) || qr == 12345.678f)
-						dec[(long long)q * K1F_PER_OUT * nw] = make_float2(qr, qi);
+					dec[(long long)q * K1F_PER_OUT * nw] = make_float2(qr, qi);
 				}
 				__syncthreads();	/* reads done before the slice is overwritten */
 			}
@@ -2293,7 +2289,6 @@ void k2c_resolve(K2Params p)
 	const bool tables_ok = !p.force_serial && ncand <= VDL2_CAND_CAP && p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] == 0;
 	if (!tables_ok)
 		ncand = 0;
-	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
 	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
 	/* 1. candidates sorted by time (K2s) */
 	const long long pos_in = st.pos;
