@@ -202,6 +202,38 @@ def test_scan_modes_agree_with_oracle(built, oracle, mode):
         assert st["candidates"] == 0
 
 
+@pytest.mark.parametrize("scale", [1e18, 1e-17])
+def test_screens_pass_what_they_cannot_judge(built, oracle, scale):
+    """cf32 input far outside the range in which the scan's screens normalise the filter output:
+    every instant must then go to the exact path (worklists overflow, tiles are done in pieces, the
+    survivor list is flushed mid-tile) -- and the bursts are still the oracle's."""
+    spec = S.regimes(seed=350, infos=(5, 40, 90))
+    raw = synth.synth_stream(spec, "cf32").astype(np.float32) * np.float32(scale)
+    assert np.isfinite(raw).all() and np.abs(raw).max() > 0
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cf32", spec.rate, spec.fo, S.FC))
+    with _rx(spec.rate, spec.fo, "cf32", max_push=1 << 20) as rx:
+        got = rx.run(raw, block=300_000)
+    assert _gpu_keys(got) == want and len(want) >= 3
+
+
+def test_silence_between_signals(built, oracle):
+    """Stretches of exact zeros (squelched or padded recordings): the filter output is exactly zero
+    there, atan2f(0, 0) = 0, and the screens must treat that as the phase it is."""
+    spec = S.regimes(seed=351, infos=(12, 64, 30, 75))
+    raw = synth.synth_stream(spec, "cs16").copy()
+    n = len(raw) // 2
+    iq = raw.reshape(n, 2)
+    iq[: n // 10] = 0
+    iq[n // 2: n // 2 + n // 8] = 0          # may cut a burst short: whatever the oracle makes of it
+    iq[-(n // 12):] = 0
+    raw = iq.reshape(-1)
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with _rx(spec.rate, spec.fo, "cs16", max_push=1 << 20) as rx:
+        got = rx.run(raw, block=250_000)
+        st = rx.stats()
+    assert _gpu_keys(got) == want and len(want) >= 1
+
+
 def test_verify_pass_catches_incomplete_tables(built, oracle):
     """With the region scan switched off the candidate tables lack most trigger classes, so the
     resolver's chain is wrong after the first burst; K2a-verify must notice and the serial redo must
