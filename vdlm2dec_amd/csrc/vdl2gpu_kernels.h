@@ -94,11 +94,7 @@ struct Cand {			/* free-running detector fires at dec_base + nrel with sub-phase
 };
 
 enum { CL_STEADY = 0, CL_DEFER_FIRST = 1, CL_NONSTEADY = 2, CL_INVALID = 3 };
-struct Cluster {
-	int status, r_s;
-	long long n_s;		/* CL_STEADY: detector is history-free again at (n_s, r_s) */
-	int nslots, slots[VDL2_CL_MAXB];	/* staged bursts of this cluster */
-	int ntrig, nrej, nburst;
+struct Cluster {		/* what the resolver reads of a cluster is its 8-byte head (cl_pack); this is the rest */
 	ChanState saved;	/* CL_NONSTEADY: explicit state to continue from */
 };
 
@@ -2043,7 +2039,6 @@ void k2s_sort(K2Params p)
 	if (ncand > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] != 0)
 		return;		/* tables unusable: the resolver runs serially */
 	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
-	Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
 	for (int i = tid; i < ncand; i += K2S_NT)
 		sbuf[i] = (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i;
 	if (tid == 0)
@@ -2071,10 +2066,8 @@ void k2s_sort(K2Params p)
 		}
 		if (primary)
 			prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
-		else {
-			clusters[idx].status = CL_INVALID;
+		else
 			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
-		}
 	}
 	__syncthreads();
 	if (tid == 0)
@@ -2178,20 +2171,10 @@ void k2b_clusters(K2Params p)
 			status = CL_INVALID;
 		if (status == CL_NONSTEADY)
 			mach_store(sh, st, &cl->saved);
-		if (tid == 0) {
-			cl->status = status;
-			cl->r_s = st.r;
-			cl->n_s = st.pos;
-			cl->nslots = out.nslots < VDL2_CL_MAXB ? out.nslots : VDL2_CL_MAXB;
-#pragma unroll
-			for (int i = 0; i < VDL2_CL_MAXB; ++i)
-				cl->slots[i] = out.slots[i];
-			cl->ntrig = out.ntrig;
-			cl->nrej = out.nrej;
-			cl->nburst = out.nburst;
+		if (tid == 0)	/* descriptors sit in static slots desc_static + i: the head only needs their number */
 			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] =
-			    cl_pack((int)(st.pos - cx.dec_base), status, st.r, cl->nslots, out.ntrig, out.nrej, out.nburst);
-		}
+			    cl_pack((int)(st.pos - cx.dec_base), status, st.r, out.nslots < VDL2_CL_MAXB ? out.nslots : VDL2_CL_MAXB,
+				    out.ntrig, out.nrej, out.nburst);
 		__syncthreads();
 	}
 }
