@@ -1,0 +1,552 @@
+/* vdl2gpu_resolve.h -- K2s, K2b, K2c, K2f, K2d: candidate order, clusters, the real chain, commit, payload.  Part of the device side of libvdl2gpu.so; included by vdl2gpu_kernels.h only. */
+#ifndef VDL2GPU_RESOLVE_H
+#define VDL2GPU_RESOLVE_H
+
+/* ====================================================================== K2s
+ * Per channel: sort the candidates by time (bitonic network in LDS) for the resolver, and pick the
+ * ones whose cluster is worth precomputing: the first of its (sub-phase, parity) class within a
+ * burst's worth of samples.  A later candidate of the same class can only be reached if the detector
+ * turns history-free in the few samples between the two; the resolver computes such a cluster itself
+ * when it ever needs one (status CL_INVALID), so this is a cost decision, never a correctness one.
+ */
+#define K2S_NT 1024
+#define K2S_LOOKBACK 72		/* a triggered detector is busy for at least 9 symbols = 72 samples */
+__global__ __launch_bounds__(K2S_NT)
+void k2s_sort(K2Params p)
+{
+	__shared__ unsigned long long sbuf[VDL2_CAND_CAP];
+	__shared__ WgSortShared ws;
+	__shared__ int s_np;
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial)
+		return;
+	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
+		return;
+	int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	if (ncand > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] != 0)
+		return;		/* tables unusable: the resolver runs serially */
+	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	for (int i = tid; i < ncand; i += K2S_NT)
+		sbuf[i] = (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i;
+	if (tid == 0)
+		s_np = 0;
+	__syncthreads();
+	wg_sort_u64<K2S_NT>(sbuf, ws, ncand, 18, (unsigned)(p.ss[s].dec_fill + p.J));
+	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
+	for (int j = tid; j < ncand; j += K2S_NT) {
+		const unsigned long long v = sbuf[j];
+		const int key = (int)(v >> 16), idx = (int)(v & 0xffffu);
+		skey[j] = key;
+		sidx[j] = (unsigned short)idx;
+		const int n = key >> 2, cls = (key & 3) * 2 + (n & 1);
+		bool primary = true;
+		for (int i = j - 1; i >= 0; --i) {
+			const int ki = (int)(sbuf[i] >> 16), ni = ki >> 2;
+			if (n - ni >= K2S_LOOKBACK)
+				break;
+			if ((ki & 3) * 2 + (ni & 1) == cls) {
+				primary = false;
+				break;
+			}
+		}
+		if (primary)
+			prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
+		else
+			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
+	}
+	__syncthreads();
+	if (tid == 0)
+		p.ctl[CTL_NPRIM0 + sc] = (unsigned)s_np;
+}
+
+/* ====================================================================== K2b
+ * One workgroup per trigger candidate (persistent workgroups pull tickets):
+ * put the detector in the history-free state at the candidate, run the exact
+ * machine through the burst (and any burst that follows before the detector is
+ * history-free again) and record where and how the idle search resumes.
+ */
+#ifndef K2B_WAVES
+#define K2B_WAVES 4
+#endif
+__global__ __launch_bounds__(K2B_NT) __attribute__((amdgpu_waves_per_eu(K2B_WAVES, 8)))
+void k2b_clusters(K2Params p)
+{
+	__shared__ MachSharedT<K2B_NT> sh;
+	__shared__ float sgrey[3 * 257];
+	__shared__ unsigned s_pref[65];
+	const int tid = threadIdx.x;
+	const int nsc = p.nstreams * VDL2_CS;
+	if (p.force_serial)
+		return;
+	for (int i = tid; i < 257; i += K2B_NT) {
+		sgrey[i] = d_tab(c_grey1, i);
+		sgrey[257 + i] = d_tab(c_grey2, i);
+		sgrey[514 + i] = d_tab(c_grey3, i);
+	}
+	mach_init_taps(sh);
+	/* blockIdx.y selects a group of up to 64 (stream, channel) slots; exclusive prefix of the
+	 * group's cluster counts maps a ticket to (slot, primary candidate) */
+	const int sc0 = (int)blockIdx.y * 64;
+	const int nsc64 = (nsc - sc0) < 64 ? (nsc - sc0) : 64;
+	if (tid == 0) {
+		unsigned acc = 0;
+		for (int k = 0; k < nsc64; ++k) {
+			unsigned n = p.ctl[CTL_NPRIM0 + sc0 + k];
+			n = n > VDL2_CAND_CAP ? VDL2_CAND_CAP : n;
+			if (p.round > 0 && p.fail[sc0 + k] >= VDL2_VERIFIED)
+				n = 0;
+			s_pref[k] = acc;
+			acc += n;
+		}
+		s_pref[nsc64] = acc;
+	}
+	__syncthreads();
+	const unsigned total = s_pref[nsc64];
+	for (unsigned tk = blockIdx.x; tk < total; tk += gridDim.x) {
+		int scl = 0;
+		while (scl + 1 < nsc64 && s_pref[scl + 1] <= tk)
+			++scl;
+		const int sc = sc0 + scl;
+		const int idx = (int)p.prim[(size_t)sc * VDL2_CAND_CAP + (tk - s_pref[scl])];
+		const int s = sc / VDL2_CS, c = sc % VDL2_CS;
+		MachCtx cx;
+		mach_ctx(cx, p, s, c, true);
+		const Cand cd = p.cands[(size_t)sc * VDL2_CAND_CAP + idx];
+		Cluster *cl = p.clusters + (size_t)sc * VDL2_CAND_CAP + idx;
+		MachState st;
+		st.pos = cx.dec_base + cd.nrel;
+		st.r = cd.r;
+		st.fresh = VDL2_STEADY;
+		cx.grey = sgrey;
+		cx.desc_static = ((long long)sc * VDL2_CAND_CAP + idx) * VDL2_CL_MAXB;
+		MachOut out;
+		out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+		out.neval = 0;
+#pragma unroll
+		for (int i = 0; i < VDL2_CL_MAXB; ++i)
+			out.slots[i] = 0;
+		const long long t0 = wall_clock64();
+		mach_materialize<K2B_NT, true>(sh, cx, st.pos, st.r);
+		const long long t1 = wall_clock64();
+		const int rc = machine_run<K2B_NT, true>(sh, cx, st, true, 1, VDL2_CL_MAXB, 1, out);
+		const long long t2 = wall_clock64();
+		if (tid == 0 && p.dbg && (tk & 15u) == 0) {
+			atomicAdd(p.dbg + 0, (unsigned long long)(t1 - t0));
+			atomicAdd(p.dbg + 1, (unsigned long long)(t2 - t1));
+			atomicAdd(p.dbg + 2, 1ull);
+			atomicAdd(p.dbg + 3, (unsigned long long)out.ntrig);
+			atomicAdd(p.dbg + 4, (unsigned long long)out.neval);
+			atomicMax(p.dbg + 5, (unsigned long long)(t2 - t1));
+			atomicAdd(p.dbg + 6, (unsigned long long)(rc == MR_STEADY));
+			atomicAdd(p.dbg + 7, (unsigned long long)out.nrej);
+		}
+		int status;
+		if (rc == MR_STEADY)
+			status = CL_STEADY;
+		else if (rc == MR_DEFER && out.ntrig == 0)
+			status = CL_DEFER_FIRST;
+		else
+			status = CL_NONSTEADY;
+		bool bad = false;
+#pragma unroll
+		for (int i = 0; i < VDL2_CL_MAXB; ++i)
+			if (i < out.nslots && out.slots[i] < 0)
+				bad = true;	/* descriptor pool full */
+		if (bad)
+			status = CL_INVALID;
+		if (status == CL_NONSTEADY)
+			mach_store(sh, st, &cl->saved);
+		if (tid == 0)	/* descriptors sit in static slots desc_static + i: the head only needs their number */
+			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] =
+			    cl_pack((int)(st.pos - cx.dec_base), status, st.r, out.nslots < VDL2_CL_MAXB ? out.nslots : VDL2_CL_MAXB,
+				    out.ntrig, out.nrej, out.nburst);
+		__syncthreads();
+	}
+}
+
+/* ====================================================================== K2c
+ * Resolver: one workgroup per VDL channel follows the real chain of events.
+ * While the detector is history-free the next event is simply the first
+ * candidate of the current (sub-phase, sample parity) at or after `pos`, and
+ * its consequences were precomputed by K2b; otherwise the serial machine runs
+ * until the detector is history-free again.
+ *   1. rank-sort the channel's candidates by time                 (parallel)
+ *   2. for every candidate: status + index of the candidate that  (parallel)
+ *      follows its cluster  -> successor table in LDS
+ *   3. walk the chain through the successor table                 (one lane, LDS only)
+ *   4. mark the staged bursts of the visited clusters, add counters (parallel)
+ */
+#define K2C_NOCAND 0xffffu
+
+/* first sorted candidate at/after stream-relative time `want` of class (r, parity), from `from` */
+__device__ __forceinline__ int k2c_next(const int *skey, int ncand, int from, int want, int r)
+{
+	/* lower bound on time */
+	int lo = from, hi = ncand;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if ((skey[mid] >> 2) < want)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	for (; lo < ncand; ++lo) {
+		const int k = skey[lo];
+		if ((k & 3) == r && (((k >> 2) - want) & 1) == 0)
+			return lo;
+	}
+	return -1;
+}
+
+__global__ __launch_bounds__(K2_NT)
+void k2c_resolve(K2Params p)
+{
+	__shared__ MachSharedT<K2_NT> sh;
+	__shared__ int skey[VDL2_CAND_CAP];		/* sorted keys: nrel*4 + r */
+	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
+	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
+	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
+	__shared__ uint8_t ssel[VDL2_CAND_CAP];		/* visited by the real chain */
+	__shared__ int2 shead[VDL2_CAND_CAP];		/* cl_pack() of every candidate's cluster, by sorted rank */
+	__shared__ int s_walk[4];
+	__shared__ int s_cnt[4];
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	if (p.round > 0) {
+		if (p.fail[sc] >= VDL2_VERIFIED)
+			return;		/* verified in the first pass: nothing to repair */
+		__syncthreads();
+		if (tid == 0) {
+			p.redo[sc] = 1;
+			atomicAdd(p.outc_total_redo + 1, 1u);	/* channel-pushes that went through a repair round */
+			if (p.dbg)
+				atomicAdd(p.dbg + 24, 1ull);
+			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
+			p.ctl[CTL_NSEL0 + sc] = 0;
+			p.ctl[CTL_NSEG0 + sc] = 0;
+		}
+		__syncthreads();
+	}
+	const ChanState *cs = p.cs + sc;	/* input state: left untouched until K2f commits */
+	ChanState *cs_out = p.cs_out + sc;
+	unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
+	unsigned *nsel = p.ctl + CTL_NSEL0 + sc;
+	Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
+	unsigned *nseg = p.ctl + CTL_NSEG0 + sc;
+	MachCtx cx;
+	mach_ctx(cx, p, s, c, true);	/* bursts of serial stretches become descriptors too */
+	cx.sel = sel;
+	cx.nsel = nsel;
+	cx.dbg = nullptr;
+	MachState st;
+	st.pos = cs->pos;
+	st.r = cs->r;
+	st.fresh = cs->fresh;
+	const int r_probe = cs->r;
+	const int par_probe = (int)(cs->pos & 1);	/* the probe scanned class (r_probe, par_probe) everywhere */
+	const int t_end = (int)(cx.avail_end - cx.dec_base);
+	const bool lazy = !p.full_scan;
+	mach_init_taps(sh);
+	mach_load(sh, cs);
+	MachOut out;
+	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.neval = 0;
+	unsigned long long n_slow = 0;
+	int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	const bool tables_ok = !p.force_serial && ncand <= VDL2_CAND_CAP && p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] == 0;
+	if (!tables_ok)
+		ncand = 0;
+	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
+	/* 1. candidates sorted by time (K2s) */
+	const long long pos_in = st.pos;
+	const long long tk0 = wall_clock64();
+	{
+		const int2 *head = p.clhead + (size_t)sc * VDL2_CAND_CAP;
+		for (int i = tid; i < ncand; i += K2_NT) {
+			const int idx = p.sidx[(size_t)sc * VDL2_CAND_CAP + i];
+			skey[i] = p.skey[(size_t)sc * VDL2_CAND_CAP + i];
+			sidx[i] = (unsigned short)idx;
+			shead[i] = head[idx];
+		}
+	}
+	__syncthreads();
+	const long long tk1 = wall_clock64();
+	/* 2. successor table */
+	for (int j = tid; j < ncand; j += K2_NT) {
+		const int2 hd = shead[j];
+		const int status = hd.y & 3;
+		int nx = -1;
+		if (status == CL_STEADY)
+			nx = k2c_next(skey, ncand, j + 1, hd.x, (hd.y >> 2) & 3);
+		sstat[j] = (uint8_t)status;
+		snext[j] = (nx < 0) ? (unsigned short)K2C_NOCAND : (unsigned short)nx;
+		ssel[j] = 0;
+	}
+	__syncthreads();
+	const long long tk2 = wall_clock64();
+	bool steady_end = false;
+	for (;;) {
+		if (!tables_ok || st.fresh < VDL2_STEADY) {
+			/* history-dependent stretch (or no tables): serial machine */
+			const long long p0 = st.pos;
+			const int rc = machine_run<K2_NT, false>(sh, cx, st, tables_ok, 0, 1 << 30, 0, out);
+			n_slow += (unsigned long long)(st.pos - p0);
+			if (rc != MR_STEADY)
+				break;
+			continue;
+		}
+		/* 3. history-free: walk the successor table until something special happens */
+		if (tid == 0) {
+			int cur = k2c_next(skey, ncand, 0, (int)(st.pos - cx.dec_base), st.r);
+			int last = -1, why = 0;	/* why: 0 = no more candidates, 1 = special cluster at cur */
+			if (lazy && (st.r != r_probe || (int)(st.pos & 1) != par_probe)) {
+				/* the chain idles from here to the next candidate in a class the probe did not
+				 * scan: K2a-verify must confirm there really is nothing in between */
+				const unsigned q = atomicAdd(nseg, 1u);
+				if (q < VDL2_SEG_CAP) {
+					Seg g;
+					g.lo = (int)(st.pos - cx.dec_base);
+					g.hi = (cur >= 0) ? (skey[cur] >> 2) : t_end;
+					g.r = st.r;
+					g.pad = 0;
+					segs[q] = g;
+				} else
+					atomicMin(p.fail + sc, 0);
+			}
+			while (cur >= 0) {
+				const int stt = sstat[cur];
+				if (stt != CL_STEADY) {
+					why = 1;
+					break;
+				}
+				ssel[cur] = 1;
+				last = cur;
+				const int nx = snext[cur];
+				cur = (nx == K2C_NOCAND) ? -1 : nx;
+			}
+			s_walk[0] = cur;
+			s_walk[1] = last;
+			s_walk[2] = why;
+		}
+		__syncthreads();
+		const int cur = s_walk[0], last = s_walk[1], why = s_walk[2];
+		__syncthreads();
+		if (last >= 0) {
+			st.pos = cx.dec_base + shead[last].x;
+			st.r = (shead[last].y >> 2) & 3;
+		}
+		if (!why) {
+			/* idle to the end of the data: next evaluation is the first one past it */
+			const long long rem = (cx.avail_end - st.pos + 1) / 2;
+			if (rem > 0)
+				st.pos += 2 * rem;
+			steady_end = true;
+			break;
+		}
+		const long long ncand_t = cx.dec_base + (skey[cur] >> 2);
+		const Cluster *cl = clusters + sidx[cur];
+		const int status = sstat[cur];
+		if (status == CL_DEFER_FIRST) {
+			st.pos = ncand_t;
+			out.ndefer++;
+			steady_end = true;
+			break;
+		}
+		if (status == CL_INVALID) {
+			/* staging pool was full: replay this stretch here */
+			st.pos = ncand_t;
+			mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
+			const int rc = machine_run<K2_NT, false>(sh, cx, st, true, 1, 1 << 30, 1, out);
+			if (rc != MR_STEADY)
+				break;
+			continue;
+		}
+		/* CL_NONSTEADY: its bursts count, then continue from the explicit state it stopped in */
+		if (tid == 0)
+			ssel[cur] = 1;
+		mach_load(sh, &cl->saved);
+		st.pos = cl->saved.pos;
+		st.r = cl->saved.r;
+		st.fresh = cl->saved.fresh < VDL2_STEADY ? cl->saved.fresh : VDL2_STEADY - 1;
+	}
+	__syncthreads();
+	const long long tk3 = wall_clock64();
+	/* 4. publish the visited clusters: list positions come from LDS counters seeded with what the
+	 *    serial stretches and the walk already listed; the global counters are written once */
+	if (tid < 4)
+		s_cnt[tid] = 0;
+	if (tid == 0) {
+		s_walk[0] = (int)*nsel;
+		s_walk[1] = (int)*nseg;
+	}
+	__syncthreads();
+	{
+		int a = 0, b = 0, d = 0;
+		for (int j = tid; j < ncand; j += K2_NT)
+			if (ssel[j]) {
+				const int2 hd = shead[j];
+				const int ns = (hd.y >> 4) & 15;
+				/* K2b's descriptors sit in static slots: (candidate index) * VDL2_CL_MAXB + burst */
+				const unsigned slot0 = (unsigned)(((size_t)sc * VDL2_CAND_CAP + sidx[j]) * VDL2_CL_MAXB);
+				if (ns) {
+					const unsigned q = (unsigned)atomicAdd(&s_walk[0], ns);
+					for (int i = 0; i < ns; ++i) {
+						if (q + i < VDL2_SEL_CAP)
+							sel[q + i] = slot0 + i;
+						else
+							atomicAdd(p.outc + 1, 1u);
+					}
+				}
+				a += (hd.y >> 8) & 255;
+				b += (hd.y >> 16) & 255;
+				d += (hd.y >> 24) & 255;
+				const int r_s = (hd.y >> 2) & 3;
+				const long long n_s = cx.dec_base + hd.x;
+				if (lazy && sstat[j] == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe)) {
+					/* after this cluster the chain idles in class (r_s, parity of n_s) until
+					 * the successor's trigger (or the end of the data) */
+					const unsigned q = (unsigned)atomicAdd(&s_walk[1], 1);
+					if (q < VDL2_SEG_CAP) {
+						Seg g;
+						g.lo = hd.x;
+						g.hi = (snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2);
+						g.r = r_s;
+						g.pad = 0;
+						segs[q] = g;
+					} else
+						atomicMin(p.fail + sc, 0);
+				}
+			}
+		if (a)
+			atomicAdd(&s_cnt[0], a);
+		if (b)
+			atomicAdd(&s_cnt[1], b);
+		if (d)
+			atomicAdd(&s_cnt[2], d);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		*nsel = (unsigned)s_walk[0];
+		*nseg = (unsigned)s_walk[1];
+	}
+	__syncthreads();
+	if (steady_end) {
+		mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
+		st.fresh = VDL2_STEADY;
+	}
+	__syncthreads();
+	mach_store(sh, st, cs_out);
+	if (tid == 0) {
+		cs_out->n_eval = cs->n_eval + (unsigned long long)((st.pos - pos_in) / 2);	/* evaluation instants covered */
+		cs_out->n_trig = cs->n_trig + (unsigned long long)(out.ntrig + s_cnt[0]);
+		cs_out->n_reject = cs->n_reject + (unsigned long long)(out.nrej + s_cnt[1]);
+		cs_out->n_burst = cs->n_burst + (unsigned long long)(out.nburst + s_cnt[2]);
+		cs_out->n_defer = cs->n_defer + (unsigned long long)out.ndefer;
+		cs_out->n_slow = cs->n_slow + n_slow;
+		cs_out->n_cand = cs->n_cand + (unsigned long long)ncand;
+		cs_out->n_redo = cs->n_redo;
+		if (p.dbg) {
+			const long long tk4 = wall_clock64();
+			atomicAdd(p.dbg + 16, (unsigned long long)(tk1 - tk0));
+			atomicAdd(p.dbg + 17, (unsigned long long)(tk2 - tk1));
+			atomicAdd(p.dbg + 18, (unsigned long long)(tk3 - tk2));
+			atomicAdd(p.dbg + 19, (unsigned long long)(tk4 - tk3));
+			atomicAdd(p.dbg + 20, 1ull);
+		}
+	}
+}
+
+/* ====================================================================== K2f
+ * Commit.  If K2a-verify found nothing the resolver's result becomes the channel state.  If it
+ * found a detector hit the tables did not contain, the channel's push is redone from its input
+ * state by the serial machine alone (always exact; it writes its bursts itself) and the
+ * resolver's selection for that channel is dropped.
+ */
+__global__ __launch_bounds__(K2_NT)
+void k2f_commit(K2Params p)
+{
+	__shared__ MachSharedT<K2_NT> sh;
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	ChanState *cs = p.cs + sc;
+	if (p.fail[sc] >= VDL2_VERIFIED) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.cs_out + sc);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(cs);
+		for (int i = tid; i < (int)(sizeof(ChanState) / 4); i += K2_NT)
+			dst[i] = src[i];
+		return;
+	}
+	MachCtx cx;
+	mach_ctx(cx, p, s, c, false);
+	cx.dbg = nullptr;
+	MachState st;
+	st.pos = cs->pos;
+	st.r = cs->r;
+	st.fresh = cs->fresh;
+	const long long p0 = st.pos;
+	mach_init_taps(sh);
+	mach_load(sh, cs);
+	MachOut out;
+	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.neval = 0;
+	machine_run<K2_NT, false>(sh, cx, st, false, 0, 1 << 30, 0, out);
+	__syncthreads();
+	mach_store(sh, st, cs);
+	if (tid == 0) {
+		cs->n_eval += (unsigned long long)out.neval;
+		cs->n_trig += (unsigned long long)out.ntrig;
+		cs->n_reject += (unsigned long long)out.nrej;
+		cs->n_burst += (unsigned long long)out.nburst;
+		cs->n_defer += (unsigned long long)out.ndefer;
+		cs->n_slow += (unsigned long long)(st.pos - p0);
+		cs->n_redo += 1;
+		atomicAdd(p.outc_total_redo, 1u);
+		p.ctl[CTL_NSEL0 + sc] = 0;	/* K2d: nothing of the resolver's for this channel */
+	}
+}
+
+/* ====================================================================== K2d
+ * Payload decode of the bursts that lie on the real chain: one workgroup per
+ * selected burst descriptor, one lane per byte.
+ */
+#define K2D_NT 256
+#ifndef K2D_WAVES
+#define K2D_WAVES 2
+#endif
+__global__ __launch_bounds__(K2D_NT) __attribute__((amdgpu_waves_per_eu(K2D_WAVES, 8)))
+void k2d_payload(K2Params p)
+{
+	__shared__ unsigned s_slot;
+	__shared__ float sph[VDL2_MAXSYM];
+	const int sc = blockIdx.y;
+	unsigned n = p.ctl[CTL_NSEL0 + sc];
+	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
+	const unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
+	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+		if (threadIdx.x == 0) {
+			unsigned slot = atomicAdd(p.outc, 1u);
+			if (slot >= p.rec_cap) {
+				atomicAdd(p.outc + 1, 1u);
+				slot = 0xffffffffu;
+			}
+			s_slot = slot;
+		}
+		__syncthreads();
+		const unsigned slot = s_slot;
+		if (slot != 0xffffffffu) {
+			const BurstDesc d = p.stage[sel[i]];
+			const int s = d.sc / VDL2_CS;
+			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
+			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph);
+		}
+		__syncthreads();
+	}
+}
+
+#endif

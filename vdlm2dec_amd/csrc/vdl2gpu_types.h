@@ -1,0 +1,178 @@
+/* vdl2gpu_types.h -- types, parameters and constant tables of the device side.  Part of the device side of libvdl2gpu.so; included by vdl2gpu_kernels.h only. */
+#ifndef VDL2GPU_TYPES_H
+#define VDL2GPU_TYPES_H
+
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vdl2_math.h"
+#include "../../include/vdl2gpu.h"
+
+#define VDL2_CS 8		/* channel planes per stream */
+#define VDL2_HIST 160		/* frames of history kept: 17-tap FIR + 17 symbols x 8 + slack */
+#define VDL2_NPH 68		/* NBPH*D8DWN, vdlm2.h:54-55 */
+#define VDL2_STEADY 68		/* evaluations after which the detector forgot the last burst */
+#define VDL2_MAXSYM 5456	/* >= ceil((25 + 8*8*255)/3) symbols of the longest burst */
+#define VDL2_CARRY_FRAMES 49152	/* >= longest burst (43592 frames) + history + slack */
+#define VDL2_PN_BITS (16384 + 64)
+#define VDL2_CAND_CAP 4096	/* trigger candidates per channel per push */
+#define VDL2_CL_MAXB 4		/* bursts per cluster before the resolver takes over */
+#define VDL2_SEL_CAP 16384	/* bursts on the real chain per channel per push */
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+struct StreamState {
+	long long dec_base;	/* stream time (84 kS/s index) of frame 0 of the current planes */
+	long long dec_fill;	/* frames present before this push's K1 output */
+	long long last_fill;	/* diagnostics: where the last push's output starts */
+	long long last_J;
+	float2 acc[2][VDL2_CS];	/* integrate-and-dump partial sums carried across pushes */
+};
+
+struct ChanState {
+	long long pos;		/* stream time of the next WSYNC evaluation */
+	int r;			/* FIR sub-phase (channel_t.clk after the -=8), 0..3 */
+	int fresh;		/* evaluations since the last trigger/reset, saturating */
+	float perr, p2err, pfr;	/* channel_t.perr/p2err/pfr */
+	float ring[VDL2_NPH];	/* channel_t.Ph in time order, ring[67] newest */
+	unsigned long long n_eval, n_trig, n_reject, n_burst, n_defer, n_slow, n_cand, n_redo;
+};
+
+struct ChanCfg {
+	int chn, Fr, Fo, pad;
+};
+
+struct Cand {			/* free-running detector fires at dec_base + nrel with sub-phase r */
+	int nrel, r;
+	float p2err, perr, err, pfr;
+};
+
+enum { CL_STEADY = 0, CL_DEFER_FIRST = 1, CL_NONSTEADY = 2, CL_INVALID = 3 };
+struct Cluster {		/* what the resolver reads of a cluster is its 8-byte head (cl_pack); this is the rest */
+	ChanState saved;	/* CL_NONSTEADY: explicit state to continue from */
+};
+
+/* resolver's view of a cluster: x = n_s - dec_base, y = status | r_s << 2 | nslots << 4 | ntrig << 8 | nrej << 16 | nburst << 24 */
+__device__ __forceinline__ int2 cl_pack(int n_s_rel, int status, int r_s, int nslots, int ntrig, int nrej, int nburst)
+{
+	ntrig = ntrig > 255 ? 255 : ntrig;
+	nrej = nrej > 255 ? 255 : nrej;
+	nburst = nburst > 255 ? 255 : nburst;
+	return make_int2(n_s_rel, status | (r_s << 2) | (nslots << 4) | (ntrig << 8) | (nrej << 16) | (nburst << 24));
+}
+
+struct BurstDesc {		/* a burst found by a cluster; payload decoded later if it is on the real chain */
+	long long nstar;	/* stream time of the sync trigger */
+	int sc;			/* stream*8 + channel */
+	int clk0;		/* (int)roundf(of), d8psk.c:305 */
+	float df;
+	int nbrow, nlbyte, pad;
+};
+
+struct Seg {			/* the chain idled in class (r, parity of lo) over stream-relative [lo, hi) */
+	int lo, hi, r, pad;
+};
+
+struct K1Params {
+	const void *raw;
+	size_t stream_stride;
+	int fmt, nbch;
+	int sdrclk, L, maxwin;
+	int c0, no0, nf0, parity;
+	long long N, J;
+	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
+	long long per_lo, per_n;	/* fast kernel: whole 84-output periods [per_lo, per_lo+per_n) */
+	int per_pb;		/* periods per wavefront (chosen so that the waves fill the GPU evenly) */
+	const float2 *lo;	/* [S][8][L] */
+	float2 *dec;		/* this push's planes, [S][8][cap] */
+	long long cap;
+	StreamState *ss;
+};
+
+struct K2Params {
+	const float2 *dec;
+	long long cap;
+	int nbch, nstreams;
+	long long J;
+	StreamState *ss;
+	ChanState *cs;
+	const ChanCfg *cfg;
+	const uint8_t *pn;
+	Cand *cands;		/* [S*8][CAND_CAP] */
+	Cluster *clusters;	/* [S*8][CAND_CAP] */
+	int2 *clhead;		/* [S*8][CAND_CAP] what the resolver needs of every cluster, 8 bytes: see cl_pack() */
+	unsigned *ctl;		/* [0]=out count [1]=out overflow [2]=stage count [3]=k2b ticket [4]=stage overflow
+				 * [8 + S*8 ...] cand counts, then cand overflow flags */
+	BurstDesc *stage;	/* burst descriptors of all clusters */
+	unsigned *sel_list;	/* descriptors on the real chain (K2c -> K2d) */
+	unsigned stage_cap;
+	vdl2gpu_burst_t *recs;	/* output ring of this push */
+	unsigned *outc;		/* [0] = records written, [1] = records dropped (ring full) */
+	unsigned *outc_total_redo;	/* running count of serial redos (host adapts the number of repair rounds) */
+	unsigned rec_cap;
+	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
+	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
+	int test_noregion;	/* test hook: skip the region scan so that K2a-verify must catch the misses */
+	int2 *regs;		/* [S*8][REG_CAP] (lo, count) stream-relative */
+	Seg *segs;		/* [S*8][SEG_CAP] */
+	int *fail;		/* [S*8] earliest unexpected hit (stream-relative), >= VDL2_VERIFIED = verified */
+	int *redo;		/* [S*8] 1 = this channel is being re-resolved in the repair round */
+	int round;		/* 0 = first pass over every channel; 1 = repair pass over the channels whose
+				 * verify failed (the hits were appended to their candidate tables) */
+	ChanState *cs_out;	/* resolver result, committed by K2f */
+	int *skey;		/* [S*8][CAND_CAP] candidates sorted by time: nrel*4 + r */
+	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
+	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
+	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
+	unsigned long long *dbg;	/* diagnostics: cycle counters */
+};
+#define CTL_OUT 0
+#define CTL_OUT_OVF 1
+#define CTL_STAGE 2
+#define CTL_TICKET 3
+#define CTL_STAGE_OVF 4
+#define CTL_CAND0 8		/* [S*8] candidate counts, [S*8] overflow flags, then: */
+#define CTL_NREG0 (CTL_CAND0 + 2 * p.nstreams * VDL2_CS)
+#define CTL_NSEG0 (CTL_CAND0 + 3 * p.nstreams * VDL2_CS)
+#define CTL_NSEL0 (CTL_CAND0 + 4 * p.nstreams * VDL2_CS)
+#define CTL_NPRIM0 (CTL_CAND0 + 5 * p.nstreams * VDL2_CS)
+#define CTL_NSEED0 (CTL_CAND0 + 6 * p.nstreams * VDL2_CS)
+
+struct K3Params {
+	const float2 *src;
+	float2 *dst;
+	long long cap;
+	int nbch;
+	long long J;
+	StreamState *ss;
+	const ChanState *cs;
+	const unsigned *outc;	/* device counters: [2*ring] records, [2*ring+1] dropped, [4] serial redos so far */
+	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4], [5]: frame counters, written by k4_publish) */
+	int ring;
+};
+
+struct KInitParams {		/* per-push reset of the demodulator's control words */
+	unsigned *ctl;
+	int ctl_words;
+	unsigned *outc;		/* 2 words of this push's ring */
+	int *fail, *redo;
+	int nsc;
+};
+
+/* ---- constant data tables (d8psk.h:20-249) as bit patterns ------------- */
+#define VDL2_TABLE_BEGIN(name, n) __constant__ uint32_t c_##name[n] = {
+#define VDL2_F32(x) x,
+#define VDL2_TABLE_END };
+#include "vdl2_tables.inc"
+#undef VDL2_TABLE_BEGIN
+#undef VDL2_F32
+#undef VDL2_TABLE_END
+
+/* parity-check columns of the (25,20) header code (data, viterbi.c:29-35) */
+__constant__ int c_hcol[25] = { 6, 7, 9, 10, 11, 12, 14, 15, 17, 19, 21, 22, 24, 25, 26, 27, 28, 29, 30, 31,
+	16, 8, 4, 2, 1
+};
+
+#endif
