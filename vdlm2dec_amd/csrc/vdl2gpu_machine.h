@@ -325,6 +325,133 @@ template <int NT, bool XL> __device__ __forceinline__ void mach_materialize(Mach
 	__syncthreads();
 }
 
+/* What a sync trigger at stream time nstar sets in motion (d8psk.c:292-306, 77-116): one-shot timing
+ * estimate from the three fit errors around the minimum, carrier estimate df = previous slope, the nine
+ * header symbols, the (25,20) Viterbi decode, burst geometry.  Needs no detector history beyond those
+ * four numbers -- which is what lets K2b take them from the scan's candidate record. */
+struct MachTrig {
+	long long nsym0;	/* stream time of burst symbol 0 */
+	float df;
+	int clk0, rb;		/* (int)roundf(of); FIR sub-phase of the burst */
+	int accepted, nbrow, nlbyte, nsym;
+	bool defer;		/* header or burst not completely inside the data held */
+};
+
+template <int NT, bool XL> __device__ MachTrig mach_trigger(MachSharedT<NT> &sh, MachCtx &cx, long long nstar,
+							     float p2err, float perr, float err, float pfr)
+{
+	const int tid = threadIdx.x;
+	if (tid == 0) {
+		/* parabolic interpolation of the error minimum, d8psk.c:303-305 */
+		const float of = 4.0f * (p2err - 4.0f * perr + 3.0f * err) / (p2err - 2.0f * perr + err);
+		int clk0 = (int)roundf(of);
+		if (clk0 < 0)
+			clk0 = 0;	/* unreachable for finite inputs: of is in [4,12] */
+		if (clk0 > 68)
+			clk0 = 68;
+		int j0, rb0;
+		burst_timing(clk0, &j0, &rb0);
+		sh.ctl[0] = clk0;
+		sh.ctl[1] = j0;
+		sh.ctl[2] = rb0;
+		sh.fctl[0] = pfr;	/* df = pfr, d8psk.c:301 */
+	}
+	__syncthreads();
+	const int clk0 = sh.ctl[0], j0 = sh.ctl[1], rb = sh.ctl[2];
+	const float df = sh.fctl[0];
+	const long long nsym0 = nstar + j0;	/* stream time of burst symbol 0 */
+	bool defer = (nsym0 + 64 >= cx.avail_end);	/* 9 header symbols must be present */
+	int accepted = 0, nbrow = 0, nlbyte = 0, nsym = 0;
+	if (!defer) {
+		mach_need<NT, XL>(sh, cx, nstar - 16, nsym0 + 65);
+		if (tid < 9)
+			sh.psym[tid] = mach_fir<NT, XL>(sh, cx, nsym0 + 8 * tid, rb);
+		if (tid == 9)
+			sh.fctl[1] = mach_fir<NT, XL>(sh, cx, nstar, clk0);	/* P1 */
+		__syncthreads();
+		if (tid < 25) {
+			const int k = tid / 3;
+			const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
+			const int idx = k2_grey_index(sh.psym[k], pprev, df);
+			float v = mach_soft_bit(cx, idx, tid % 3, (int)((VDL2_PN_HEAD >> tid) & 1u));
+			if (tid < 3)
+				v = 0.0f;	/* reserved bits forced, d8psk.c:81-82 */
+			sh.hsoft[tid] = v;
+		}
+		__syncthreads();
+		if (tid < 64) {
+			/* (25,20) code, 32 syndrome states = 32 lanes (viterbi.c:46-78).
+			 * Target state t has two candidates: bit 0 from state t, bit 1
+			 * from state t^H[n]; the reference visits sources in ascending
+			 * order and replaces a survivor only by a strictly larger metric. */
+			const int t = tid & 31;
+			double pb = (t == 0) ? 1.0 : 0.0;
+			for (int n = 0; n < 25; ++n) {
+				const double v = (double)sh.hsoft[n];
+				const int src1 = t ^ c_hcol[n];
+				const double pb1 = __shfl(pb, src1, 32);
+				const double m0 = pb * (1.0 - v);
+				const double m1 = pb1 * v;
+				const bool has0 = (pb != 0.0), has1 = (pb1 != 0.0);
+				double nv = 0.0;
+				int nb = 0, ns = 0;
+				if (t < src1) {
+					if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
+					if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
+				} else {
+					if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
+					if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
+				}
+				if (tid < 32) {
+					sh.vbk[n + 1][t] = (uint8_t)ns;
+					sh.vbv[n + 1][t] = (uint8_t)nb;
+				}
+				pb = nv;
+			}
+		}
+		__syncthreads();
+		if (tid == 0) {
+			unsigned word = 0, mask = 1;
+			int sv = 0;
+			for (int n = 25; n > 0; --n) {
+				if (sh.vbv[n][sv])
+					word |= mask;
+				sv = sh.vbk[n][sv];
+				mask <<= 1;
+			}
+			word >>= 5;	/* drop the 5 parity bits, d8psk.c:90 */
+			unsigned len = 0;
+			for (int i = 0; i < 17; ++i)
+				len |= ((word >> i) & 1u) << (16 - i);	/* reversebits(.,17) */
+			const int nbr = (int)(len / 1992u) + 1;
+			const int nlb = (int)((len % 1992u + 7u) / 8u);
+			sh.ctl[3] = (len >= 96u && nbr <= 8) ? 1 : 0;
+			sh.ctl[4] = nbr;
+			sh.ctl[5] = nlb;
+		}
+		__syncthreads();
+		accepted = sh.ctl[3];
+		nbrow = sh.ctl[4];
+		nlbyte = sh.ctl[5];
+		if (accepted) {
+			nsym = burst_geom(nbrow, nlbyte).nsym;
+			if (nsym0 + 8LL * (nsym - 1) >= cx.avail_end)
+				defer = true;
+		}
+	}
+	MachTrig tg;
+	tg.nsym0 = nsym0;
+	tg.df = df;
+	tg.clk0 = clk0;
+	tg.rb = rb;
+	tg.accepted = accepted;
+	tg.nbrow = nbrow;
+	tg.nlbyte = nlbyte;
+	tg.nsym = nsym;
+	tg.defer = defer;
+	return tg;
+}
+
 /* stop_steady: return MR_STEADY as soon as the detector is history-free and at least
  * `min_trig` triggers were handled.  first_nev: size of the first search window (a hint). */
 template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachCtx &cx, MachState &st, bool stop_steady,
@@ -388,105 +515,11 @@ template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachC
 		}
 		/* ---- sync trigger at evaluation ts (stream time nstar) */
 		const long long nstar = pos + 2LL * ts;
-		if (tid == 0) {
-			const float p2err = sh.errs[ts], perr = sh.errs[ts + 1], err = sh.errs[ts + 2];
-			/* parabolic interpolation of the error minimum, d8psk.c:303-305 */
-			const float of = 4.0f * (p2err - 4.0f * perr + 3.0f * err) / (p2err - 2.0f * perr + err);
-			int clk0 = (int)roundf(of);
-			if (clk0 < 0)
-				clk0 = 0;	/* unreachable for finite inputs: of is in [4,12] */
-			if (clk0 > 68)
-				clk0 = 68;
-			int j0, rb0;
-			burst_timing(clk0, &j0, &rb0);
-			sh.ctl[0] = clk0;
-			sh.ctl[1] = j0;
-			sh.ctl[2] = rb0;
-			sh.fctl[0] = sh.frs[ts];	/* df = pfr, d8psk.c:301 */
-		}
-		__syncthreads();
-		const int clk0 = sh.ctl[0], j0 = sh.ctl[1], rb = sh.ctl[2];
-		const float df = sh.fctl[0];
-		const long long nsym0 = nstar + j0;	/* stream time of burst symbol 0 */
-		bool defer = (nsym0 + 64 >= cx.avail_end);	/* 9 header symbols must be present */
-		int accepted = 0, nbrow = 0, nlbyte = 0, nsym = 0;
-		if (!defer) {
-			mach_need<NT, XL>(sh, cx, nstar - 16, nsym0 + 65);
-			if (tid < 9)
-				sh.psym[tid] = mach_fir<NT, XL>(sh, cx, nsym0 + 8 * tid, rb);
-			if (tid == 9)
-				sh.fctl[1] = mach_fir<NT, XL>(sh, cx, nstar, clk0);	/* P1 */
-			__syncthreads();
-			if (tid < 25) {
-				const int k = tid / 3;
-				const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
-				const int idx = k2_grey_index(sh.psym[k], pprev, df);
-				float v = mach_soft_bit(cx, idx, tid % 3, (int)((VDL2_PN_HEAD >> tid) & 1u));
-				if (tid < 3)
-					v = 0.0f;	/* reserved bits forced, d8psk.c:81-82 */
-				sh.hsoft[tid] = v;
-			}
-			__syncthreads();
-			if (tid < 64) {
-				/* (25,20) code, 32 syndrome states = 32 lanes (viterbi.c:46-78).
-				 * Target state t has two candidates: bit 0 from state t, bit 1
-				 * from state t^H[n]; the reference visits sources in ascending
-				 * order and replaces a survivor only by a strictly larger metric. */
-				const int t = tid & 31;
-				double pb = (t == 0) ? 1.0 : 0.0;
-				for (int n = 0; n < 25; ++n) {
-					const double v = (double)sh.hsoft[n];
-					const int src1 = t ^ c_hcol[n];
-					const double pb1 = __shfl(pb, src1, 32);
-					const double m0 = pb * (1.0 - v);
-					const double m1 = pb1 * v;
-					const bool has0 = (pb != 0.0), has1 = (pb1 != 0.0);
-					double nv = 0.0;
-					int nb = 0, ns = 0;
-					if (t < src1) {
-						if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
-						if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
-					} else {
-						if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
-						if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
-					}
-					if (tid < 32) {
-						sh.vbk[n + 1][t] = (uint8_t)ns;
-						sh.vbv[n + 1][t] = (uint8_t)nb;
-					}
-					pb = nv;
-				}
-			}
-			__syncthreads();
-			if (tid == 0) {
-				unsigned word = 0, mask = 1;
-				int sv = 0;
-				for (int n = 25; n > 0; --n) {
-					if (sh.vbv[n][sv])
-						word |= mask;
-					sv = sh.vbk[n][sv];
-					mask <<= 1;
-				}
-				word >>= 5;	/* drop the 5 parity bits, d8psk.c:90 */
-				unsigned len = 0;
-				for (int i = 0; i < 17; ++i)
-					len |= ((word >> i) & 1u) << (16 - i);	/* reversebits(.,17) */
-				const int nbr = (int)(len / 1992u) + 1;
-				const int nlb = (int)((len % 1992u + 7u) / 8u);
-				sh.ctl[3] = (len >= 96u && nbr <= 8) ? 1 : 0;
-				sh.ctl[4] = nbr;
-				sh.ctl[5] = nlb;
-			}
-			__syncthreads();
-			accepted = sh.ctl[3];
-			nbrow = sh.ctl[4];
-			nlbyte = sh.ctl[5];
-			if (accepted) {
-				nsym = burst_geom(nbrow, nlbyte).nsym;
-				if (nsym0 + 8LL * (nsym - 1) >= cx.avail_end)
-					defer = true;
-			}
-		}
+		const MachTrig tg = mach_trigger<NT, XL>(sh, cx, nstar, sh.errs[ts], sh.errs[ts + 1], sh.errs[ts + 2], sh.frs[ts]);
+		const int clk0 = tg.clk0, rb = tg.rb, accepted = tg.accepted, nbrow = tg.nbrow, nlbyte = tg.nlbyte, nsym = tg.nsym;
+		const float df = tg.df;
+		const long long nsym0 = tg.nsym0;
+		const bool defer = tg.defer;
 		if (defer) {
 			/* the burst is not completely inside the data we hold: commit the
 			 * evaluations before the trigger and retry on the next push */
