@@ -36,8 +36,14 @@
 #define K2A_WL 192		/* screened-in evaluations per tile and sub-phase; more than that and the tile is done in pieces */
 #endif
 #define VDL2_REG_CAP 1024	/* probe-hit regions per channel per push */
-#define VDL2_REG_PAD 40		/* samples scanned on either side of a probe hit */
-#define VDL2_REG_GAP 96		/* hits closer than this share a region */
+#ifndef VDL2_REG_PAD
+#define VDL2_REG_PAD 40
+#endif
+//		/* samples scanned on either side of a probe hit */
+#ifndef VDL2_REG_GAP
+#define VDL2_REG_GAP 96
+#endif
+//		/* hits closer than this share a region */
 #define VDL2_SEG_CAP 4096	/* verify segments per channel per push */
 #define VDL2_VERIFIED 0x7f000000	/* fail[] values at or above this mean: nothing unexpected found */
 #define VDL2_SEED_ERR 7.0f	/* probe fit error below which a neighbourhood is scanned in every class
