@@ -463,10 +463,10 @@ void k2a_probe(K2Params p)
 
 /* ---- workgroup sort of up to VDL2_CAND_CAP 64-bit keys whose top bits are a time stamp.
  * Detector events are spread over the push (a few per burst, bursts are sparse), so a bucket
- * sort on time -- histogram, scan, scatter, then a short insertion sort inside each bucket -- needs
+ * sort on time -- histogram, scan, scatter, then ranking inside each bucket -- needs
  * about a dozen barriers where a bitonic network needs log^2(n)/2 = 78.  A push whose events
  * pile up in one bucket (more than WGS_MAXB) falls back to the bitonic network.
- *   keys[] in/out (LDS), tmp[] scratch (LDS), both VDL2_CAND_CAP long; time = key >> tshift, < range. */
+ *   keys[] in/out (LDS), all different; tmp[] scratch (LDS), both VDL2_CAND_CAP long; time = key >> tshift, < range. */
 #define WGS_NBK 2048
 #define WGS_MAXB 48
 struct WgSortShared {
@@ -562,21 +562,19 @@ template <int NT> __device__ void wg_sort_u64(unsigned long long *keys, WgSortSh
 		ws.tmp[atomicAdd(&ws.cur[b], 1u)] = v;
 	}
 	__syncthreads();
-	for (int b = tid; b < WGS_NBK; b += NT) {
+	/* inside a bucket: every key finds its rank by counting the smaller ones (keys are unique; a burst puts
+	 * a dozen or two into one bucket, so this is a handful of independent LDS reads per key where an
+	 * insertion sort by one lane would be a long dependent chain) */
+	for (int i = tid; i < n; i += NT) {
+		const unsigned long long v = ws.tmp[i];
+		unsigned b = (unsigned)(v >> tshift) >> bsh;
+		b = b < WGS_NBK ? b : WGS_NBK - 1;
 		const int lo = (int)ws.start[b], hi = (int)ws.start[b + 1];
-		for (int i = lo + 1; i < hi; ++i) {
-			const unsigned long long v = ws.tmp[i];
-			int j = i - 1;
-			while (j >= lo && ws.tmp[j] > v) {
-				ws.tmp[j + 1] = ws.tmp[j];
-				--j;
-			}
-			ws.tmp[j + 1] = v;
-		}
+		int rank = 0;
+		for (int j = lo; j < hi; ++j)
+			rank += (ws.tmp[j] < v) ? 1 : 0;
+		keys[lo + rank] = v;
 	}
-	__syncthreads();
-	for (int i = tid; i < n; i += NT)
-		keys[i] = ws.tmp[i];
 	__syncthreads();
 }
 
@@ -598,12 +596,12 @@ void k2r_regions(K2Params p)
 	int ncand = (int)p.ctl[CTL_NSEED0 + sc];
 	ncand = ncand > VDL2_CAND_CAP ? VDL2_CAND_CAP : ncand;
 	const int *seeds = p.seeds + (size_t)sc * VDL2_CAND_CAP;
-	for (int i = tid; i < ncand; i += K2R_NT)
-		key64[i] = (unsigned long long)(unsigned)seeds[i];
+	for (int i = tid; i < ncand; i += K2R_NT)	/* the index makes equal instants distinct keys (the sort ranks keys) */
+		key64[i] = ((unsigned long long)(unsigned)seeds[i] << 16) | (unsigned)i;
 	__syncthreads();
-	wg_sort_u64<K2R_NT>(key64, ws, ncand, 0, (unsigned)(p.ss[s].dec_fill + p.J));
+	wg_sort_u64<K2R_NT>(key64, ws, ncand, 16, (unsigned)(p.ss[s].dec_fill + p.J));
 	for (int i = tid; i < ncand; i += K2R_NT)
-		key[i] = (int)key64[i];
+		key[i] = (int)(key64[i] >> 16);
 	__syncthreads();
 	{
 		/* every run of hits closer than VDL2_REG_GAP becomes a region (order is irrelevant) */
