@@ -91,6 +91,10 @@ struct vdl2gpu {
 	hipStream_t k1_stream = nullptr;	/* channeliser of push N+1 runs beside the demodulator of push N */
 	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
 	bool k2_rec[2] = {false, false};
+	hipStream_t pay_stream = nullptr;	/* K2d beside the verify pass (when no repair rounds are scheduled) */
+	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
+	unsigned *d_fmask = nullptr;	/* K2f's redo mask of the push in flight, 16 words */
+	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
 	double k1_split = 0.25;		/* share of the channeliser launched at k2_mid_a, the rest at k2_mid */
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
@@ -120,7 +124,7 @@ struct vdl2gpu {
 	size_t fready_pos = 0;
 	uint64_t frames_dropped = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
-	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [8*ring + {0..5}] */
+	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase / k4_publish: [24*ring + {0..5}] counters, [24*ring + 8 ..] redo mask */
 	unsigned *d_pin_cnt = nullptr;	/* its device address */
 	unsigned pin_recs = 0;
 	std::string err;
@@ -283,6 +287,15 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	}
 	if (h->k2_mid)
 		(void)hipEventDestroy(h->k2_mid);
+	if (h->pay_stream) {
+		(void)hipStreamSynchronize(h->pay_stream);
+		(void)hipStreamDestroy(h->pay_stream);
+	}
+	if (h->k2c_done)
+		(void)hipEventDestroy(h->k2c_done);
+	if (h->pay_done)
+		(void)hipEventDestroy(h->pay_done);
+	(void)hipFree(h->d_fmask);
 	if (h->k2_mid_a)
 		(void)hipEventDestroy(h->k2_mid_a);
 	if (h->k1_stream)
@@ -366,6 +379,11 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
 	}
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid, hipEventDisableTiming));
+	HIPCHK(h, hipStreamCreateWithFlags(&h->pay_stream, hipStreamNonBlocking));
+	HIPCHK(h, hipEventCreateWithFlags(&h->k2c_done, hipEventDisableTiming));
+	HIPCHK(h, hipEventCreateWithFlags(&h->pay_done, hipEventDisableTiming));
+	HIPCHK(h, hipMalloc(&h->d_fmask, 16 * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_fmask, 0, 16 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid_a, hipEventDisableTiming));
 	if (getenv("VDL2GPU_K1_SPLIT"))
 		h->k1_split = atof(getenv("VDL2GPU_K1_SPLIT"));
@@ -393,8 +411,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 16 * sizeof(unsigned), hipHostMallocMapped));
-	memset(h->h_pin_cnt, 0, 16 * sizeof(unsigned));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 48 * sizeof(unsigned), hipHostMallocMapped));
+	memset(h->h_pin_cnt, 0, 48 * sizeof(unsigned));
 	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
 	if (h->frames_on) {
 		h->frame_cap = std::min<unsigned>(h->rec_cap, 16384u);
@@ -714,6 +732,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		ki.fail = h->d_fail;
 		ki.redo = h->d_redo;
 		ki.nsc = h->S * VDL2_CS;
+		ki.fmask = h->d_fmask;
 		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, h->stream, ki);
 	}
 	HIPCHK(h, hipStreamWaitEvent(h->stream, h->k1_done[par], 0));
@@ -740,6 +759,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.recs = h->d_recs[ring];
 		k2.outc = h->d_outc + 2 * ring;
 		k2.outc_total_redo = h->d_outc + 4;
+		k2.fmask = h->d_fmask;
 		k2.rec_cap = h->rec_cap;
 		k2.force_serial = h->force_serial;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
@@ -779,6 +799,17 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		h->k2_mid_rec = true;
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
+		/* With no repair round scheduled the resolver's selection is final unless the verify pass fails
+		 * (then K2f redoes the channel and the host drops what K2d made of it, see harvest_ring): decode
+		 * the payloads beside the verify pass instead of behind it. */
+		const bool spec = h->repair_rounds == 0 && !h->full_scan && !h->force_serial && !h->frames_on && h->S * VDL2_CS <= 512;
+		h->ring_spec[ring] = spec;
+		if (spec) {
+			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
+			HIPCHK(h, hipStreamWaitEvent(h->pay_stream, h->k2c_done, 0));
+			hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
+			HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
+		}
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
 		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
@@ -802,7 +833,10 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
-		hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
+		if (h->ring_spec[ring])
+			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
+		else
+			hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->frames_on) {
 			/* block path on the records where they lie (vdlm2.c:84-161), on its own stream: nothing
@@ -819,7 +853,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			HIPCHK(h, hipStreamWaitEvent(h->blk_stream, h->recs_done, 0));
 			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 2 * ring, 0, 2 * sizeof(unsigned), h->blk_stream));
 			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->blk_stream, k4);
-			hipLaunchKernelGGL(k4_publish, dim3(1), dim3(64), 0, h->blk_stream, h->d_fcnt + 2 * ring, h->d_pin_cnt + 8 * ring);
+			hipLaunchKernelGGL(k4_publish, dim3(1), dim3(64), 0, h->blk_stream, h->d_fcnt + 2 * ring, h->d_pin_cnt + 24 * ring);
 			HIPCHK(h, hipGetLastError());
 			HIPCHK(h, hipEventRecord(h->frames_done[ring], h->blk_stream));
 		}
@@ -836,7 +870,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k3.ss = h->d_ss;
 		k3.cs = h->d_cs;
 		k3.outc = h->d_outc;
-		k3.host_cnt = h->d_pin_cnt + 8 * ring;
+		k3.fmask = h->d_fmask;
+		k3.host_cnt = h->d_pin_cnt + 24 * ring;
 		k3.ring = ring;
 		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
@@ -894,14 +929,14 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
 	if (h->frames_on)
 		HIPCHK(h, hipEventSynchronize(h->frames_done[ring]));
-	const unsigned c0 = h->h_pin_cnt[8 * ring], c1 = h->h_pin_cnt[8 * ring + 1];
+	const unsigned c0 = h->h_pin_cnt[24 * ring], c1 = h->h_pin_cnt[24 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
 	{
 		/* repair rounds only cost launches while nothing fails, so: none until the first verify
 		 * failure shows up (as a serial redo), then as many as it takes to get rid of the serial
 		 * redos, and back down one at a time after long quiet stretches */
-		const unsigned redos = h->h_pin_cnt[8 * ring + 2], repairs = h->h_pin_cnt[8 * ring + 3];
+		const unsigned redos = h->h_pin_cnt[24 * ring + 2], repairs = h->h_pin_cnt[24 * ring + 3];
 		if (redos != h->redos_seen) {
 			h->redos_seen = redos;
 			h->last_redo_push = h->ring_push[ring];
@@ -929,6 +964,27 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			HIPCHK(h, hipStreamSynchronize(h->copy_stream));
 			memcpy(h->ready.data() + old + done, h->h_pin, (size_t)m * sizeof(vdl2gpu_burst_t));
 		}
+		if (h->ring_spec[ring]) {
+			/* K2d ran ahead of the verify pass: for a channel that K2f then redid serially, its records
+			 * (trig_sample == 0 on the device) are void; K2f's own (== 1) are the channel's bursts */
+			const unsigned *mask = h->h_pin_cnt + 24 * ring + 8;
+			bool any = false;
+			for (int i = 0; i < 16; ++i)
+				any = any || mask[i] != 0;
+			if (any) {
+				size_t w = old;
+				for (size_t i = old; i < h->ready.size(); ++i) {
+					const vdl2gpu_burst_t &b = h->ready[i];
+					const unsigned sc = (unsigned)b.end_sample;
+					if (b.trig_sample == 0 && sc < 512 && (mask[sc >> 5] >> (sc & 31) & 1u))
+						continue;
+					if (w != i)
+						h->ready[w] = b;
+					++w;
+				}
+				h->ready.resize(w);
+			}
+		}
 		const size_t iold = h->ready_idx.size();
 		for (size_t i = old; i < h->ready.size(); ++i) {
 			vdl2gpu_burst_t &b = h->ready[i];
@@ -949,8 +1005,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		});
 	}
 	if (h->frames_on) {
-		const unsigned nf = std::min(h->h_pin_cnt[8 * ring + 4], h->frame_cap);
-		h->frames_dropped += h->h_pin_cnt[8 * ring + 5];
+		const unsigned nf = std::min(h->h_pin_cnt[24 * ring + 4], h->frame_cap);
+		h->frames_dropped += h->h_pin_cnt[24 * ring + 5];
 		if (nf) {
 			if (h->fready_pos == h->fready_idx.size()) {
 				h->fready.clear();

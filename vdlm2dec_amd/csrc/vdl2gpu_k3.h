@@ -48,6 +48,8 @@ __global__ void k_push_init(KInitParams p)
 	}
 	if (threadIdx.x < 2)
 		p.outc[threadIdx.x] = 0u;
+	if (threadIdx.x < 16)
+		p.fmask[threadIdx.x] = 0u;
 }
 
 /* runs after k3_compact (same stream): publish the new time base and hand the push's counters to the host */
@@ -61,6 +63,8 @@ __global__ void k3_rebase(K3Params p)
 		p.host_cnt[1] = p.outc[2 * p.ring + 1];
 		p.host_cnt[2] = p.outc[4];
 		p.host_cnt[3] = p.outc[5];
+		for (int i = 0; i < 16; ++i)
+			p.host_cnt[8 + i] = p.fmask[i];
 	}
 	StreamState *ss = p.ss + s;
 	long long mn = 0x7fffffffffffffffLL;

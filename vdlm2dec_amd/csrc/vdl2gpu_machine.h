@@ -64,7 +64,8 @@ __device__ __forceinline__ void burst_timing(int clk0, int *j0, int *rb)
  * have no LDS to spare) each byte lane computes the four or five phases it needs itself. */
 #define VDL2_MAXSYM 5456	/* symbols 7 .. (25 + 8 * 2040 - 1) / 3 */
 template <int NT> __device__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
-						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph = nullptr)
+						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph = nullptr,
+						  int tag = 1, int slot = 0)
 {
 	const int tid = threadIdx.x;
 	int j0, rb;
@@ -134,8 +135,9 @@ template <int NT> __device__ void burst_payload(vdl2gpu_burst_t *rec, const floa
 		rec->ppm = 0.0f;	/* host: d8psk.c:302 needs libm double math */
 		rec->trig_dec = nstar;
 		rec->end_dec = nsym0 + 8LL * (g.nsym - 1);
-		rec->trig_sample = 0;
-		rec->end_sample = 0;
+		rec->trig_sample = tag;	/* device-side use of the two host-filled fields: 0 = decoded by K2d from the resolver's
+					 * selection (the host drops these for a channel that K2f then redid), 1 = final */
+		rec->end_sample = slot;	/* stream * 8 + channel slot */
 	}
 }
 

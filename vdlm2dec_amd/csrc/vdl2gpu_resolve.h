@@ -507,7 +507,9 @@ void k2f_commit(K2Params p)
 		cs->n_slow += (unsigned long long)(st.pos - p0);
 		cs->n_redo += 1;
 		atomicAdd(p.outc_total_redo, 1u);
-		p.ctl[CTL_NSEL0 + sc] = 0;	/* K2d: nothing of the resolver's for this channel */
+		p.ctl[CTL_NSEL0 + sc] = 0;	/* K2d: nothing of the resolver's for this channel ... */
+		if (p.fmask && sc < 512)	/* ... and if K2d ran ahead of the verify pass, the host drops what it made of it */
+			atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
 	}
 }
 
@@ -543,7 +545,7 @@ void k2d_payload(K2Params p)
 			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
-			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph);
+			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, 0, d.sc);
 		}
 		__syncthreads();
 	}

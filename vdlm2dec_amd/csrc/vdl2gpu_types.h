@@ -111,6 +111,7 @@ struct K2Params {
 	vdl2gpu_burst_t *recs;	/* output ring of this push */
 	unsigned *outc;		/* [0] = records written, [1] = records dropped (ring full) */
 	unsigned *outc_total_redo;	/* running count of serial redos (host adapts the number of repair rounds) */
+	unsigned *fmask;	/* [16] bit per (stream, channel slot) that K2f redid serially in this push */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
 	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
@@ -149,6 +150,7 @@ struct K3Params {
 	StreamState *ss;
 	const ChanState *cs;
 	const unsigned *outc;	/* device counters: [2*ring] records, [2*ring+1] dropped, [4] serial redos so far */
+	const unsigned *fmask;	/* K2f's redo mask of this push (16 words) */
 	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4], [5]: frame counters, written by k4_publish) */
 	int ring;
 };
@@ -159,6 +161,7 @@ struct KInitParams {		/* per-push reset of the demodulator's control words */
 	unsigned *outc;		/* 2 words of this push's ring */
 	int *fail, *redo;
 	int nsc;
+	unsigned *fmask;	/* 16 words */
 };
 
 /* ---- constant data tables (d8psk.h:20-249) as bit patterns ------------- */
