@@ -194,7 +194,8 @@ int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks, int n,
 /* With VDL2GPU_F_FRAMES the same kernel runs on every push's burst records where they lie in device
  * memory, right behind the demodulator.  Collect the frames of everything pushed so far (waits like
  * vdl2gpu_poll; the bursts themselves stay available through vdl2gpu_poll).  Frames come out ordered
- * by (end_dec, stream, chn, seq); `block` is meaningless here.  Returns the count or a negative error. */
+ * by (end_dec, stream, chn, seq); `block` is -1 here, and of data[] only [0, len) is written.  Returns the
+ * count or a negative error. */
 int vdl2gpu_poll_frames(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max);
 /* Same, but never waits (like vdl2gpu_poll_ready). */
 int vdl2gpu_poll_frames_ready(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max);

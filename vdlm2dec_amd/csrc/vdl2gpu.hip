@@ -114,17 +114,16 @@ struct vdl2gpu {
 	size_t ready_pos = 0;
 	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
 	bool frames_on = false;
-	vdl2gpu_frame_t *d_frames[2] = {nullptr, nullptr};
-	unsigned *d_fcnt = nullptr;	/* [2*ring] frames written, [2*ring+1] dropped */
-	unsigned frame_cap = 0;
-	hipStream_t blk_stream = nullptr;	/* the block kernel runs beside the next push's demodulator */
-	hipEvent_t recs_done = nullptr, frames_done[2] = {nullptr, nullptr};
-	std::vector<vdl2gpu_frame_t> fready;	/* storage order */
-	std::vector<uint32_t> fready_idx;	/* hand-out order, consumed from fready_pos */
+	vdl2gpu_frame_t *d_frames[2] = {nullptr, nullptr};	/* byte buffers of compact entries */
+	unsigned *d_fcnt = nullptr;	/* [4*ring] frames written, [4*ring+1] dropped, [4*ring+2] bytes used */
+	unsigned frame_cap = 0;	/* bytes of a frame buffer (compact entries) */
+
+	std::vector<uint8_t> fready;		/* compact frame entries as k4_frames wrote them, storage order */
+	std::vector<uint32_t> fready_idx;	/* hand-out order: byte offsets into `fready`, consumed from fready_pos */
 	size_t fready_pos = 0;
 	uint64_t frames_dropped = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
-	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase / k4_publish: [24*ring + {0..5}] counters, [24*ring + 8 ..] redo mask */
+	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [24*ring + {0..6}] counters, [24*ring + 8 ..] redo mask */
 	unsigned *d_pin_cnt = nullptr;	/* its device address */
 	unsigned pin_recs = 0;
 	std::string err;
@@ -264,15 +263,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_frames[0]);
 	(void)hipFree(h->d_frames[1]);
 	(void)hipFree(h->d_fcnt);
-	if (h->blk_stream) {
-		(void)hipStreamSynchronize(h->blk_stream);
-		(void)hipStreamDestroy(h->blk_stream);
-	}
-	if (h->recs_done)
-		(void)hipEventDestroy(h->recs_done);
-	for (auto &e : h->frames_done)
-		if (e)
-			(void)hipEventDestroy(e);
 	(void)hipFree(h->d_outc);
 	for (auto &e : h->ring_done)
 		if (e)
@@ -415,15 +405,11 @@ static int create_impl(vdl2gpu_t *h)
 	memset(h->h_pin_cnt, 0, 48 * sizeof(unsigned));
 	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
 	if (h->frames_on) {
-		h->frame_cap = std::min<unsigned>(h->rec_cap, 16384u);
+		h->frame_cap = 16u << 20;	/* bytes: compact entries, about 100 bytes per frame */
 		for (int r = 0; r < 2; ++r)
-			HIPCHK(h, hipMalloc(&h->d_frames[r], (size_t)h->frame_cap * sizeof(vdl2gpu_frame_t)));
-		HIPCHK(h, hipMalloc(&h->d_fcnt, 4 * sizeof(unsigned)));
-		HIPCHK(h, hipStreamCreateWithFlags(&h->blk_stream, hipStreamNonBlocking));
-		HIPCHK(h, hipEventCreateWithFlags(&h->recs_done, hipEventDisableTiming));
-		for (int r = 0; r < 2; ++r)
-			HIPCHK(h, hipEventCreateWithFlags(&h->frames_done[r], hipEventDisableTiming));
-		HIPCHK(h, hipMemsetAsync(h->d_fcnt, 0, 4 * sizeof(unsigned), h->stream));
+			HIPCHK(h, hipMalloc((void **)&h->d_frames[r], (size_t)h->frame_cap));
+		HIPCHK(h, hipMalloc(&h->d_fcnt, 8 * sizeof(unsigned)));
+		HIPCHK(h, hipMemsetAsync(h->d_fcnt, 0, 8 * sizeof(unsigned), h->stream));
 	}
 	HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pin_cnt, h->h_pin_cnt, 0));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
@@ -839,23 +825,21 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->frames_on) {
-			/* block path on the records where they lie (vdlm2.c:84-161), on its own stream: nothing
-			 * further down this push's chain needs the frames */
+			/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
+			 * a latency-bound kernel like this one and the next push's scan slow each other down by
+			 * more than the overlap saves. */
 			K4Params k4{};
 			k4.recs = h->d_recs[ring];
 			k4.nrecs_dev = h->d_outc + 2 * ring;
 			k4.rec_cap = h->rec_cap;
 			k4.frames = h->d_frames[ring];
-			k4.nframes = h->d_fcnt + 2 * ring;
+			k4.nframes = h->d_fcnt + 4 * ring;
 			k4.frame_cap = h->frame_cap;
+			k4.compact = 1;
 			k4.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
-			HIPCHK(h, hipEventRecord(h->recs_done, h->stream));
-			HIPCHK(h, hipStreamWaitEvent(h->blk_stream, h->recs_done, 0));
-			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 2 * ring, 0, 2 * sizeof(unsigned), h->blk_stream));
-			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->blk_stream, k4);
-			hipLaunchKernelGGL(k4_publish, dim3(1), dim3(64), 0, h->blk_stream, h->d_fcnt + 2 * ring, h->d_pin_cnt + 24 * ring);
+			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 4 * ring, 0, 4 * sizeof(unsigned), h->stream));
+			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->stream, k4);
 			HIPCHK(h, hipGetLastError());
-			HIPCHK(h, hipEventRecord(h->frames_done[ring], h->blk_stream));
 		}
 	}
 	if (h->stage_events)
@@ -871,6 +855,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k3.cs = h->d_cs;
 		k3.outc = h->d_outc;
 		k3.fmask = h->d_fmask;
+		k3.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
 		k3.host_cnt = h->d_pin_cnt + 24 * ring;
 		k3.ring = ring;
 		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
@@ -917,18 +902,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			return VDL2GPU_EHIP;
 		}
 	}
-	if (h->frames_on && !blocking) {
-		const hipError_t q = hipEventQuery(h->frames_done[ring]);
-		if (q == hipErrorNotReady)
-			return 1;
-		if (q != hipSuccess) {
-			h->err = std::string("hipEventQuery: ") + hipGetErrorString(q);
-			return VDL2GPU_EHIP;
-		}
-	}
 	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
-	if (h->frames_on)
-		HIPCHK(h, hipEventSynchronize(h->frames_done[ring]));
 	const unsigned c0 = h->h_pin_cnt[24 * ring], c1 = h->h_pin_cnt[24 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
@@ -1005,34 +979,40 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		});
 	}
 	if (h->frames_on) {
-		const unsigned nf = std::min(h->h_pin_cnt[24 * ring + 4], h->frame_cap);
+		const unsigned nf = h->h_pin_cnt[24 * ring + 4];
+		const unsigned nbytes = std::min(h->h_pin_cnt[24 * ring + 6], h->frame_cap);
 		h->frames_dropped += h->h_pin_cnt[24 * ring + 5];
-		if (nf) {
+		if (nf && nbytes) {
 			if (h->fready_pos == h->fready_idx.size()) {
 				h->fready.clear();
 				h->fready_idx.clear();
 				h->fready_pos = 0;
 			}
 			const size_t old = h->fready.size();
-			h->fready.resize(old + nf);
-			const unsigned per = (unsigned)(((size_t)h->pin_recs * sizeof(vdl2gpu_burst_t)) / sizeof(vdl2gpu_frame_t));
-			for (unsigned done = 0; done < nf; done += per) {
-				const unsigned m = std::min(per, nf - done);
-				HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_frames[ring] + done, (size_t)m * sizeof(vdl2gpu_frame_t),
-							 hipMemcpyDeviceToHost, h->copy_stream));
+			h->fready.resize(old + nbytes);
+			const size_t pin_bytes = (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t);
+			for (size_t done = 0; done < nbytes; done += pin_bytes) {
+				const size_t m = std::min(pin_bytes, (size_t)nbytes - done);
+				HIPCHK(h, hipMemcpyAsync(h->h_pin, (const char *)h->d_frames[ring] + done, m, hipMemcpyDeviceToHost, h->copy_stream));
 				HIPCHK(h, hipStreamSynchronize(h->copy_stream));
-				memcpy(h->fready.data() + old + done, h->h_pin, (size_t)m * sizeof(vdl2gpu_frame_t));
+				memcpy(h->fready.data() + old + done, h->h_pin, m);
 			}
+			/* walk the entries (56 header bytes + len data bytes, rounded up to 8) */
 			const size_t iold = h->fready_idx.size();
-			for (size_t i = old; i < h->fready.size(); ++i) {
-				vdl2gpu_frame_t &f = h->fready[i];
-				f.ppm = (float)((double)(10500.0f * f.df) / (2.0 * M_PI * (double)f.Fr) * 1e6);	/* d8psk.c:302 */
-				f.block = -1;
-				h->fready_idx.push_back((uint32_t)i);
+			const size_t hdr = offsetof(vdl2gpu_frame_t, data);
+			for (size_t off = old; off + hdr <= h->fready.size();) {
+				vdl2gpu_frame_t *f = reinterpret_cast<vdl2gpu_frame_t *>(h->fready.data() + off);
+				if (f->len < 0 || f->len > VDL2GPU_MAXFRAME || off + hdr + (size_t)f->len > h->fready.size())
+					break;
+				f->ppm = (float)((double)(10500.0f * f->df) / (2.0 * M_PI * (double)f->Fr) * 1e6);	/* d8psk.c:302 */
+				f->block = -1;
+				h->fready_idx.push_back((uint32_t)off);
+				off += (hdr + (size_t)f->len + 7) & ~(size_t)7;
 			}
-			const vdl2gpu_frame_t *fd = h->fready.data();
+			const uint8_t *fd = h->fready.data();
 			std::sort(h->fready_idx.begin() + iold, h->fready_idx.end(), [fd](uint32_t x, uint32_t y) {
-				const vdl2gpu_frame_t &a = fd[x], &b = fd[y];
+				const vdl2gpu_frame_t &a = *reinterpret_cast<const vdl2gpu_frame_t *>(fd + x);
+				const vdl2gpu_frame_t &b = *reinterpret_cast<const vdl2gpu_frame_t *>(fd + y);
 				if (a.end_dec != b.end_dec)
 					return a.end_dec < b.end_dec;
 				if (a.stream != b.stream)
@@ -1094,11 +1074,11 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 	if (e == hipSuccess)
 		e = hipMalloc(&d_fr, (size_t)max_frames * sizeof(vdl2gpu_frame_t));
 	if (e == hipSuccess)
-		e = hipMalloc(&d_cnt, 2 * sizeof(unsigned));
+		e = hipMalloc(&d_cnt, 4 * sizeof(unsigned));
 	if (e == hipSuccess)
 		e = hipMemcpy(d_blk, blocks, (size_t)n * sizeof(vdl2gpu_burst_t), hipMemcpyHostToDevice);
 	if (e == hipSuccess)
-		e = hipMemset(d_cnt, 0, 2 * sizeof(unsigned));
+		e = hipMemset(d_cnt, 0, 4 * sizeof(unsigned));
 	unsigned cnt[2] = {0, 0};
 	if (e == hipSuccess) {
 		K4Params k4{};
@@ -1109,6 +1089,7 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		k4.frames = d_fr;
 		k4.nframes = d_cnt;
 		k4.frame_cap = (unsigned)max_frames;
+		k4.compact = 0;
 		const unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
 		hipLaunchKernelGGL(k4_frames, dim3(grid), dim3(K4_NT), 0, h->copy_stream, k4);
 		e = hipGetLastError();
@@ -1146,8 +1127,11 @@ static int poll_frames_impl(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max, bool bl
 	if (rc)
 		return rc;
 	const int n = std::min<int>(max, (int)(h->fready_idx.size() - h->fready_pos));
-	for (int i = 0; i < n; ++i)
-		out[i] = h->fready[h->fready_idx[h->fready_pos + i]];
+	for (int i = 0; i < n; ++i) {	/* only what is meaningful of the record: its head and data[0..len) */
+		const uint8_t *e = h->fready.data() + h->fready_idx[h->fready_pos + i];
+		const vdl2gpu_frame_t *f = reinterpret_cast<const vdl2gpu_frame_t *>(e);
+		memcpy(&out[i], e, offsetof(vdl2gpu_frame_t, data) + (size_t)f->len);
+	}
 	h->fready_pos += (size_t)n;
 	return n;
 }

@@ -33,8 +33,10 @@ struct K4Params {
 	unsigned nrecs;
 	unsigned rec_cap;
 	vdl2gpu_frame_t *frames;
-	unsigned *nframes;		/* [0] frames written, [1] frames dropped (ring full) */
-	unsigned frame_cap;
+	unsigned *nframes;		/* [0] frames written, [1] frames dropped (buffer full), [2] bytes used (compact) */
+	unsigned frame_cap;		/* records, or bytes if compact */
+	int compact;			/* 0: an array of vdl2gpu_frame_t; 1: entries of 56 header bytes (the struct's head) +
+					 * len data bytes, each rounded up to 8 bytes -- a frame is rarely longer than 100 bytes */
 	unsigned long long *dbg;	/* diagnostics: stage cycle counters, or nullptr */
 };
 
@@ -519,17 +521,28 @@ void k4_frames(K4Params p)
 			const int q = sh.ctl[2 + f];
 			const int len = q - m1 + 2;
 			if (lane == 0) {
-				unsigned slot = atomicAdd(p.nframes, 1u);
-				if (slot >= p.frame_cap) {
-					atomicAdd(p.nframes + 1, 1u);
-					slot = 0xffffffffu;
+				unsigned slot;
+				if (p.compact) {
+					const unsigned sz = (unsigned)((offsetof(vdl2gpu_frame_t, data) + len + 7) & ~7);
+					slot = atomicAdd(p.nframes + 2, sz);	/* byte offset */
+					if (slot + sz > p.frame_cap) {
+						atomicAdd(p.nframes + 1, 1u);
+						slot = 0xffffffffu;
+					} else
+						atomicAdd(p.nframes, 1u);
+				} else {
+					slot = atomicAdd(p.nframes, 1u);
+					if (slot >= p.frame_cap) {
+						atomicAdd(p.nframes + 1, 1u);
+						slot = 0xffffffffu;
+					}
 				}
 				sh.ctl[0] = (int)slot;
 			}
 			__syncthreads();
 			const unsigned slot = (unsigned)sh.ctl[0];
 			if (slot != 0xffffffffu) {
-				vdl2gpu_frame_t *fr = p.frames + slot;
+				vdl2gpu_frame_t *fr = p.compact ? reinterpret_cast<vdl2gpu_frame_t *>(reinterpret_cast<char *>(p.frames) + slot) : p.frames + slot;
 				if (lane == 0) {
 					fr->stream = rec->stream;
 					fr->chn = rec->chn;
@@ -564,15 +577,6 @@ void k4_frames(K4Params p)
 		}
 	}
 #undef K4_STAMP
-}
-
-/* runs behind k4_frames on its stream: hand the frame counters of the push to the host (mapped memory) */
-__global__ void k4_publish(const unsigned *fcnt, unsigned *host_cnt)
-{
-	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		host_cnt[4] = fcnt[0];
-		host_cnt[5] = fcnt[1];
-	}
 }
 
 #endif

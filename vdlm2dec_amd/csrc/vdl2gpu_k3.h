@@ -63,6 +63,8 @@ __global__ void k3_rebase(K3Params p)
 		p.host_cnt[1] = p.outc[2 * p.ring + 1];
 		p.host_cnt[2] = p.outc[4];
 		p.host_cnt[3] = p.outc[5];
+		for (int i = 0; i < 3; ++i)
+			p.host_cnt[4 + i] = p.fcnt ? p.fcnt[i] : 0u;
 		for (int i = 0; i < 16; ++i)
 			p.host_cnt[8 + i] = p.fmask[i];
 	}

@@ -151,7 +151,8 @@ struct K3Params {
 	const ChanState *cs;
 	const unsigned *outc;	/* device counters: [2*ring] records, [2*ring+1] dropped, [4] serial redos so far */
 	const unsigned *fmask;	/* K2f's redo mask of this push (16 words) */
-	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4], [5]: frame counters, written by k4_publish) */
+	const unsigned *fcnt;	/* block path in the pipeline (VDL2GPU_F_FRAMES): frames, dropped, bytes; else nullptr */
+	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4..6]: frame counters) */
 	int ring;
 };
 
