@@ -96,7 +96,9 @@ struct vdl2gpu {
 	unsigned *d_fmask = nullptr;	/* K2f's redo mask of the push in flight, 16 words */
 	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
-	double k1_split = 0.25;		/* share of the channeliser launched at k2_mid_a, the rest at k2_mid */
+	double k1_split = 0.0;		/* share of the channeliser launched already at k2_mid_a (beside the candidate sort), the rest at
+					 * k2_mid (beside the resolver).  Measured: no throughput difference between 0 and 0.4, and one
+					 * launch keeps k1_fast's own time lower, so 0; VDL2GPU_K1_SPLIT overrides */
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
 	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted 0..4 from how often the serial fallback was needed */
