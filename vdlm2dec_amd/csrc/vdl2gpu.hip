@@ -691,8 +691,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 				}
 				(void)hipEventRecord(ev1, ks);
 			};
-			/* Two launches, placed beside the two stretches of the previous push's demodulator chain
-			 * that run one workgroup per channel (candidate sort; resolver) and leave the GPU idle */
+			/* One launch beside the previous push's resolver, or (k1_split > 0) a first share already beside
+			 * its candidate sort: the stretches of the demodulator chain that run one workgroup per channel */
 			const long long per_all = periods - 2;
 			long long per_a = (long long)((double)per_all * h->k1_split);
 			per_a = (h->k2_mid_rec && per_all >= 64) ? std::min(per_a, per_all - 1) : 0;
