@@ -103,46 +103,6 @@ template <int STRIDE> __device__ __forceinline__ float k2_sync_metric(const floa
 	return err;
 }
 
-/* Screening form of the fit error for the scan kernels.  It takes exactly the same unwrap
- * decisions as k2_sync_metric (pc and pd are the same float operations) but counts turns and
- * applies them as turns * 2pi in one fused step instead of rounding Pu through double after
- * every turn, and it may fuse/reassociate the regression.  With the decisions equal, the two
- * differ only by rounding: |Pr - Pr'| < 8e-5 per point (16 roundings of Pu at |Pu| < 128 plus
- * one ulp), |M - M'|, 8|fr - fr'| < 1e-3, so for an exact error below 4 (every residual < 2)
- * |err - err'| < 2 * sqrt(17 * 4) * 1.2e-3 < 0.02.  The scan therefore treats
- * err' >= VDL2_SCREEN_ERR (4.25) as proof that the exact error is >= 4 and recomputes every
- * instant below it, and its two neighbours, with k2_sync_metric. */
-#define VDL2_SCREEN_ERR 4.25f
-template <int STRIDE> __device__ __forceinline__ float k2_sync_metric_screen(const float *ph)
-{
-	const float pi_lo = __uint_as_float(VDL2_PI_BELOW);
-	const float two_pi = 6.28318530717958647692f;
-	float pr[17];
-	float pv = ph[0] - d_tab(c_sw, 0);
-	float turns = 0.0f, sum = pv, sl = pv * -8.0f;
-	pr[0] = pv;
-#pragma unroll
-	for (int l = 1; l < 17; ++l) {
-		const float pc = ph[STRIDE * l] - d_tab(c_sw, l);
-		const float pd = pc - pv;
-		pv = pc;
-		const float k = (fabsf(pd) > pi_lo) ? copysignf(1.0f, pd) : 0.0f;
-		turns -= k;
-		pr[l] = __fmaf_rn(turns, two_pi, pc);
-		sum += pr[l];
-		sl = __fmaf_rn(pr[l], (float)(l - 8), sl);
-	}
-	const float mean = sum * (1.0f / 17.0f);
-	const float fr = sl * (1.0f / 408.0f);
-	float err = 0.0f;
-#pragma unroll
-	for (int l = 0; l < 17; ++l) {
-		const float e = __fmaf_rn((float)(8 - l), fr, pr[l] - mean);
-		err = __fmaf_rn(e, e, err);
-	}
-	return err;
-}
-
 /* differential slice of one symbol -> Grey table index (d8psk.c:213, 323-327) */
 __device__ __forceinline__ int k2_grey_index(float p, float pprev, float df)
 {
