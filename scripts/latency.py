@@ -13,7 +13,7 @@ RATE, FC, BLK = 2_000_000, 136_975_000, 32768
 nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 spec = synth.random_scenario(RATE, synth.DEFAULT_FO_8CH, nblk * BLK, seed=77, bursts_per_s=8.0, info_max=200)
 raw = synth.synth_stream(spec, "cu8")
-with Receiver(RATE, plan_channels(FC, spec.fo), fmt="cu8", max_push=BLK) as rx:
+with Receiver(RATE, plan_channels(FC, spec.fo), fmt="cu8", max_push=BLK, serial=bool(os.environ.get("SERIAL"))) as rx:
     for i in range(8):                                   # warm-up
         rx.push(raw[2 * i * BLK:2 * (i + 1) * BLK]); rx.poll()
     lat, nb = [], 0

@@ -749,7 +749,10 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.outc_total_redo = h->d_outc + 4;
 		k2.fmask = h->d_fmask;
 		k2.rec_cap = h->rec_cap;
-		k2.force_serial = h->force_serial;
+		/* A short push (a live SDR block is 1376 frames per channel) is cheaper on the serial machine alone
+		 * than through the scan's ten launches: the parallel path only pays from a few thousand frames on. */
+		const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !(h->cfg.flags & VDL2GPU_F_TEST_NOREGION));
+		k2.force_serial = serial ? 1 : 0;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
 		k2.full_scan = h->full_scan;
 		k2.test_noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) ? 1 : 0;
@@ -765,21 +768,25 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		k2.seeds = h->d_seeds;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
-		{
-			/* as many workgroups as are resident at once, each walking its share of the channel's tiles */
-			const unsigned want = h->full_scan ? tiles : tiles / 2 + 1;
-			unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * h->S - 1) / (h->C * h->S));
-			per = per < 1 ? 1 : (per > want ? want : per);
-			hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		if (!serial) {
+			{
+				/* as many workgroups as are resident at once, each walking its share of the channel's tiles */
+				const unsigned want = h->full_scan ? tiles : tiles / 2 + 1;
+				unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * h->S - 1) / (h->C * h->S));
+				per = per < 1 ? 1 : (per > want ? want : per);
+				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+			}
+			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2);
+			hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+			HIPCHK(h, hipGetLastError());
 		}
-		hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2);
-		hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
-		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipEventRecord(h->k2_mid_a, h->stream));
-		hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
+		if (!serial)
+			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
-		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
+		if (!serial)
+			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
@@ -790,7 +797,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		/* With no repair round scheduled the resolver's selection is final unless the verify pass fails
 		 * (then K2f redoes the channel and the host drops what K2d made of it, see harvest_ring): decode
 		 * the payloads beside the verify pass instead of behind it. */
-		const bool spec = h->repair_rounds == 0 && !h->full_scan && !h->force_serial && !h->frames_on && h->S * VDL2_CS <= 512;
+		const bool spec = h->repair_rounds == 0 && !h->full_scan && !serial && !h->frames_on && h->S * VDL2_CS <= 512;
 		h->ring_spec[ring] = spec;
 		if (spec) {
 			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
@@ -800,9 +807,10 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		}
 		if (h->stage_events)
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
-		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		if (!serial)
+			hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
-		if (!h->full_scan && !h->force_serial) {
+		if (!h->full_scan && !serial) {
 			/* repair round: channels whose verify found an unlisted hit are re-sorted, re-clustered,
 			 * re-resolved and re-verified with that hit in their table; every other channel's
 			 * workgroups exit at once.  What still fails is redone serially by K2f. */

@@ -13,6 +13,7 @@
 #define VDL2_NPH 68		/* NBPH*D8DWN, vdlm2.h:54-55 */
 #define VDL2_STEADY 68		/* evaluations after which the detector forgot the last burst */
 #define VDL2_MAXSYM 5456	/* >= ceil((25 + 8*8*255)/3) symbols of the longest burst */
+#define VDL2_SERIAL_BELOW 4096	/* pushes of at most this many 84 kS/s frames go to the serial machine directly */
 #define VDL2_CARRY_FRAMES 49152	/* >= longest burst (43592 frames) + history + slack */
 #define VDL2_PN_BITS (16384 + 64)
 #define VDL2_CAND_CAP 4096	/* trigger candidates per channel per push */
