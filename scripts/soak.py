@@ -1,0 +1,35 @@
+"""dev aid: randomised parity soak -- many seeds, rates, formats, push sizes; GPU bursts must equal the oracle's"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from vdlm2dec_amd import synth
+from vdlm2dec_amd.demod import Receiver, plan_channels
+from oracle import oracle as O
+
+FC = 136_975_000
+n_ok = n_bad = 0
+t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 120
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    rate = int(rng.choice([2_000_000, 2_000_000, 2_000_000, 5_000_000, 10_000_000]))
+    nch = int(rng.integers(1, 9))
+    fos = [int(f * rate / 2_000_000) // 25000 * 25000 for f in synth.DEFAULT_FO_8CH[:nch]]
+    fmt = str(rng.choice(["cs16", "cu8", "cs16"]))
+    ns = int(rng.integers(3, 14)) * 1_000_000 * (rate // 2_000_000 if rate > 2_000_000 else 1) // (2 if rate > 2_000_000 else 1)
+    dens = float(rng.choice([3.0, 8.0, 20.0, 40.0])) * rate / 2_000_000
+    spec = synth.random_scenario(rate, fos, ns, seed=seed, bursts_per_s=dens, info_max=int(rng.choice([60, 240, 900])),
+                                 )
+    raw = synth.synth_stream(spec, fmt)
+    want = sorted(b.key() for b in O.run_oracle(raw, fmt, rate, fos, FC))
+    block = int(rng.choice([ns, ns // 2 + 17, 1_234_567, 400_000, 2_000_000, 65536]))
+    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16)) as rx:
+        got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in rx.run(raw, block=block))
+        st = rx.stats()
+    ok = got == want
+    n_ok += ok; n_bad += (not ok)
+    print("seed %d rate %d ch %d %s ns %d dens %.0f block %d: %d bursts %s redos %d" % (seed, rate, nch, fmt, ns, dens, block, len(want), "OK" if ok else "MISMATCH", st["serial_redos"]), flush=True)
+    seed += 1
+print("soak: %d ok, %d bad" % (n_ok, n_bad))
+sys.exit(1 if n_bad else 0)
