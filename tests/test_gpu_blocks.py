@@ -108,3 +108,26 @@ def test_block_path_in_the_pipeline(built, oracle):
             bursts += rx.poll()
     assert sorted(frames) == sorted(want) and len(want) >= 8
     assert sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in bursts) == sorted(b.key() for b in ob)
+
+
+def test_frames_of_channels_redone_serially(built, oracle):
+    """The payload gather runs ahead of the verify pass; when that pass fails a channel, the serial redo
+    makes the channel's records again and the ones made ahead are void.  The block kernel must skip
+    them on the device (the records themselves are filtered on the host): every frame exactly once."""
+    from vdlm2dec_amd import lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = synth.random_scenario(2_000_000, S.FO8[:3], 1 << 21, seed=92, bursts_per_s=10.0, info_max=100)
+    raw = synth.synth_stream(spec, "cs16")
+    ob = oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC)
+    want = sorted((0, b.chn, f) for b in ob for f in oracle.frames_of_block(b.nbrow, b.nlbyte, b.data))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20, frames=True,
+                  flags=lib.F_TEST_NOREGION) as rx:
+        bursts, frames = [], []
+        for s0 in range(0, spec.nsamples, 600_000):
+            rx.push(raw[2 * s0:2 * (s0 + 600_000)])
+            frames += rx.poll_frames()
+            bursts += rx.poll()
+        st = rx.stats()
+    assert st["serial_redos"] > 0
+    assert sorted(frames) == want and len(want) >= 10
+    assert sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in bursts) == sorted(b.key() for b in ob)

@@ -117,8 +117,9 @@ struct vdl2gpu {
 	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
 	bool frames_on = false;
 	vdl2gpu_frame_t *d_frames[2] = {nullptr, nullptr};	/* byte buffers of compact entries */
+	unsigned *d_k4tab = nullptr;	/* GF(256) and FCS tables of the block path */
 	unsigned *d_fcnt = nullptr;	/* [4*ring] frames written, [4*ring+1] dropped, [4*ring+2] bytes used */
-	unsigned frame_cap = 0;	/* bytes of a frame buffer (compact entries) */
+	unsigned frame_cap = 0;	/* bytes of a frame buffer (slots + arena) */
 
 	std::vector<uint8_t> fready;		/* compact frame entries as k4_frames wrote them, storage order */
 	std::vector<uint32_t> fready_idx;	/* hand-out order: byte offsets into `fready`, consumed from fready_pos */
@@ -265,6 +266,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_frames[0]);
 	(void)hipFree(h->d_frames[1]);
 	(void)hipFree(h->d_fcnt);
+	(void)hipFree(h->d_k4tab);
 	(void)hipFree(h->d_outc);
 	for (auto &e : h->ring_done)
 		if (e)
@@ -406,8 +408,11 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 48 * sizeof(unsigned), hipHostMallocMapped));
 	memset(h->h_pin_cnt, 0, 48 * sizeof(unsigned));
 	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
+	HIPCHK(h, hipMalloc(&h->d_k4tab, K4_TABW * sizeof(unsigned)));
+	hipLaunchKernelGGL(k4_tables, dim3(1), dim3(64), 0, h->stream, h->d_k4tab);
+	HIPCHK(h, hipGetLastError());
 	if (h->frames_on) {
-		h->frame_cap = 16u << 20;	/* bytes: compact entries, about 100 bytes per frame */
+		h->frame_cap = h->rec_cap * K4_SLOT + (4u << 20);	/* bytes: a slot per record, and the arena (see K4Params) */
 		for (int r = 0; r < 2; ++r)
 			HIPCHK(h, hipMalloc((void **)&h->d_frames[r], (size_t)h->frame_cap));
 		HIPCHK(h, hipMalloc(&h->d_fcnt, 8 * sizeof(unsigned)));
@@ -721,6 +726,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		ki.redo = h->d_redo;
 		ki.nsc = h->S * VDL2_CS;
 		ki.fmask = h->d_fmask;
+		ki.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
 		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, h->stream, ki);
 	}
 	HIPCHK(h, hipStreamWaitEvent(h->stream, h->k1_done[par], 0));
@@ -797,7 +803,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 		/* With no repair round scheduled the resolver's selection is final unless the verify pass fails
 		 * (then K2f redoes the channel and the host drops what K2d made of it, see harvest_ring): decode
 		 * the payloads beside the verify pass instead of behind it. */
-		const bool spec = h->repair_rounds == 0 && !h->full_scan && !serial && !h->frames_on && h->S * VDL2_CS <= 512;
+		const bool spec = h->repair_rounds == 0 && !h->full_scan && !serial && h->S * VDL2_CS <= 512;
 		h->ring_spec[ring] = spec;
 		if (spec) {
 			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
@@ -846,9 +852,10 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 			k4.nframes = h->d_fcnt + 4 * ring;
 			k4.frame_cap = h->frame_cap;
 			k4.compact = 1;
+			k4.tabs = h->d_k4tab;
+			k4.fmask = h->ring_spec[ring] ? h->d_fmask : nullptr;
 			k4.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
-			HIPCHK(h, hipMemsetAsync(h->d_fcnt + 4 * ring, 0, 4 * sizeof(unsigned), h->stream));
-			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 8), dim3(K4_NT), 0, h->stream, k4);
+			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 16), dim3(K4_NT), 0, h->stream, k4);
 			HIPCHK(h, hipGetLastError());
 		}
 	}
@@ -989,27 +996,46 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		});
 	}
 	if (h->frames_on) {
-		const unsigned nf = h->h_pin_cnt[24 * ring + 4];
-		const unsigned nbytes = std::min(h->h_pin_cnt[24 * ring + 6], h->frame_cap);
+		const unsigned arena0 = h->rec_cap * K4_SLOT;
+		const unsigned nbytes = std::min(h->h_pin_cnt[24 * ring + 6], h->frame_cap - arena0);
 		h->frames_dropped += h->h_pin_cnt[24 * ring + 5];
-		if (nf && nbytes) {
+		if (n) {
 			if (h->fready_pos == h->fready_idx.size()) {
 				h->fready.clear();
 				h->fready_idx.clear();
 				h->fready_pos = 0;
 			}
 			const size_t old = h->fready.size();
-			h->fready.resize(old + nbytes);
+			const size_t hdr = offsetof(vdl2gpu_frame_t, data);
 			const size_t pin_bytes = (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t);
-			for (size_t done = 0; done < nbytes; done += pin_bytes) {
-				const size_t m = std::min(pin_bytes, (size_t)nbytes - done);
+			/* the records' slots: keep the occupied ones, packed like arena entries */
+			const size_t slot_bytes = (size_t)n * K4_SLOT;
+			for (size_t done = 0; done < slot_bytes; done += pin_bytes) {
+				const size_t m = std::min(pin_bytes, slot_bytes - done);
 				HIPCHK(h, hipMemcpyAsync(h->h_pin, (const char *)h->d_frames[ring] + done, m, hipMemcpyDeviceToHost, h->copy_stream));
 				HIPCHK(h, hipStreamSynchronize(h->copy_stream));
-				memcpy(h->fready.data() + old + done, h->h_pin, m);
+				const uint8_t *pin = reinterpret_cast<const uint8_t *>(h->h_pin);
+				for (size_t o = 0; o < m; o += K4_SLOT) {
+					const vdl2gpu_frame_t *f = reinterpret_cast<const vdl2gpu_frame_t *>(pin + o);
+					if (f->len <= 0 || hdr + (size_t)f->len > K4_SLOT)
+						continue;
+					const size_t sz = (hdr + (size_t)f->len + 7) & ~(size_t)7;
+					h->fready.insert(h->fready.end(), pin + o, pin + o + sz);
+				}
+			}
+			if (nbytes) {
+				const size_t at = h->fready.size();
+				h->fready.resize(at + nbytes);
+				for (size_t done = 0; done < nbytes; done += pin_bytes) {
+					const size_t m = std::min(pin_bytes, (size_t)nbytes - done);
+					HIPCHK(h, hipMemcpyAsync(h->h_pin, (const char *)h->d_frames[ring] + arena0 + done, m, hipMemcpyDeviceToHost,
+								 h->copy_stream));
+					HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+					memcpy(h->fready.data() + at + done, h->h_pin, m);
+				}
 			}
 			/* walk the entries (56 header bytes + len data bytes, rounded up to 8) */
 			const size_t iold = h->fready_idx.size();
-			const size_t hdr = offsetof(vdl2gpu_frame_t, data);
 			for (size_t off = old; off + hdr <= h->fready.size();) {
 				vdl2gpu_frame_t *f = reinterpret_cast<vdl2gpu_frame_t *>(h->fready.data() + off);
 				if (f->len < 0 || f->len > VDL2GPU_MAXFRAME || off + hdr + (size_t)f->len > h->fready.size())
@@ -1100,6 +1126,7 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		k4.nframes = d_cnt;
 		k4.frame_cap = (unsigned)max_frames;
 		k4.compact = 0;
+		k4.tabs = h->d_k4tab;
 		const unsigned grid = (unsigned)std::min<long long>(n, (long long)h->n_cu * 32);
 		hipLaunchKernelGGL(k4_frames, dim3(grid), dim3(K4_NT), 0, h->copy_stream, k4);
 		e = hipGetLastError();

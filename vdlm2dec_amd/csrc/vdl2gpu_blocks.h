@@ -26,6 +26,7 @@
 #define K4_NT 64
 #define K4_NOLOG 255
 #define K4_MAXBY (VDL2GPU_MAXROWS * 249)
+#define K4_SLOT 256
 
 struct K4Params {
 	const vdl2gpu_burst_t *recs;
@@ -33,32 +34,75 @@ struct K4Params {
 	unsigned nrecs;
 	unsigned rec_cap;
 	vdl2gpu_frame_t *frames;
-	unsigned *nframes;		/* [0] frames written, [1] frames dropped (buffer full), [2] bytes used (compact) */
+	unsigned *nframes;		/* [0] frames written (compact: to the arena), [1] frames dropped (buffer full),
+					 * [2] arena bytes used (compact) */
 	unsigned frame_cap;		/* records, or bytes if compact */
-	int compact;			/* 0: an array of vdl2gpu_frame_t; 1: entries of 56 header bytes (the struct's head) +
-					 * len data bytes, each rounded up to 8 bytes -- a frame is rarely longer than 100 bytes */
+	int compact;			/* 0: an array of vdl2gpu_frame_t.
+					 * 1: entries of 56 header bytes (the struct's head) + len data bytes.  Record i owns
+					 * the K4_SLOT bytes at i * K4_SLOT: the first frame of its burst goes there when it
+					 * fits (len 0: none) -- no allocation, because two thousand waves asking one
+					 * device-scope counter for space at the same moment cost more than the whole block
+					 * path; longer and further frames go to the arena behind rec_cap slots, entries
+					 * rounded up to 8 bytes, space taken from nframes[2] */
+	const unsigned *fmask;		/* channels redone serially (bit s*C+c): records tagged 0 of those are void, or nullptr */
 	unsigned long long *dbg;	/* diagnostics: stage cycle counters, or nullptr */
+	const unsigned *tabs;		/* K4_TABW words from k4_tables: gexp[512], glog[256], crc_tab[256] */
 };
 
+#define K4_TABW ((512 + 256 + 512) / 4)
+/* A block is one wavefront: its lanes meet at every instruction, LDS operations of a wave complete in
+ * order, and all a barrier has to do is keep the compiler from moving LDS accesses across it.  (A
+ * __syncthreads() would also wait for every global store in flight.) */
+static_assert(K4_NT == 64, "k4_frames is written for one wavefront per block");
+#define K4_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+		       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define K4_RECW ((int)(sizeof(vdl2gpu_burst_t) / 4))
+#define K4_RECW0 192	/* words of a record fetched before its header has been looked at: header + two rows */
+static_assert(offsetof(vdl2gpu_burst_t, data) % 4 == 0 && sizeof(vdl2gpu_burst_t) % 4 == 0, "rows are fetched as words");
+
 struct K4Shared {
-	uint8_t gexp[512], glog[256];
+	uint8_t gexp[512], glog[256];	/* these three in the order of K4Params.tabs */
 	unsigned short crc_tab[256];
-	uint8_t row[VDL2GPU_MAXROWS][256];	/* the burst's rows, corrected in place */
+	unsigned long long recw[(sizeof(vdl2gpu_burst_t) + 7) / 8];	/* the record; its rows are corrected in place */
 	uint8_t src[K4_MAXBY + 8];		/* data bytes of all rows, in order */
 	unsigned dst[(K4_MAXBY + 8) / 4 + 2];	/* un-stuffed bit stream */
-	int lsum[K4_NT][2];			/* per lane: all ones?, trailing ones */
-	int tin[K4_NT];				/* run of ones in front of the lane's first bit */
-	int kept[K4_NT + 1];			/* exclusive prefix of kept bits */
-	unsigned char lor[K4_NT + 1];		/* exclusive prefix OR of the lanes' bytes */
 	int eras[6];
+	unsigned fm[16];	/* K4Params.fmask */
 	int ctl[16];
 	/* Berlekamp-Massey work arrays live here, not in (scratch-backed) private arrays */
 	uint8_t lam[8], syn[8], bpoly[8], tpoly[8], omg[8], root[8], reg[8], loc[8];
 	int rs_deg, rs_count;
-	unsigned short crc_adv[16];	/* FCS state advanced over one lane's worth of zero bytes, per state bit */
-	unsigned short crc_in[K4_NT + 1];	/* running FCS at the start of each lane's bytes */
-	unsigned short crc_own[K4_NT];	/* FCS (from zero) of each lane's bytes */
 };
+
+/* GF(256)/0x187 (rs.c:17-79) and FCS-16 reflected 0x8408 (crc.c) tables, built once per handle */
+__global__ void k4_tables(unsigned *out)
+{
+	__shared__ uint8_t t[512 + 256 + 512];
+	uint8_t *gexp = t, *glog = t + 512;
+	unsigned short *crc = reinterpret_cast<unsigned short *>(t + 768);
+	if (threadIdx.x == 0) {
+		unsigned x = 1;
+		for (int i = 0; i < 255; i++) {
+			gexp[i] = (uint8_t)x;
+			glog[x] = (uint8_t)i;
+			x <<= 1;
+			if (x & 0x100)
+				x ^= 0x187;
+		}
+		for (int i = 255; i < 512; i++)
+			gexp[i] = gexp[i - 255];
+		glog[0] = K4_NOLOG;
+	}
+	for (int v = threadIdx.x; v < 256; v += blockDim.x) {
+		unsigned c = (unsigned)v;
+		for (int i = 0; i < 8; i++)
+			c = (c & 1) ? ((c >> 1) ^ 0x8408u) : (c >> 1);
+		crc[v] = (unsigned short)c;
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < K4_TABW; i += blockDim.x)
+		out[i] = reinterpret_cast<const unsigned *>(t)[i];
+}
 
 __device__ __forceinline__ int k4_m255(int x)
 {
@@ -69,68 +113,80 @@ __device__ __forceinline__ int k4_m255(int x)
 	return x;
 }
 
-/* rs.c:81-291 for one row whose syndromes are not all zero, in three parts.
- * k4_rs_bm (one lane): erasure locator and Berlekamp-Massey in the reference's update order; leaves
- * lambda in index form and its degree in LDS. */
-__device__ void k4_rs_bm(K4Shared &sh, const unsigned *synv, const int *eras_pos, int no_eras)
+/* rs.c:81-291 for one row whose syndromes are not all zero, in three parts, all of them spread over
+ * the lanes (a single lane walking these little polynomials pays an LDS round trip per table look-up
+ * and took longer than everything else in the kernel together).
+ * k4_rs_bm: erasure locator and Berlekamp-Massey.  Lane i owns coefficient i of lambda (value form) and
+ * of B (index form); one step of the reference's r loop is a discrepancy (XOR over the lanes), a shift
+ * of B by one lane, and one update per lane -- the same field operations on the same operands as the
+ * reference's loops, which read only values of the step before.  Leaves lambda in index form and its
+ * degree in LDS. */
+__device__ void k4_rs_bm(K4Shared &sh, const unsigned *synv, int no_eras, int lane)
 {
 	enum { NR = 6, NNN = 255 };
 	const uint8_t *gexp = sh.gexp, *glog = sh.glog;
-	uint8_t *lam = sh.lam, *syn = sh.syn, *bpoly = sh.bpoly, *tpoly = sh.tpoly;
-	for (int i = 0; i < NR; i++)
-		syn[i] = glog[synv[i]];	/* index form, NOLOG for zero */
-	for (int i = 0; i <= NR; i++)
-		lam[i] = 0;
-	lam[0] = 1;
+	{
+		unsigned mine = 0;
+#pragma unroll
+		for (int i = 0; i < NR; i++)
+			mine = (lane == i) ? synv[i] : mine;
+		if (lane < NR)
+			sh.syn[lane] = glog[mine];	/* index form, NOLOG for zero */
+	}
+	unsigned lam = (lane == 0) ? 1u : 0u;
 	if (no_eras > 0) {
-		lam[1] = gexp[k4_m255(NNN - 1 - eras_pos[0])];
+		if (lane == 1)
+			lam = gexp[k4_m255(NNN - 1 - sh.eras[0])];
 		for (int i = 1; i < no_eras; i++) {
-			const int u = k4_m255(NNN - 1 - eras_pos[i]);
-			for (int j = i + 1; j > 0; j--) {
-				const uint8_t lg = glog[lam[j - 1]];
+			const int u = k4_m255(NNN - 1 - sh.eras[i]);
+			const unsigned lp = __shfl_up(lam, 1, K4_NT);
+			if (lane >= 1 && lane <= i + 1) {
+				const unsigned lg = glog[lp];
 				if (lg != K4_NOLOG)
-					lam[j] ^= gexp[k4_m255(u + lg)];
+					lam ^= gexp[k4_m255(u + lg)];
 			}
 		}
 	}
-	for (int i = 0; i <= NR; i++)
-		bpoly[i] = glog[lam[i]];
+	unsigned b = (lane <= NR) ? (unsigned)glog[lam] : (unsigned)K4_NOLOG;
+	K4_SYNC();
 	int el = no_eras;
 	for (int r = no_eras + 1; r <= NR; r++) {
-		uint8_t disc = 0;
-		for (int i = 0; i < r; i++)
-			if (lam[i] && syn[r - i - 1] != K4_NOLOG)
-				disc ^= gexp[k4_m255(glog[lam[i]] + syn[r - i - 1])];
-		const uint8_t dl = glog[disc];
-		if (dl == K4_NOLOG) {
-			for (int i = NR; i > 0; i--)
-				bpoly[i] = bpoly[i - 1];
-			bpoly[0] = K4_NOLOG;
+		unsigned term = 0;
+		if (lane < r && lam) {
+			const unsigned sy = sh.syn[r - lane - 1];
+			if (sy != K4_NOLOG)
+				term = gexp[k4_m255(glog[lam] + sy)];
+		}
+		term ^= __shfl_xor(term, 1, K4_NT);
+		term ^= __shfl_xor(term, 2, K4_NT);
+		term ^= __shfl_xor(term, 4, K4_NT);
+		const unsigned disc = (unsigned)__builtin_amdgcn_readfirstlane((int)term);
+		unsigned bprev = __shfl_up(b, 1, K4_NT);
+		if (lane == 0)
+			bprev = K4_NOLOG;
+		if (disc == 0) {
+			b = bprev;
 			continue;
 		}
-		tpoly[0] = lam[0];
-		for (int i = 0; i < NR; i++)
-			tpoly[i + 1] = (bpoly[i] != K4_NOLOG) ? (uint8_t)(lam[i + 1] ^ gexp[k4_m255(dl + bpoly[i])]) : lam[i + 1];
+		const unsigned dl = glog[disc];
+		unsigned t = lam;
+		if (lane >= 1 && lane <= NR && bprev != K4_NOLOG)
+			t = lam ^ gexp[k4_m255(dl + bprev)];
 		if (2 * el <= r + no_eras - 1) {
 			el = r + no_eras - el;
-			for (int i = 0; i <= NR; i++)
-				bpoly[i] = lam[i] ? (uint8_t)k4_m255(glog[lam[i]] - dl + NNN) : (uint8_t)K4_NOLOG;
-		} else {
-			for (int i = NR; i > 0; i--)
-				bpoly[i] = bpoly[i - 1];
-			bpoly[0] = K4_NOLOG;
-		}
-		for (int i = 0; i <= NR; i++)
-			lam[i] = tpoly[i];
+			b = (lane <= NR && lam) ? (unsigned)k4_m255(glog[lam] - dl + NNN) : (unsigned)K4_NOLOG;
+		} else
+			b = bprev;
+		lam = t;
 	}
-	int deg = 0;
-	for (int i = 0; i <= NR; i++) {
-		lam[i] = glog[lam[i]];
-		if (lam[i] != K4_NOLOG)
-			deg = i;
+	const unsigned li = (lane <= NR) ? (unsigned)glog[lam] : (unsigned)K4_NOLOG;
+	if (lane <= NR)
+		sh.lam[lane] = (uint8_t)li;
+	const unsigned long long m = __ballot(li != K4_NOLOG);	/* bit 0 is always set: lambda_0 = 1 */
+	if (lane == 0) {
+		sh.rs_deg = 63 - __clzll((long long)m);
+		sh.rs_count = 0;
 	}
-	sh.rs_deg = deg;
-	sh.rs_count = 0;
 }
 
 /* Chien search, all lanes: position i (1..255) is a root when 1 + sum_j lambda_j alpha^(i j) = 0.  The
@@ -139,6 +195,7 @@ __device__ void k4_rs_bm(K4Shared &sh, const unsigned *synv, const int *eras_pos
 __device__ void k4_rs_chien(K4Shared &sh, int lane)
 {
 	const int deg = sh.rs_deg;
+	int count = 0;	/* the same in every lane */
 	for (int t = 0; t < 4; ++t) {
 		const int i = 1 + lane + 64 * t;
 		bool isroot = false;
@@ -147,65 +204,69 @@ __device__ void k4_rs_chien(K4Shared &sh, int lane)
 			for (int j = 1; j <= deg; ++j) {
 				const unsigned l = sh.lam[j];
 				if (l != K4_NOLOG)
-					q ^= sh.gexp[(l + (unsigned)(i * j)) % 255u];
+					q ^= sh.gexp[k4_m255((int)l + i * j)];
 			}
 			isroot = (q == 0);
 		}
 		const unsigned long long m = __ballot(isroot);
 		if (isroot) {
-			const int pos = sh.rs_count + __popcll(m & ((1ull << lane) - 1ull));
+			const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
 			if (pos < 6) {
 				sh.root[pos] = (uint8_t)i;
 				sh.loc[pos] = (uint8_t)((i - 1) % 255);
 			}
 		}
-		__syncthreads();
-		if (lane == 0)
-			sh.rs_count += __popcll(m);
-		__syncthreads();
+		count += __popcll(m);
 	}
+	if (lane == 0)
+		sh.rs_count = count;
 }
 
-/* Omega and Forney (one lane), last root first; a zero denominator abandons the row with the
- * corrections made so far, like the reference.  eras[] in/out like the reference. */
-__device__ void k4_rs_forney(K4Shared &sh, uint8_t *data, int *eras_pos)
+/* Omega and Forney.  Lane i computes omega_i, then lane j the correction for root j.  The reference
+ * takes the roots last first and abandons the row at the first zero denominator, keeping the corrections
+ * made so far: here, the roots above the highest one with a zero denominator.  eras[] in/out like the
+ * reference's eras_pos[]. */
+__device__ void k4_rs_forney(K4Shared &sh, uint8_t *data, int lane)
 {
 	enum { NR = 6, NNN = 255, FIRST = 120 };
 	const uint8_t *gexp = sh.gexp, *glog = sh.glog;
-	const uint8_t *lam = sh.lam, *syn = sh.syn, *root = sh.root, *loc = sh.loc;
-	uint8_t *omg = sh.omg;
+	const uint8_t *lam = sh.lam, *syn = sh.syn;
 	const int deg = sh.rs_deg, count = sh.rs_count;
 	if (deg != count)
 		return;
-	int dego = 0;
-	for (int i = 0; i < NR; i++) {
-		uint8_t tmp = 0;
-		for (int j = (deg < i) ? deg : i; j >= 0; j--)
-			if (syn[i - j] != K4_NOLOG && lam[j] != K4_NOLOG)
-				tmp ^= gexp[k4_m255(syn[i - j] + lam[j])];
-		if (tmp)
-			dego = i;
-		omg[i] = glog[tmp];
+	unsigned tmp = 0;
+	if (lane < NR) {
+		for (int j = (deg < lane) ? deg : lane; j >= 0; j--)
+			if (syn[lane - j] != K4_NOLOG && lam[j] != K4_NOLOG)
+				tmp ^= gexp[k4_m255(syn[lane - j] + lam[j])];
+		sh.omg[lane] = glog[tmp];
 	}
-	omg[NR] = K4_NOLOG;
-	for (int j = count - 1; j >= 0; j--) {
-		uint8_t num1 = 0;
+	if (lane == NR)
+		sh.omg[NR] = K4_NOLOG;
+	const unsigned long long mo = __ballot(lane < NR && tmp != 0);
+	const int dego = mo ? 63 - __clzll((long long)mo) : 0;
+	K4_SYNC();
+	unsigned num1 = 0, num2 = 0, den = 1;
+	int loc = 0;
+	if (lane < count) {
+		const int root = sh.root[lane];
+		loc = sh.loc[lane];
 		for (int i = dego; i >= 0; i--)
-			if (omg[i] != K4_NOLOG)
-				num1 ^= gexp[k4_m255(omg[i] + i * root[j])];
-		const uint8_t num2 = gexp[k4_m255(root[j] * (FIRST - 1) + NNN)];
-		uint8_t den = 0;
+			if (sh.omg[i] != K4_NOLOG)
+				num1 ^= gexp[k4_m255(sh.omg[i] + i * root)];
+		num2 = gexp[k4_m255(root * (FIRST - 1) + NNN)];
+		den = 0;
 		const int top = (deg < NR - 1 ? deg : NR - 1) & ~1;
 		for (int i = top; i >= 0; i -= 2)
 			if (lam[i + 1] != K4_NOLOG)
-				den ^= gexp[k4_m255(lam[i + 1] + i * root[j])];
-		if (den == 0)
-			return;
-		if (num1)
-			data[loc[j]] ^= gexp[k4_m255(glog[num1] + glog[num2] + NNN - glog[den])];
+				den ^= gexp[k4_m255(lam[i + 1] + i * root)];
 	}
-	for (int i = 0; i < count; i++)
-		eras_pos[i] = loc[i];
+	const unsigned long long bad = __ballot(lane < count && den == 0);
+	const int jstop = bad ? 63 - __clzll((long long)bad) : -1;
+	if (lane < count && lane > jstop && num1)
+		data[loc] ^= gexp[k4_m255(glog[num1] + glog[num2] + NNN - glog[den])];
+	if (!bad && lane < count)
+		sh.eras[lane] = loc;
 }
 
 __global__ __launch_bounds__(K4_NT)
@@ -215,51 +276,78 @@ void k4_frames(K4Params p)
 	const int lane = threadIdx.x;
 	const bool prof = p.dbg && lane == 0;
 	long long tq = prof ? clock64() : 0;
-	/* tables: GF(256)/0x187 (rs.c:17-79), FCS-16 reflected 0x8408 (crc.c) */
-	if (lane == 0) {
-		unsigned x = 1;
-		for (int i = 0; i < 255; i++) {
-			sh.gexp[i] = (uint8_t)x;
-			sh.glog[x] = (uint8_t)i;
-			x <<= 1;
-			if (x & 0x100)
-				x ^= 0x187;
-		}
-		for (int i = 255; i < 512; i++)
-			sh.gexp[i] = sh.gexp[i - 255];
-		sh.glog[0] = K4_NOLOG;
+	/* Everything the first record needs from memory is asked for at once -- the tables, the record
+	 * count and the front of record blockIdx.x -- because this kernel runs beside the next push's
+	 * channeliser, which keeps the memory queues full: every dependent round trip costs microseconds. */
+	unsigned tw[(K4_TABW + K4_NT - 1) / K4_NT], rw[K4_RECW0 / K4_NT] = {};
+	const unsigned fmw = (p.fmask && lane < 16) ? p.fmask[lane] : 0u;
+#pragma unroll
+	for (int k = 0; k < (K4_TABW + K4_NT - 1) / K4_NT; ++k)
+		tw[k] = (lane + K4_NT * k < K4_TABW) ? p.tabs[lane + K4_NT * k] : 0u;
+	if (blockIdx.x < p.rec_cap) {
+		const unsigned *w = reinterpret_cast<const unsigned *>(p.recs + blockIdx.x);
+#pragma unroll
+		for (int k = 0; k < K4_RECW0 / K4_NT; ++k)
+			rw[k] = w[lane + K4_NT * k];
 	}
-	for (int v = lane; v < 256; v += K4_NT) {
-		unsigned c = (unsigned)v;
-		for (int i = 0; i < 8; i++)
-			c = (c & 1) ? ((c >> 1) ^ 0x8408u) : (c >> 1);
-		sh.crc_tab[v] = (unsigned short)c;
-	}
-	__syncthreads();
 	unsigned nrecs = p.nrecs_dev ? *p.nrecs_dev : p.nrecs;
 	nrecs = nrecs > p.rec_cap ? p.rec_cap : nrecs;
+	if (blockIdx.x >= nrecs)
+		return;
+#pragma unroll
+	for (int k = 0; k < (K4_TABW + K4_NT - 1) / K4_NT; ++k)
+		if (lane + K4_NT * k < K4_TABW)
+			reinterpret_cast<unsigned *>(sh.gexp)[lane + K4_NT * k] = tw[k];
+	if (lane < 16)
+		sh.fm[lane] = fmw;
+	unsigned *const recw = reinterpret_cast<unsigned *>(sh.recw);
+	const vdl2gpu_burst_t *const rec = reinterpret_cast<const vdl2gpu_burst_t *>(sh.recw);	/* the copy in LDS */
+	uint8_t *const rows = reinterpret_cast<uint8_t *>(sh.recw) + offsetof(vdl2gpu_burst_t, data);
+	/* exponents of the syndrome sums for this lane's four bytes, (120+i)(254-j) mod 255, a byte each */
+	unsigned sexp[4][2];
+#pragma unroll
+	for (int b = 0; b < 4; ++b) {
+		const int j = lane * 4 + b;
+		sexp[b][0] = sexp[b][1] = 0;
+#pragma unroll
+		for (int i = 0; i < 6; ++i)
+			sexp[b][i / 4] |= (unsigned)k4_m255((120 + i) * (254 - (j < 255 ? j : 254))) << (8 * (i % 4));
+	}
 #define K4_STAMP(slot) do { if (prof) { const long long tn = clock64(); atomicAdd(p.dbg + 48 + (slot), (unsigned long long)(tn - tq)); tq = tn; } } while (0)
 	K4_STAMP(0);
 	for (unsigned ib = blockIdx.x; ib < nrecs; ib += gridDim.x) {
-		const vdl2gpu_burst_t *rec = p.recs + ib;
+		const unsigned *gw = reinterpret_cast<const unsigned *>(p.recs + ib);
+		if (ib != blockIdx.x) {
+			K4_SYNC();	/* the previous record's frame bytes have been read */
+#pragma unroll
+			for (int k = 0; k < K4_RECW0 / K4_NT; ++k)
+				rw[k] = gw[lane + K4_NT * k];
+		}
+#pragma unroll
+		for (int k = 0; k < K4_RECW0 / K4_NT; ++k)
+			recw[lane + K4_NT * k] = rw[k];
+		K4_SYNC();
 		const long long tb0 = prof ? clock64() : 0;
 		if (prof)
 			tq = tb0;
 		const int nbrow = rec->nbrow, nlbyte = rec->nlbyte;
+		const unsigned hdr = (unsigned)offsetof(vdl2gpu_frame_t, data);
+		vdl2gpu_frame_t *const myslot = p.compact ? reinterpret_cast<vdl2gpu_frame_t *>(reinterpret_cast<char *>(p.frames) + (size_t)ib * K4_SLOT) : nullptr;
+		if (myslot && lane == 0)
+			myslot->len = 0;
+		{
+			const unsigned sc = (unsigned)rec->end_sample;	/* device-side: the channel's index */
+			if (rec->trig_sample == 0 && sc < 512u && ((sh.fm[sc >> 5] >> (sc & 31u)) & 1u))
+				continue;
+		}
 		if (nbrow < 1 || nbrow > VDL2GPU_MAXROWS || nlbyte < 0 || nlbyte > 249)
 			continue;
 		/* ---- rows to LDS */
-		for (int i = lane; i < nbrow * 64; i += K4_NT) {
-			const int r = i >> 6, w = i & 63;
-			if (w * 4 < 255) {
-				const uint8_t *d = &rec->data[r][w * 4];
-				for (int b = 0; b < 4 && w * 4 + b < 255; ++b)
-					sh.row[r][w * 4 + b] = d[b];
-			}
-		}
+		for (int i = K4_RECW0 + lane; i < ((int)offsetof(vdl2gpu_burst_t, data) + nbrow * VDL2GPU_ROWLEN + 3) / 4; i += K4_NT)
+			recw[i] = gw[i];
 		if (lane < 6)
 			sh.eras[lane] = 0;
-		__syncthreads();
+		K4_SYNC();
 		K4_STAMP(1);
 		/* ---- RS per row (rows in order: eras_pos[] carries over, vdlm2.c:104-113) */
 		int nby = 0;
@@ -283,45 +371,55 @@ void k4_frames(K4Params p)
 			}
 			/* syndromes S_i = sum_j data[j] alpha^((120+i)(254-j)) */
 			unsigned syn[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
 			for (int b = 0; b < 4; ++b) {
 				const int j = lane * 4 + b;
 				if (j < 255) {
-					const unsigned d = sh.row[r][j];
+					const unsigned d = rows[r * VDL2GPU_ROWLEN + j];
 					if (d) {
-						const int lg = sh.glog[d];
+						const unsigned lg = sh.glog[d];
 #pragma unroll
 						for (int i = 0; i < 6; ++i)
-							syn[i] ^= sh.gexp[(lg + (120 + i) * (254 - j)) % 255];
+							syn[i] ^= sh.gexp[lg + ((sexp[b][i / 4] >> (8 * (i % 4))) & 0xffu)];
 					}
 				}
 			}
-#pragma unroll
-			for (int i = 0; i < 6; ++i)
-				for (int d = 32; d > 0; d >>= 1)
-					syn[i] ^= __shfl_xor(syn[i], d, 64);
-			const unsigned any = syn[0] | syn[1] | syn[2] | syn[3] | syn[4] | syn[5];
-			__syncthreads();
-			if (any) {	/* wave-uniform: every lane holds the reduced syndromes */
-				if (lane == 0)
-					k4_rs_bm(sh, syn, sh.eras, nera);
-				__syncthreads();
-				k4_rs_chien(sh, lane);
-				if (lane == 0)
-					k4_rs_forney(sh, sh.row[r], sh.eras);
+			{	/* field sums: XOR over the lanes, four syndromes to a word */
+				unsigned s03 = syn[0] | (syn[1] << 8) | (syn[2] << 16) | (syn[3] << 24), s45 = syn[4] | (syn[5] << 8);
+				for (int d = 32; d > 0; d >>= 1) {
+					s03 ^= __shfl_xor(s03, d, K4_NT);
+					s45 ^= __shfl_xor(s45, d, K4_NT);
+				}
+				syn[0] = s03 & 0xffu;
+				syn[1] = (s03 >> 8) & 0xffu;
+				syn[2] = (s03 >> 16) & 0xffu;
+				syn[3] = s03 >> 24;
+				syn[4] = s45 & 0xffu;
+				syn[5] = s45 >> 8;
 			}
-			__syncthreads();
+			const unsigned any = syn[0] | syn[1] | syn[2] | syn[3] | syn[4] | syn[5];
+			K4_SYNC();
+			if (any) {	/* wave-uniform: every lane holds the reduced syndromes */
+				k4_rs_bm(sh, syn, nera, lane);
+				K4_SYNC();
+				k4_rs_chien(sh, lane);
+				K4_SYNC();
+				k4_rs_forney(sh, rows + r * VDL2GPU_ROWLEN, lane);
+			}
+			K4_SYNC();
 			for (int i = lane; i < by; i += K4_NT)
-				sh.src[nby + i] = sh.row[r][i];
+				sh.src[nby + i] = rows[r * VDL2GPU_ROWLEN + i];
 			nby += by;
 		}
 		K4_STAMP(2);
-		for (int i = lane; i < (K4_MAXBY + 8) / 4 + 2; i += K4_NT)
+		for (int i = lane; i < nby / 4 + 2; i += K4_NT)
 			sh.dst[i] = 0u;
-		__syncthreads();
+		K4_SYNC();
 		/* ---- HDLC bit un-stuffing (vdlm2.c:116-128): lane owns bytes [b0, b1) */
 		const int per = (nby + K4_NT - 1) / K4_NT;
 		const int b0 = lane * per < nby ? lane * per : nby;
 		const int b1 = b0 + per < nby ? b0 + per : nby;
+		int tin;
 		{
 			int all = 1, trail = 0;
 			for (int i = b0; i < b1; ++i) {
@@ -333,104 +431,99 @@ void k4_frames(K4Params p)
 					trail = __clz((int)((~v & 0xffu) << 24));	/* ones above the highest zero (bit 7 downwards) */
 				}
 			}
-			sh.lsum[lane][0] = all;
-			sh.lsum[lane][1] = trail;
-		}
-		__syncthreads();
-		if (lane == 0) {
-			int t = 0;
-			for (int l = 0; l < K4_NT; ++l) {
-				sh.tin[l] = t;
-				t = sh.lsum[l][0] ? t + sh.lsum[l][1] : sh.lsum[l][1];
+			/* run of ones in front of the lane's first bit: scan of t' = all ? t + trail : trail */
+			for (int d = 1; d < K4_NT; d <<= 1) {
+				const int la = __shfl_up(all, d, K4_NT), lt = __shfl_up(trail, d, K4_NT);
+				if (lane >= d) {
+					trail = all ? lt + trail : trail;
+					all &= la;
+				}
 			}
+			tin = __shfl_up(trail, 1, K4_NT);
+			if (lane == 0)
+				tin = 0;
 		}
-		__syncthreads();
+		/* A zero is a stuffed one iff exactly five ones stand in front of it.  With the (at most six
+		 * relevant) bits in front of a byte put below it, that is a bit pattern test on the whole byte. */
+		auto drops = [](unsigned v, int t) -> unsigned {
+			const int tt = t < 6 ? t : 6;
+			const unsigned W = (v << 6) | (((1u << tt) - 1u) << (6 - tt));
+			const unsigned D = ~W & (W << 1) & (W << 2) & (W << 3) & (W << 4) & (W << 5) & ~(W << 6);
+			return (D >> 6) & 0xffu;
+		};
+		auto run_after = [](unsigned v, int t) -> int {	/* ones at the end of the stream after byte v */
+			return v == 0xffu ? t + 8 : __clz((int)((~v & 0xffu) << 24));
+		};
 		int nkeep = 0;
 		{
-			int t = sh.tin[lane];
+			int t = tin;
 			for (int i = b0; i < b1; ++i) {
 				const unsigned v = sh.src[i];
-				for (int n = 0; n < 8; ++n) {
-					if (v & (1u << n)) {
-						++t;
-						++nkeep;
-					} else {
-						if (t != 5)
-							++nkeep;
-						t = 0;
-					}
-				}
+				nkeep += 8 - __popc(drops(v, t));
+				t = run_after(v, t);
 			}
 		}
-		sh.kept[lane + 1] = nkeep;
-		__syncthreads();
-		if (lane == 0) {
-			int a = 0;
-			sh.kept[0] = 0;
-			for (int l = 1; l <= K4_NT; ++l) {
-				a += sh.kept[l];
-				sh.kept[l] = a;
-			}
+		int kept_incl = nkeep;	/* prefix sum of the kept bits */
+		for (int d = 1; d < K4_NT; d <<= 1) {
+			const int o = __shfl_up(kept_incl, d, K4_NT);
+			if (lane >= d)
+				kept_incl += o;
 		}
-		__syncthreads();
+		const int kept_all = __shfl(kept_incl, K4_NT - 1, K4_NT);
 		{
-			int t = sh.tin[lane], o = sh.kept[lane];
-			unsigned acc = 0;	/* bits of the output word being filled */
+			int t = tin, o = kept_incl - nkeep;
+			unsigned long long acc = 0;	/* bits of the output word being filled, and what spills over */
 			int w = o >> 5;
 			for (int i = b0; i < b1; ++i) {
-				const unsigned v = sh.src[i];
-				for (int n = 0; n < 8; ++n) {
-					const unsigned bit = (v >> n) & 1u;
-					if (bit)
-						++t;
-					else {
-						const bool stuffed = (t == 5);
-						t = 0;
-						if (stuffed)
-							continue;
-					}
-					acc |= bit << (o & 31);
-					++o;
-					if ((o & 31) == 0) {
-						atomicOr(&sh.dst[w], acc);
-						acc = 0;
-						++w;
-					}
+				unsigned v = sh.src[i];
+				unsigned dr = drops(v, t);
+				t = run_after(v, t);
+				int nbits = 8;
+				while (dr) {	/* squeeze the dropped zeros out, highest first (there are at most two) */
+					const int d = 31 - __clz((int)dr);
+					v = (v & ((1u << d) - 1u)) | ((v >> (d + 1)) << d);
+					dr &= ~(1u << d);
+					--nbits;
+				}
+				acc |= (unsigned long long)v << (o & 31);
+				o += nbits;
+				if ((o >> 5) != w) {
+					atomicOr(&sh.dst[w], (unsigned)acc);
+					acc >>= 32;
+					++w;
 				}
 			}
-			if (acc)
-				atomicOr(&sh.dst[w], acc);
+			if ((unsigned)acc)
+				atomicOr(&sh.dst[w], (unsigned)acc);
 		}
-		__syncthreads();
+		K4_SYNC();
 		K4_STAMP(3);
-		const int nb = sh.kept[K4_NT] >> 3;	/* whole un-stuffed bytes */
+		const int nb = kept_all >> 3;	/* whole un-stuffed bytes */
 		const uint8_t *B = reinterpret_cast<const uint8_t *>(sh.dst);
 		/* ---- first flag: the byte at which the OR of all bytes so far equals 0x7e (vdlm2.c:129-133) */
 		const int per2 = (nb + K4_NT - 1) / K4_NT;
 		const int c0 = lane * per2 < nb ? lane * per2 : nb;
 		const int c1 = c0 + per2 < nb ? c0 + per2 : nb;
+		unsigned lor = 0;	/* OR of all bytes in front of the lane's */
 		{
-			unsigned o = 0;
 			for (int i = c0; i < c1; ++i)
-				o |= B[i];
-			sh.lor[lane + 1] = (unsigned char)o;
+				lor |= B[i];
+			for (int d = 1; d < K4_NT; d <<= 1) {
+				const unsigned o = __shfl_up(lor, d, K4_NT);
+				if (lane >= d)
+					lor |= o;
+			}
+			lor = __shfl_up(lor, 1, K4_NT);
+			if (lane == 0)
+				lor = 0;
 		}
 		if (lane == 0) {
 			sh.ctl[0] = 0x7fffffff;	/* m0 */
 			sh.ctl[1] = 0x7fffffff;	/* m1 */
 		}
-		__syncthreads();
-		if (lane == 0) {
-			unsigned a = 0;
-			sh.lor[0] = 0;
-			for (int l = 1; l <= K4_NT; ++l) {
-				a |= sh.lor[l];
-				sh.lor[l] = (unsigned char)a;
-			}
-		}
-		__syncthreads();
+		K4_SYNC();
 		{
-			unsigned o = sh.lor[lane];
+			unsigned o = lor;
 			for (int i = c0; i < c1; ++i) {
 				o |= B[i];
 				if (o == 0x7eu) {
@@ -441,7 +534,7 @@ void k4_frames(K4Params p)
 					break;	/* a bit outside 0x7e is set for good: no flag will ever be seen */
 			}
 		}
-		__syncthreads();
+		K4_SYNC();
 		const int m0 = sh.ctl[0];
 		if (m0 != 0x7fffffff) {
 			/* flags right behind the first one are swallowed (k == 1, vdlm2.c:134-135) */
@@ -451,48 +544,55 @@ void k4_frames(K4Params p)
 					break;
 				}
 		}
-		__syncthreads();
+		K4_SYNC();
 		const int m1 = sh.ctl[1];
 		if (m0 == 0x7fffffff || m1 == 0x7fffffff) {
-			__syncthreads();
+			K4_SYNC();
 			continue;
 		}
 		/* ---- hdata[] = 0x7e, B[m1], B[m1+1], ...; every later 0x7e closes a candidate frame
 		 *      hdata[0..k] whose FCS runs over hdata[1..k-1] (check_frame, vdlm2.c:38-61).  All candidates
 		 *      start at m1, so one running FCS serves -- computed lane-parallel: the FCS is linear, the state
 		 *      at the start of a lane's bytes is (state one lane earlier, advanced over per2 zero bytes)
-		 *      xor (FCS from zero of that lane's bytes). */
+		 *      xor (FCS from zero of that lane's bytes); that recurrence is scanned in log2(64) doubling steps,
+		 *      the advance map (16 columns, one per lane) being squared alongside. */
 		K4_STAMP(4);
-		if (lane < 16) {	/* the advance map, one state bit per lane */
-			unsigned c = 1u << lane;
+		unsigned col = 0;	/* the advance map, one state bit per lane */
+		if (lane < 16) {
+			col = 1u << lane;
 			for (int i = 0; i < per2; ++i)
-				c = (c >> 8) ^ sh.crc_tab[c & 0xffu];
-			sh.crc_adv[lane] = (unsigned short)c;
+				col = (col >> 8) ^ sh.crc_tab[col & 0xffu];
 		}
 		const int L1 = m1 / per2;	/* lane that holds m1 (per2 >= 1 since nb > m1) */
+		unsigned crc_in;
 		{
-			unsigned c = (lane == L1) ? 0xffffu : 0u;
-			for (int i = (lane == L1) ? m1 : c0; i < c1; ++i)
-				c = (c >> 8) ^ sh.crc_tab[(c ^ B[i]) & 0xffu];
-			sh.crc_own[lane] = (unsigned short)c;
+			unsigned x = 0;	/* FCS over the lane's own bytes, from 0xffff at m1, from zero behind it */
+			if (lane >= L1) {
+				x = (lane == L1) ? 0xffffu : 0u;
+				for (int i = (lane == L1) ? m1 : c0; i < c1; ++i)
+					x = (x >> 8) ^ sh.crc_tab[(x ^ B[i]) & 0xffu];
+			}
+			for (int d = 1; d < K4_NT; d <<= 1) {
+				unsigned xl = __shfl_up(x, d, K4_NT);
+				if (lane < d)
+					xl = 0;
+				unsigned y = 0, nc = 0;
+#pragma unroll
+				for (int b = 0; b < 16; ++b) {
+					const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)col, b);
+					y ^= (0u - ((xl >> b) & 1u)) & cb;
+					nc ^= (0u - ((col >> b) & 1u)) & cb;
+				}
+				x ^= y;	/* exact for whole lanes; the last, partial lane's end state is not needed */
+				col = nc;
+			}
+			crc_in = __shfl_up(x, 1, K4_NT);	/* state at the lane's first byte */
 		}
 		if (lane == 0)
 			sh.ctl[1] = 0;	/* number of frames */
-		__syncthreads();
-		if (lane == 0) {
-			unsigned st = sh.crc_own[L1];	/* state after lane L1's bytes (from 0xffff at m1) */
-			for (int l = L1 + 1; l < K4_NT; ++l) {
-				sh.crc_in[l] = (unsigned short)st;
-				unsigned adv = 0;
-				for (int b = 0; b < 16; ++b)
-					if (st & (1u << b))
-						adv ^= sh.crc_adv[b];
-				st = adv ^ sh.crc_own[l];	/* exact for whole lanes; the last lane's state is not needed */
-			}
-		}
-		__syncthreads();
+		K4_SYNC();
 		if (lane >= L1) {
-			unsigned c = (lane == L1) ? 0xffffu : sh.crc_in[lane];
+			unsigned c = (lane == L1) ? 0xffffu : crc_in;
 			for (int q = (lane == L1) ? m1 : c0; q < c1; ++q) {
 				const unsigned v = B[q];
 				if (v == 0x7eu && (q - m1 + 2) >= 13 && c == 0xf0b8u) {
@@ -503,7 +603,7 @@ void k4_frames(K4Params p)
 				c = (c >> 8) ^ sh.crc_tab[(c ^ v) & 0xffu];
 			}
 		}
-		__syncthreads();
+		K4_SYNC();
 		if (lane == 0) {	/* frames in stream order (there is almost never more than one) */
 			int nf0 = sh.ctl[1] < 12 ? sh.ctl[1] : 12;
 			for (int i = 1; i < nf0; ++i)
@@ -514,35 +614,41 @@ void k4_frames(K4Params p)
 				}
 			sh.ctl[1] = nf0;
 		}
-		__syncthreads();
+		K4_SYNC();
 		K4_STAMP(5);
 		const int nf = sh.ctl[1];
 		for (int f = 0; f < nf; ++f) {
 			const int q = sh.ctl[2 + f];
 			const int len = q - m1 + 2;
-			if (lane == 0) {
-				unsigned slot;
-				if (p.compact) {
-					const unsigned sz = (unsigned)((offsetof(vdl2gpu_frame_t, data) + len + 7) & ~7);
-					slot = atomicAdd(p.nframes + 2, sz);	/* byte offset */
-					if (slot + sz > p.frame_cap) {
-						atomicAdd(p.nframes + 1, 1u);
-						slot = 0xffffffffu;
-					} else
-						atomicAdd(p.nframes, 1u);
-				} else {
-					slot = atomicAdd(p.nframes, 1u);
-					if (slot >= p.frame_cap) {
-						atomicAdd(p.nframes + 1, 1u);
-						slot = 0xffffffffu;
+			const bool inslot = myslot && f == 0 && hdr + (unsigned)len <= K4_SLOT;	/* uniform */
+			if (!inslot) {
+				if (lane == 0) {
+					unsigned slot;
+					if (p.compact) {
+						const unsigned sz = (hdr + (unsigned)len + 7u) & ~7u;
+						const unsigned base = p.rec_cap * K4_SLOT;
+						slot = base + atomicAdd(p.nframes + 2, sz);	/* byte offset */
+						if (slot + sz > p.frame_cap) {
+							atomicAdd(p.nframes + 1, 1u);
+							slot = 0xffffffffu;
+						} else
+							atomicAdd(p.nframes, 1u);
+					} else {
+						slot = atomicAdd(p.nframes, 1u);
+						if (slot >= p.frame_cap) {
+							atomicAdd(p.nframes + 1, 1u);
+							slot = 0xffffffffu;
+						}
 					}
+					sh.ctl[0] = (int)slot;
 				}
-				sh.ctl[0] = (int)slot;
+				K4_SYNC();
 			}
-			__syncthreads();
-			const unsigned slot = (unsigned)sh.ctl[0];
+			const unsigned slot = inslot ? 0u : (unsigned)sh.ctl[0];
+			K4_STAMP(12);
 			if (slot != 0xffffffffu) {
-				vdl2gpu_frame_t *fr = p.compact ? reinterpret_cast<vdl2gpu_frame_t *>(reinterpret_cast<char *>(p.frames) + slot) : p.frames + slot;
+				vdl2gpu_frame_t *fr = inslot ? myslot
+						     : (p.compact ? reinterpret_cast<vdl2gpu_frame_t *>(reinterpret_cast<char *>(p.frames) + slot) : p.frames + slot);
 				if (lane == 0) {
 					fr->stream = rec->stream;
 					fr->chn = rec->chn;
@@ -561,18 +667,23 @@ void k4_frames(K4Params p)
 				for (int i = lane; i < len - 1 && i + 1 < VDL2GPU_MAXFRAME; i += K4_NT)
 					fr->data[i + 1] = B[m1 + i];
 			}
-			__syncthreads();
+			K4_SYNC();
 		}
-		__syncthreads();
+		K4_SYNC();
 		K4_STAMP(6);
 		if (prof) {
 			atomicAdd(p.dbg + 48 + 7, 1ull);
 			const unsigned long long tot = (unsigned long long)(tq - tb0);
 			atomicMax(p.dbg + 48 + 8, tot);
+			if (nbrow >= 3) {
+				atomicAdd(p.dbg + 48 + 13, tot);
+				atomicAdd(p.dbg + 48 + 14, 1ull);
+			}
+			atomicMax(p.dbg + 48 + 15, (unsigned long long)nbrow);
 			if (tot > 400000ull) {
 				atomicAdd(p.dbg + 48 + 9, 1ull);
 				p.dbg[48 + 10] = ((unsigned long long)nbrow << 32) | (unsigned)nlbyte;
-				p.dbg[48 + 11] = (unsigned long long)sh.kept[K4_NT];
+				p.dbg[48 + 11] = (unsigned long long)kept_all;
 			}
 		}
 	}

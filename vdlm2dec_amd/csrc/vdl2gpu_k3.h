@@ -50,6 +50,8 @@ __global__ void k_push_init(KInitParams p)
 		p.outc[threadIdx.x] = 0u;
 	if (threadIdx.x < 16)
 		p.fmask[threadIdx.x] = 0u;
+	if (p.fcnt && threadIdx.x < 4)
+		p.fcnt[threadIdx.x] = 0u;
 }
 
 /* runs after k3_compact (same stream): publish the new time base and hand the push's counters to the host */

@@ -164,6 +164,7 @@ struct KInitParams {		/* per-push reset of the demodulator's control words */
 	int *fail, *redo;
 	int nsc;
 	unsigned *fmask;	/* 16 words */
+	unsigned *fcnt;		/* 4 words: this ring's block-path counters, or nullptr */
 };
 
 /* ---- constant data tables (d8psk.h:20-249) as bit patterns ------------- */
