@@ -8,8 +8,10 @@
  *
  * One wavefront per burst record.  Integer/byte work, bit-exact by construction:
  *   syndromes      64 lanes x 4 bytes each, XOR-reduced (a syndrome is a field sum: any order)
- *   BM/Chien/Forney  one lane, the reference's update order, so that miscorrections, the early
- *                  exits and the partially applied corrections of an uncorrectable row agree
+ *   BM/Chien/Forney  a coefficient (a candidate position, a root) per lane; each step performs the
+ *                  reference's field operations on the operands the reference's loops read, so that
+ *                  miscorrections, the early exits and the partially applied corrections of an
+ *                  uncorrectable row agree
  *   un-stuffing    a stuffed zero is a zero after exactly five ones: the run of ones in front of a
  *                  bit does not depend on what was dropped before, so every lane knows the run it
  *                  starts in from a scan of (all ones?, trailing ones) and drops its own zeros;
