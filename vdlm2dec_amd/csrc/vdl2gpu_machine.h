@@ -63,7 +63,8 @@ __device__ __forceinline__ void burst_timing(int clk0, int *j0, int *rb)
  * one lane and the byte lanes read them from LDS; without it (serial stretches of the resolver, which
  * have no LDS to spare) each byte lane computes the four or five phases it needs itself. */
 #define VDL2_MAXSYM 5456	/* symbols 7 .. (25 + 8 * 2040 - 1) / 3 */
-template <int NT> __device__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
+/* (inlined: as a call it costs the resolver and the gather kernel 8 % -- callee-saved registers through scratch) */
+template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
 						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph = nullptr,
 						  int tag = 1, int slot = 0)
 {
