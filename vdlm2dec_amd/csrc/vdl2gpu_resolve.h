@@ -182,25 +182,35 @@ void k2b_clusters(K2Params p)
  */
 #define K2C_NOCAND 0xffffu
 
-/* first sorted candidate at/after stream-relative time `want` of class (r, parity), from `from` */
-__device__ __forceinline__ int k2c_next(const int *skey, int ncand, int from, int want, int r)
+/* first sorted candidate at/after stream-relative time `want` of class (r, parity of want): a binary
+ * search in that class's own list (ranks in time order, ascending), -1 if there is none.  (Scanning
+ * the time-sorted list for the next entry of the class costs a candidate of a rare class a walk to the
+ * end of the list, one LDS round trip per step.) */
+__device__ __forceinline__ int k2c_next(const int *ctime, const unsigned short *clist, const int *coff, int want, int r)
 {
-	/* lower bound on time */
-	int lo = from, hi = ncand;
+	const int cls = r * 2 + (want & 1);
+	int lo = coff[cls], hi = coff[cls + 1];
+	const int end = hi;
 	while (lo < hi) {
 		const int mid = (lo + hi) >> 1;
-		if ((skey[mid] >> 2) < want)
+		if (ctime[mid] < want)
 			lo = mid + 1;
 		else
 			hi = mid;
 	}
-	for (; lo < ncand; ++lo) {
-		const int k = skey[lo];
-		if ((k & 3) == r && (((k >> 2) - want) & 1) == 0)
-			return lo;
-	}
-	return -1;
+	return lo < end ? (int)clist[lo] : -1;
 }
+
+/* one hop of the walk in 16 bits: rank of the successor | its cluster status << 12, 0xffff = none */
+#define K2C_HOP_NONE 0xffffu
+#define K2C_VIS 4096	/* entries of the visited list; more than that (it would take ten thousand bursts in a
+			 * channel's push) fails the channel over to the serial redo */
+/* sjump[j], for a steady cluster j: bits 0-11 = the last steady cluster within four hops of j (j itself if
+ * the first hop is not steady); K2C_J_CONT: all four hops were steady, go on from there; otherwise the
+ * chain ends behind it (no successor) or, K2C_J_SPECIAL, at the non-steady cluster in bits 16-27 */
+#define K2C_J_CONT 0x80000000u
+#define K2C_J_SPECIAL 0x10000000u
+static_assert(VDL2_CAND_CAP <= 4096, "a hop holds a 12-bit rank");
 
 __global__ __launch_bounds__(K2_NT)
 void k2c_resolve(K2Params p)
@@ -210,10 +220,21 @@ void k2c_resolve(K2Params p)
 	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
 	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
 	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
-	__shared__ uint8_t ssel[VDL2_CAND_CAP];		/* visited by the real chain */
+	__shared__ unsigned short svis[K2C_VIS];	/* what the real chain visited: rank | 0x8000 = that cluster; rank = the steady
+							 * hops of swalk[rank] */
+	__shared__ unsigned sjump[VDL2_CAND_CAP];	/* the walk's view of swalk[]: see K2C_J_* */
 	__shared__ int2 shead[VDL2_CAND_CAP];		/* cl_pack() of every candidate's cluster, by sorted rank */
 	__shared__ int s_walk[4];
 	__shared__ int s_cnt[4];
+	__shared__ unsigned short clist[VDL2_CAND_CAP];	/* ranks of the candidates, class by class, time order within */
+	__shared__ unsigned long long swalk[VDL2_CAND_CAP];	/* the next four hops from a steady cluster: what the walk reads */
+	__shared__ int ctime[VDL2_CAND_CAP];		/* times of clist[] */
+	__shared__ int coff[9];				/* where each class (r * 2 + time parity) starts in clist */
+	__shared__ int s_wcnt[K2_NT / 64][8];
+#ifndef K2C_PRIO
+#define K2C_PRIO 3
+#endif
+	__builtin_amdgcn_s_setprio(K2C_PRIO);	/* one workgroup per channel beside the channeliser's thousands of waves */
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
@@ -275,21 +296,107 @@ void k2c_resolve(K2Params p)
 		}
 	}
 	__syncthreads();
+	/* 1b. the class lists, a counting sort that keeps the time order: every thread counts the classes in
+	 *     its own contiguous stretch of the sorted list, an exclusive scan over (class, thread) turns the
+	 *     counts into positions, and the thread places its stretch */
+	{
+		const int per = (ncand + K2_NT - 1) / K2_NT;
+		const int j0 = tid * per < ncand ? tid * per : ncand, j1 = j0 + per < ncand ? j0 + per : ncand;
+		int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int j = j0; j < j1; ++j) {
+			const int k = skey[j], cls = (k & 3) * 2 + ((k >> 2) & 1);
+#pragma unroll
+			for (int q = 0; q < 8; ++q)
+				cnt[q] += (cls == q);
+		}
+		const int wave = tid >> 6, lane = tid & 63;
+		int excl[8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			int v = cnt[q];
+			for (int d = 1; d < 64; d <<= 1) {
+				const int o = __shfl_up(v, d, 64);
+				if (lane >= d)
+					v += o;
+			}
+			excl[q] = v - cnt[q];
+			if (lane == 63)
+				s_wcnt[wave][q] = v;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int acc = 0;
+			for (int q = 0; q < 8; ++q) {
+				coff[q] = acc;
+				for (int w = 0; w < K2_NT / 64; ++w) {
+					const int v = s_wcnt[w][q];
+					s_wcnt[w][q] = acc;	/* where wave w's share of class q starts */
+					acc += v;
+				}
+			}
+			coff[8] = acc;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < 8; ++q)
+			excl[q] += s_wcnt[wave][q];
+		for (int j = j0; j < j1; ++j) {
+			const int k = skey[j], cls = (k & 3) * 2 + ((k >> 2) & 1);
+			int at = 0;
+#pragma unroll
+			for (int q = 0; q < 8; ++q)
+				if (cls == q)
+					at = excl[q]++;
+			clist[at] = (unsigned short)j;
+			ctime[at] = k >> 2;
+		}
+		__syncthreads();
+	}
 	const long long tk1 = wall_clock64();
-	/* 2. successor table */
+	/* 2. successor table.  (Interleaving several searches per thread to overlap their LDS round trips
+	 *    was slower: this kernel, with two serial machines inlined, has no registers to spare.) */
 	for (int j = tid; j < ncand; j += K2_NT) {
 		const int2 hd = shead[j];
 		const int status = hd.y & 3;
 		int nx = -1;
 		if (status == CL_STEADY)
-			nx = k2c_next(skey, ncand, j + 1, hd.x, (hd.y >> 2) & 3);
+			nx = k2c_next(ctime, clist, coff, hd.x, (hd.y >> 2) & 3);	/* hd.x lies behind the candidate's own time */
 		sstat[j] = (uint8_t)status;
 		snext[j] = (nx < 0) ? (unsigned short)K2C_NOCAND : (unsigned short)nx;
-		ssel[j] = 0;
+	}
+	__syncthreads();
+	/* 2b. four hops per table entry: the walk below is one lane chasing pointers through LDS, a round
+	 *     trip per read, so it reads as rarely as possible */
+	for (int j = tid; j < ncand; j += K2_NT) {
+		unsigned long long e = 0;
+		unsigned jv = 0;
+		int at = j;
+		bool open = (sstat[j] == CL_STEADY);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			unsigned hop = K2C_HOP_NONE;
+			if (open) {
+				const unsigned nx = snext[at];
+				if (nx != K2C_NOCAND) {
+					const unsigned stt = sstat[nx];
+					hop = nx | (stt << 12);
+					open = (stt == CL_STEADY);
+					if (open)
+						at = (int)nx;
+				} else
+					open = false;
+			}
+			e |= (unsigned long long)hop << (16 * i);
+			if (!open && !(jv & K2C_J_SPECIAL) && hop != K2C_HOP_NONE)
+				jv |= K2C_J_SPECIAL | ((hop & 0xfffu) << 16);
+		}
+		swalk[j] = e;
+		sjump[j] = jv | (unsigned)at | (open ? K2C_J_CONT : 0u);
 	}
 	__syncthreads();
 	const long long tk2 = wall_clock64();
 	bool steady_end = false;
+	int nvis = 0;	/* slots of svis[] in use (thread 0's copy counts) */
 	for (;;) {
 		if (!tables_ok || st.fresh < VDL2_STEADY) {
 			/* history-dependent stretch (or no tables): serial machine */
@@ -302,7 +409,7 @@ void k2c_resolve(K2Params p)
 		}
 		/* 3. history-free: walk the successor table until something special happens */
 		if (tid == 0) {
-			int cur = k2c_next(skey, ncand, 0, (int)(st.pos - cx.dec_base), st.r);
+			int cur = k2c_next(ctime, clist, coff, (int)(st.pos - cx.dec_base), st.r);
 			int last = -1, why = 0;	/* why: 0 = no more candidates, 1 = special cluster at cur */
 			if (lazy && (st.r != r_probe || (int)(st.pos & 1) != par_probe)) {
 				/* the chain idles from here to the next candidate in a class the probe did not
@@ -318,16 +425,34 @@ void k2c_resolve(K2Params p)
 				} else
 					atomicMin(p.fail + sc, 0);
 			}
-			while (cur >= 0) {
-				const int stt = sstat[cur];
-				if (stt != CL_STEADY) {
-					why = 1;
-					break;
-				}
-				ssel[cur] = 1;
+			if (cur >= 0 && sstat[cur] != CL_STEADY)
+				why = 1;
+			else if (cur >= 0) {
+				/* A lone lane chasing pointers: a wavefront on its own issues an instruction every ~5
+				 * cycles, so the loop is four instructions and one LDS round trip per four clusters;
+				 * what was visited is worked out from the list afterwards, by everybody. */
+				if (nvis < K2C_VIS)
+					svis[nvis] = (unsigned short)(cur | 0x8000);
+				++nvis;
 				last = cur;
-				const int nx = snext[cur];
-				cur = (nx == K2C_NOCAND) ? -1 : nx;
+				unsigned v;
+				for (;;) {
+					v = sjump[last];
+					if (nvis < K2C_VIS)
+						svis[nvis] = (unsigned short)last;
+					++nvis;
+					if (!(v & K2C_J_CONT))
+						break;
+					last = (int)(v & 0xfffu);
+				}
+				last = (int)(v & 0xfffu);
+				if (v & K2C_J_SPECIAL) {
+					cur = (int)((v >> 16) & 0xfffu);
+					why = 1;
+				} else
+					cur = -1;
+				if (nvis > K2C_VIS)
+					atomicMin(p.fail + sc, 0);
 			}
 			s_walk[0] = cur;
 			s_walk[1] = last;
@@ -367,8 +492,13 @@ void k2c_resolve(K2Params p)
 			continue;
 		}
 		/* CL_NONSTEADY: its bursts count, then continue from the explicit state it stopped in */
-		if (tid == 0)
-			ssel[cur] = 1;
+		if (tid == 0) {
+			if (nvis < K2C_VIS)
+				svis[nvis] = (unsigned short)(cur | 0x8000);
+			else
+				atomicMin(p.fail + sc, 0);
+			++nvis;
+		}
 		mach_load(sh, &cl->saved);
 		st.pos = cl->saved.pos;
 		st.r = cl->saved.r;
@@ -383,12 +513,23 @@ void k2c_resolve(K2Params p)
 	if (tid == 0) {
 		s_walk[0] = (int)*nsel;
 		s_walk[1] = (int)*nseg;
+		s_walk[3] = nvis < K2C_VIS ? nvis : K2C_VIS;
 	}
 	__syncthreads();
 	{
 		int a = 0, b = 0, d = 0;
-		for (int j = tid; j < ncand; j += K2_NT)
-			if (ssel[j]) {
+		const int nv4 = s_walk[3] * 4;
+		for (int t = tid; t < nv4; t += K2_NT) {
+			const unsigned ve = svis[t >> 2];
+			int j = -1;
+			if (ve & 0x8000u)
+				j = (t & 3) == 0 ? (int)(ve & 0xfffu) : -1;
+			else {
+				const unsigned hop = (unsigned)(swalk[ve] >> (16 * (t & 3))) & 0xffffu;
+				if (hop != K2C_HOP_NONE && (hop >> 12) == CL_STEADY)
+					j = (int)(hop & 0xfffu);
+			}
+			if (j >= 0) {
 				const int2 hd = shead[j];
 				const int ns = (hd.y >> 4) & 15;
 				/* K2b's descriptors sit in static slots: (candidate index) * VDL2_CL_MAXB + burst */
@@ -422,6 +563,7 @@ void k2c_resolve(K2Params p)
 						atomicMin(p.fail + sc, 0);
 				}
 			}
+		}
 		if (a)
 			atomicAdd(&s_cnt[0], a);
 		if (b)
