@@ -56,10 +56,10 @@ struct K2aDef {			/* an evaluation that needs the exact fit */
 	int lo, hi;		/* verify: only hits in [lo, hi) count */
 };
 
-struct K2aShared {
+struct alignas(16) K2aShared {
 	float2 xs[K2A_XMAX + 8];	/* S = 1: samples in order; S = 2: even samples, then (at K2A_XODD) odd samples, so that
 					 * both FIR tap parities are unit-stride across lanes */
-	float2 wu[K2A_TS + K2A_POFF];	/* unit phasor of every filtered sample (history first), then in place the phasor
+	float2 wu[K2A_TS + K2A_POFF + 2];	/* unit phasor of every filtered sample (history first), then in place the phasor
 					 * of the symbol-spaced phase step */
 	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45) */
 	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants (vdl2_math.h) */
@@ -69,7 +69,10 @@ struct K2aShared {
 	float sph[K2A_WL2][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
 	float we[3][K2A_WL2], wf[K2A_WL2];	/* their exact fit errors, and the slope at the middle one */
 	int nwl, ndl;
+	unsigned long long prof[16];	/* diagnostics: stage cycle counters of the workgroup's first lane, added to p.dbg at the end
+					 * (a global atomic per stamp would sit in front of the tile's next s_waitcnt vmcnt) */
 };
+static_assert((K2A_XMAX / 2 + 4) % 2 == 0 && (K2A_XMAX + 8) % 2 == 0, "16-byte reads of xs[] and wu[]");
 #define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
 
 /* Screens for the 17-point fit (the expensive part of the scan).
@@ -236,23 +239,61 @@ __device__ void k2a_flush(K2aShared &sh, const K2Params &p, int sc, long long de
 	__syncthreads();
 }
 
-/* filtered sample of tile instant q (sub-phase taps mf[], 17th tap only for r == 0): d8psk.c:219-228 */
-template <int S> __device__ __forceinline__ v2f k2a_fir(const K2aShared &sh, int q, const float (&mf)[17], bool tap17)
+/* Filtered samples of the tile instants q0 (even) and q0 + 1, sub-phase taps mf[] (d8psk.c:219-228), for
+ * the screens only: fused multiply-adds,
+ * and the 18 or 19 samples the two share are read once, 16 bytes per lane and read -- the filter pass is
+ * bound by LDS bandwidth (one pipe per CU against four SIMDs), not by arithmetic.  A tap that does not
+ * exist has mf[] = 0. */
+template <int S> __device__ __forceinline__ void k2a_fir2(const K2aShared &sh, int q0, const float (&mf)[17], v2f &acc0, v2f &acc1)
 {
-	/* tap j multiplies sample (nbase + S*(q-PH)) - 16 + j = tile sample S*q + j */
-	const v2f *xe = reinterpret_cast<const v2f *>(&sh.xs[q]);
-	const v2f *xo = reinterpret_cast<const v2f *>(&sh.xs[K2A_XODD + q]);
-	v2f xv[17];
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	acc0 = (v2f){0.0f, 0.0f};
+	acc1 = (v2f){0.0f, 0.0f};
+	if (S == 2) {
+		/* instant q, tap j: even j = 2m -> even sample q + m, odd j = 2m + 1 -> odd sample q + m */
+		const v4f *pe = reinterpret_cast<const v4f *>(&sh.xs[q0]);
+		const v4f *po = reinterpret_cast<const v4f *>(&sh.xs[K2A_XODD + q0]);
+		v4f e[5], o[5];
 #pragma unroll
-	for (int j = 0; j < 17; ++j)	/* every LDS read in flight before the first multiply */
-		xv[j] = (S == 2) ? ((j & 1) ? xo[j >> 1] : xe[j >> 1]) : xe[j];
-	v2f acc = {0.0f, 0.0f};
+		for (int i = 0; i < 5; ++i) {
+			e[i] = pe[i];
+			o[i] = po[i];
+		}
+		v2f xe[10], xo[10];
 #pragma unroll
-	for (int j = 0; j < 16; ++j)
-		acc += xv[j] * (v2f){mf[j], mf[j]};
-	if (tap17)
-		acc += xv[16] * (v2f){mf[16], mf[16]};
-	return acc;
+		for (int i = 0; i < 5; ++i) {
+			xe[2 * i] = e[i].xy;
+			xe[2 * i + 1] = e[i].zw;
+			xo[2 * i] = o[i].xy;
+			xo[2 * i + 1] = o[i].zw;
+		}
+#pragma unroll
+		for (int m = 0; m < 9; ++m) {
+			acc0 = __builtin_elementwise_fma(xe[m], (v2f){mf[2 * m], mf[2 * m]}, acc0);
+			acc1 = __builtin_elementwise_fma(xe[m + 1], (v2f){mf[2 * m], mf[2 * m]}, acc1);
+			if (m < 8) {
+				acc0 = __builtin_elementwise_fma(xo[m], (v2f){mf[2 * m + 1], mf[2 * m + 1]}, acc0);
+				acc1 = __builtin_elementwise_fma(xo[m + 1], (v2f){mf[2 * m + 1], mf[2 * m + 1]}, acc1);
+			}
+		}
+	} else {
+		const v4f *pe = reinterpret_cast<const v4f *>(&sh.xs[q0]);
+		v4f e[9];
+#pragma unroll
+		for (int i = 0; i < 9; ++i)
+			e[i] = pe[i];
+		v2f x[18];
+#pragma unroll
+		for (int i = 0; i < 9; ++i) {
+			x[2 * i] = e[i].xy;
+			x[2 * i + 1] = e[i].zw;
+		}
+#pragma unroll
+		for (int j = 0; j < 17; ++j) {
+			acc0 = __builtin_elementwise_fma(x[j], (v2f){mf[j], mf[j]}, acc0);
+			acc1 = __builtin_elementwise_fma(x[j + 1], (v2f){mf[j], mf[j]}, acc1);
+		}
+	}
 }
 
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
@@ -272,10 +313,11 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
 	const bool prof = p.dbg && mode == 2 && tid == 0 && (blockIdx.x & 7) == 0;
 	long long tq = prof ? clock64() : 0;
-#define K2A_STAMP(slot) do { if (prof) { const long long tn = clock64(); atomicAdd(p.dbg + 32 + (slot), (unsigned long long)(tn - tq)); tq = tn; } } while (0)
+#define K2A_STAMP(slot) do { if (prof) { const long long tn = clock64(); sh.prof[slot] += (unsigned long long)(tn - tq); tq = tn; } } while (0)
 	if (!pre.loaded)
 		k2a_fetch<S>(pre, p, sc, dec_base, nbase, cnt);
 	__syncthreads();
+	K2A_STAMP(12);
 #pragma unroll
 	for (int k = 0; k < K2aPre<S>::NL; ++k) {
 		const int i = tid + k * K2A_THREADS;
@@ -283,6 +325,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 			sh.xs[S == 2 ? (i & 1) * K2A_XODD + (i >> 1) : i] = pre.v[k];
 	}
 	pre.loaded = false;
+	K2A_STAMP(13);
 	if (next_cnt > 0)
 		k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
 	__syncthreads();
@@ -295,17 +338,28 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 #pragma unroll
 		for (int j = 0; j < 17; ++j)	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
 			mf[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.smf[r + 4 * j])));
-		const bool tap17 = (r == 0);
 		/* ---- unit phasors of the filtered samples of instants -PH .. cnt-1 */
-		for (int q = tid; q < cnt + PH; q += K2A_THREADS) {
-			const v2f acc = k2a_fir<S>(sh, q, mf, tap17);
-			const float n2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-			v2f w = acc * __frsqrt_rn(n2);
-			if (!(n2 >= 1e-30f && n2 <= 1e30f)) {	/* atan2f(0, 0) = 0; anything else odd: let it through */
-				const float bad = (acc.x == 0.0f && acc.y == 0.0f) ? 0.0f : __builtin_nanf("");
-				w = (v2f){1.0f + bad, bad};
+		for (int q0 = 2 * tid; q0 < cnt + PH; q0 += 2 * K2A_THREADS) {	/* (the odd one out at the end lands in wu[]'s padding) */
+			v2f acc[2];
+			k2a_fir2<S>(sh, q0, mf, acc[0], acc[1]);
+			float4 out;
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const float n2 = __fmaf_rn(acc[h].x, acc[h].x, acc[h].y * acc[h].y);
+				v2f w = acc[h] * __frsqrt_rn(n2);
+				if (!(n2 >= 1e-30f && n2 <= 1e30f)) {	/* atan2f(0, 0) = 0; anything else odd: let it through */
+					const float bad = (acc[h].x == 0.0f && acc[h].y == 0.0f) ? 0.0f : __builtin_nanf("");
+					w = (v2f){1.0f + bad, bad};
+				}
+				if (h == 0) {
+					out.x = w.x;
+					out.y = w.y;
+				} else {
+					out.z = w.x;
+					out.w = w.y;
+				}
 			}
-			sh.wu[q] = make_float2(w.x, w.y);
+			*reinterpret_cast<float4 *>(&sh.wu[q0]) = out;
 		}
 		K2A_STAMP(1);
 		__syncthreads();
@@ -370,7 +424,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 			K2A_STAMP(5);
 			const int nwl = sh.nwl;
 			if (prof)
-				atomicAdd(p.dbg + 32 + 10, (unsigned long long)nwl);
+				sh.prof[10] += (unsigned long long)nwl;
 			if (nwl > K2A_WL) {
 				piece = K2A_WL;
 				__syncthreads();	/* everyone has read nwl before it is reset */
@@ -414,7 +468,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		__syncthreads();
 		K2A_STAMP(9);
 		if (prof)
-			atomicAdd(p.dbg + 32 + 11, 1ull);
+			sh.prof[11] += 1ull;
 	}
 #undef K2A_STAMP
 }
@@ -430,6 +484,8 @@ void k2a_probe(K2Params p)
 	const long long avail_end = dec_base + ss->dec_fill + p.J;
 	if (p.force_serial)
 		return;
+	if (threadIdx.x < 16)
+		sh.prof[threadIdx.x] = 0;
 	k2a_tables(sh);
 	/* each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its channel */
 	if (p.full_scan) {
@@ -459,6 +515,9 @@ void k2a_probe(K2Params p)
 		k2a_tile<2>(sh, p, sc, dec_base, n0, nt, rmask, 2, 0, 0, nullptr, pre, n1, nt1);
 	}
 	k2a_flush(sh, p, sc, dec_base, 2, nullptr, -1, 0);
+	__syncthreads();
+	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
+		atomicAdd(p.dbg + 32 + threadIdx.x, sh.prof[threadIdx.x]);
 }
 
 /* ---- workgroup sort of up to VDL2_CAND_CAP 64-bit keys whose top bits are a time stamp.
