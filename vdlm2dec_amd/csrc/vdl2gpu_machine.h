@@ -455,6 +455,70 @@ template <int NT, bool XL> __device__ MachTrig mach_trigger(MachSharedT<NT> &sh,
 	return tg;
 }
 
+/* What a trigger that is not deferred leaves behind: counters and, for an accepted header, the burst's
+ * descriptor (or its record, payload decoded at once).  Returns the stream time of the burst's last
+ * symbol (of header symbol 8 for a rejected one): the idle search resumes two samples later. */
+template <int NT, bool XL> __device__ __forceinline__ long long mach_commit_trigger(MachSharedT<NT> &sh, MachCtx &cx, const float2 *x0,
+										       long long nstar, const MachTrig &tg, MachOut &out)
+{
+	const int tid = threadIdx.x;
+	const int clk0 = tg.clk0, accepted = tg.accepted, nbrow = tg.nbrow, nlbyte = tg.nlbyte, nsym = tg.nsym;
+	const float df = tg.df;
+	const long long nsym0 = tg.nsym0;
+	out.ntrig++;
+	long long nlast;
+	if (!accepted) {
+		out.nrej++;
+		nlast = nsym0 + 64;	/* state returns to WSYNC on the 25th bit (symbol 8) */
+	} else {
+		nlast = nsym0 + 8LL * (nsym - 1);
+		if (tid == 0) {
+			unsigned slot;
+			if (cx.desc_static >= 0)
+				slot = (unsigned)(cx.desc_static + out.nslots);	/* out.nslots < VDL2_CL_MAXB here */
+			else {
+				/* dynamic slots live behind the static region of the pool */
+				slot = atomicAdd(cx.rec_count, 1u);
+				if (cx.desc)
+					slot += cx.dyn_base;
+			}
+			if (slot >= cx.rec_cap) {
+				atomicAdd(cx.rec_ovf, 1u);
+				slot = 0xffffffffu;
+			} else if (cx.desc) {
+				BurstDesc d;
+				d.nstar = nstar;
+				d.sc = cx.sc;
+				d.clk0 = clk0;
+				d.df = df;
+				d.nbrow = nbrow;
+				d.nlbyte = nlbyte;
+				d.pad = 0;
+				cx.desc[slot] = d;
+				if (cx.sel) {
+					const unsigned q = atomicAdd(cx.nsel, 1u);
+					if (q < VDL2_SEL_CAP)
+						cx.sel[q] = slot;
+					else
+						atomicAdd(cx.rec_ovf, 1u);
+				}
+			}
+			sh.ctl[6] = (int)slot;
+		}
+		__syncthreads();
+		const unsigned slot = (unsigned)sh.ctl[6];
+		if (!XL && !cx.desc && slot != 0xffffffffu)
+			burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg);
+#pragma unroll
+		for (int i = 0; i < VDL2_CL_MAXB; ++i)
+			if (out.nslots == i)
+				out.slots[i] = (int)slot;
+		out.nslots++;
+		out.nburst++;
+	}
+	return nlast;
+}
+
 /* stop_steady: return MR_STEADY as soon as the detector is history-free and at least
  * `min_trig` triggers were handled.  first_nev: size of the first search window (a hint). */
 template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachCtx &cx, MachState &st, bool stop_steady,
@@ -519,11 +583,8 @@ template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachC
 		/* ---- sync trigger at evaluation ts (stream time nstar) */
 		const long long nstar = pos + 2LL * ts;
 		const MachTrig tg = mach_trigger<NT, XL>(sh, cx, nstar, sh.errs[ts], sh.errs[ts + 1], sh.errs[ts + 2], sh.frs[ts]);
-		const int clk0 = tg.clk0, rb = tg.rb, accepted = tg.accepted, nbrow = tg.nbrow, nlbyte = tg.nlbyte, nsym = tg.nsym;
-		const float df = tg.df;
-		const long long nsym0 = tg.nsym0;
-		const bool defer = tg.defer;
-		if (defer) {
+		const int rb = tg.rb;
+		if (tg.defer) {
 			/* the burst is not completely inside the data we hold: commit the
 			 * evaluations before the trigger and retry on the next push */
 			mach_shift_ring(sh, ts, sh.errs[ts], sh.errs[ts + 1], sh.frs[ts]);
@@ -534,57 +595,7 @@ template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachC
 			rc = MR_DEFER;
 			break;
 		}
-		out.ntrig++;
-		long long nlast;
-		if (!accepted) {
-			out.nrej++;
-			nlast = nsym0 + 64;	/* state returns to WSYNC on the 25th bit (symbol 8) */
-		} else {
-			nlast = nsym0 + 8LL * (nsym - 1);
-			if (tid == 0) {
-				unsigned slot;
-				if (cx.desc_static >= 0)
-					slot = (unsigned)(cx.desc_static + out.nslots);	/* out.nslots < VDL2_CL_MAXB here */
-				else {
-					/* dynamic slots live behind the static region of the pool */
-					slot = atomicAdd(cx.rec_count, 1u);
-					if (cx.desc)
-						slot += cx.dyn_base;
-				}
-				if (slot >= cx.rec_cap) {
-					atomicAdd(cx.rec_ovf, 1u);
-					slot = 0xffffffffu;
-				} else if (cx.desc) {
-					BurstDesc d;
-					d.nstar = nstar;
-					d.sc = cx.sc;
-					d.clk0 = clk0;
-					d.df = df;
-					d.nbrow = nbrow;
-					d.nlbyte = nlbyte;
-					d.pad = 0;
-					cx.desc[slot] = d;
-					if (cx.sel) {
-						const unsigned q = atomicAdd(cx.nsel, 1u);
-						if (q < VDL2_SEL_CAP)
-							cx.sel[q] = slot;
-						else
-							atomicAdd(cx.rec_ovf, 1u);
-					}
-				}
-				sh.ctl[6] = (int)slot;
-			}
-			__syncthreads();
-			const unsigned slot = (unsigned)sh.ctl[6];
-			if (!XL && !cx.desc && slot != 0xffffffffu)
-				burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg);
-#pragma unroll
-			for (int i = 0; i < VDL2_CL_MAXB; ++i)
-				if (out.nslots == i)
-					out.slots[i] = (int)slot;
-			out.nslots++;
-			out.nburst++;
-		}
+		const long long nlast = mach_commit_trigger<NT, XL>(sh, cx, x0, nstar, tg, out);
 		/* back to the idle detector: ring keeps the phases up to the trigger
 		 * evaluation (Ph is not written during a burst), errors re-armed
 		 * (d8psk.c:308), sub-phase sticks at rb */

@@ -129,10 +129,37 @@ void k2b_clusters(K2Params p)
 #pragma unroll
 		for (int i = 0; i < VDL2_CL_MAXB; ++i)
 			out.slots[i] = 0;
+		/* The candidate record holds what the detector saw when it fired -- the three fit errors and
+		 * the slope (the scan computed them with the detector's own arithmetic) --, so the trigger is
+		 * handled from those; what has to be rebuilt is the phase ring the detector returns to after
+		 * the burst: the phases of the 68 evaluations up to and including this one. */
 		const long long t0 = wall_clock64();
-		mach_materialize<K2B_NT, true>(sh, cx, st.pos, st.r);
+		const long long nstar = st.pos;
+		mach_need<K2B_NT, true>(sh, cx, nstar - 152, nstar + 1);
+		for (int i = tid; i < VDL2_NPH; i += K2B_NT)
+			sh.pbuf[i] = mach_fir<K2B_NT, true>(sh, cx, nstar - 2LL * (VDL2_NPH - 1 - i), st.r);
+		if (tid == 0) {
+			sh.errs[0] = 500.0f;	/* errors re-armed (d8psk.c:308) */
+			sh.errs[1] = 500.0f;
+			sh.frs[0] = cd.pfr;
+		}
+		__syncthreads();
 		const long long t1 = wall_clock64();
-		const int rc = machine_run<K2B_NT, true>(sh, cx, st, true, 1, VDL2_CL_MAXB, 1, out);
+		int rc;
+		{
+			const MachTrig tg = mach_trigger<K2B_NT, true>(sh, cx, nstar, cd.p2err, cd.perr, cd.err, cd.pfr);
+			if (tg.defer) {
+				out.ndefer++;
+				rc = MR_DEFER;
+			} else {
+				const long long nlast = mach_commit_trigger<K2B_NT, true>(sh, cx, cx.x - cx.dec_base, nstar, tg, out);
+				out.neval += 1;
+				st.pos = nlast + 2;
+				st.r = tg.rb;
+				st.fresh = 0;
+				rc = machine_run<K2B_NT, true>(sh, cx, st, true, 1, VDL2_CL_MAXB, 0, out);
+			}
+		}
 		const long long t2 = wall_clock64();
 		if (tid == 0 && p.dbg && (tk & 15u) == 0) {
 			atomicAdd(p.dbg + 0, (unsigned long long)(t1 - t0));
