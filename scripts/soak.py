@@ -22,12 +22,18 @@ while time.time() < t_end:
     spec = synth.random_scenario(rate, fos, ns, seed=seed, bursts_per_s=dens, info_max=int(rng.choice([60, 240, 900])),
                                  )
     raw = synth.synth_stream(spec, fmt)
-    want = sorted(b.key() for b in O.run_oracle(raw, fmt, rate, fos, FC))
+    ob = O.run_oracle(raw, fmt, rate, fos, FC)
+    want = sorted(b.key() for b in ob)
     block = int(rng.choice([ns, ns // 2 + 17, 1_234_567, 400_000, 2_000_000, 65536]))
-    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16)) as rx:
+    frames_too = bool(seed & 1)  # every other scenario also runs the block path in the pipeline
+    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16), frames=frames_too) as rx:
         got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in rx.run(raw, block=block))
+        gotf = sorted(rx.poll_frames()) if frames_too else []
         st = rx.stats()
     ok = got == want
+    if frames_too:
+        wantf = sorted((0, b.chn, f) for b in ob for f in O.frames_of_block(b.nbrow, b.nlbyte, b.data))
+        ok = ok and gotf == wantf
     n_ok += ok; n_bad += (not ok)
     print("seed %d rate %d ch %d %s ns %d dens %.0f block %d: %d bursts %s redos %d" % (seed, rate, nch, fmt, ns, dens, block, len(want), "OK" if ok else "MISMATCH", st["serial_redos"]), flush=True)
     seed += 1
