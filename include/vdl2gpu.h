@@ -146,6 +146,19 @@ void vdl2gpu_destroy(vdl2gpu_t *h);
  * hand-off of Cbuff (d8psk.c:360-383) for all channels at once, with any
  * block length instead of the fixed 32768. */
 int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind);
+
+/* Ingest ring: replaces the producer side of the hand-off -- in_callback()
+ * converting a USB block into Cbuff between Bar1 and Bar2 (rtl.c:274-295), rx_callback() copying airspy
+ * samples (air.c:191-217) -- by `nslots` slots of page-locked host memory that the producer fills in place
+ * (e.g. rtlsdr_read_sync() straight into the slot; the cu8/cs16 conversion happens in the channeliser
+ * kernel).  acquire() hands out the next slot -- stream s starts at slot + s * *stream_stride_bytes -- and
+ * waits only if that slot's previous contents are still on their way to the GPU; commit(nsamples) enqueues
+ * the copy and the whole decode behind it and returns at once, so the copy of one block runs beside the
+ * kernels of the one before.  commit(0) drops the block (a short USB read, rtl.c:278-281).  One producer:
+ * acquire and commit alternate.  Bursts come out through vdl2gpu_poll*() as with vdl2gpu_push(). */
+int vdl2gpu_ring_init(vdl2gpu_t *h, size_t slot_samples, int nslots);
+void *vdl2gpu_ring_acquire(vdl2gpu_t *h, size_t *stream_stride_bytes);
+int vdl2gpu_ring_commit(vdl2gpu_t *h, size_t nsamples);
 /* Wait until everything pushed so far has been demodulated. */
 int vdl2gpu_sync(vdl2gpu_t *h);
 /* Collect finished bursts (waits for everything pushed so far).  Bursts come out ordered by

@@ -301,3 +301,30 @@ def test_many_streams_batch(built, oracle):
         want = sorted(b.key() for b in oracle.run_oracle(raws[s][:n], "cs16", specs[s].rate, specs[s].fo, S.FC))
         mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
         assert mine == want and len(want) >= 6, s
+
+
+def test_ingest_ring_equals_push(built, oracle):
+    """blocks written in place into the page-locked ring (more blocks than slots, so slots
+    are reused while earlier copies and kernels are still in flight, one dropped block in between) decode
+    to exactly the oracle's bursts."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 3_000_000, seed=77, bursts_per_s=20.0, info_max=120)
+    raw = synth.synth_stream(spec, "cu8")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cu8", spec.rate, spec.fo, S.FC))
+    blk = 32768   # the reference's hand-off size, vdlm2.h:35
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cu8", max_push=blk) as rx:
+        rx.ring_init(blk, nslots=3)
+        got = []
+        rawb = raw.view(np.uint8).reshape(-1)
+        for i, s0 in enumerate(range(0, spec.nsamples, blk)):
+            n = min(blk, spec.nsamples - s0)
+            slot = rx.ring_acquire()
+            slot[0, :2 * n] = rawb[2 * s0:2 * (s0 + n)]
+            rx.ring_commit(n)
+            if i == 5:   # a short USB read: the producer gives the slot back empty
+                rx.ring_acquire()
+                rx.ring_commit(0)
+            if i % 16 == 15:
+                got += rx.poll_ready()
+        got += rx.poll()
+    assert _gpu_keys(got) == want and len(want) >= 20

@@ -51,9 +51,21 @@ struct vdl2gpu {
 	size_t sample_bytes;
 	long long cap;		/* frames per stream per ping-pong buffer */
 	hipStream_t stream = nullptr;
-	hipEvent_t copy_done = nullptr;
-	void *d_raw = nullptr;
-	size_t raw_bytes = 0;
+	/* host samples: two staging buffers in HBM, filled on a stream of their own, so that the copy of one
+	 * push runs beside the channeliser of the one before */
+	hipStream_t in_stream = nullptr;
+	hipEvent_t raw_copied[2] = {nullptr, nullptr};
+	void *d_raw[2] = {nullptr, nullptr};
+	size_t raw_bytes[2] = {0, 0};
+	bool k1_rec[2] = {false, false};	/* k1_done[i] has been recorded at least once */
+	/* ingest ring (rtl.c:274-295, air.c:191-217): pinned host slots the producer fills in place */
+	void *ring_host = nullptr;
+	size_t ring_slot_samples = 0, ring_slot_bytes = 0;
+	int ring_nslots = 0;
+	unsigned long long ring_next = 0;
+	bool ring_acquired = false;
+	std::vector<hipEvent_t> ring_copied;
+	std::vector<char> ring_inflight;
 	float2 *d_lo = nullptr;
 	float2 *d_dec[2] = { nullptr, nullptr };
 	StreamState *d_ss = nullptr;
@@ -253,7 +265,17 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	for (auto &pt : h->free_ev)
 		for (auto &e : pt.e)
 			(void)hipEventDestroy(e);
-	(void)hipFree(h->d_raw);
+	(void)hipFree(h->d_raw[0]);
+	(void)hipFree(h->d_raw[1]);
+	if (h->ring_host)
+		(void)hipHostFree(h->ring_host);
+	for (hipEvent_t e : h->ring_copied)
+		(void)hipEventDestroy(e);
+	for (int i = 0; i < 2; ++i)
+		if (h->raw_copied[i])
+			(void)hipEventDestroy(h->raw_copied[i]);
+	if (h->in_stream)
+		(void)hipStreamDestroy(h->in_stream);
 	(void)hipFree(h->d_lo);
 	(void)hipFree(h->d_dec[0]);
 	(void)hipFree(h->d_dec[1]);
@@ -314,8 +336,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipHostFree(h->h_pin);
 	if (h->h_pin_cnt)
 		(void)hipHostFree(h->h_pin_cnt);
-	if (h->copy_done)
-		(void)hipEventDestroy(h->copy_done);
 	if (h->stream)
 		(void)hipStreamDestroy(h->stream);
 	delete h;
@@ -557,7 +577,73 @@ template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t sm
 	hipLaunchKernelGGL(k1_channelise<FMT>, grid, dim3(K1_THREADS), smem, st, p);
 }
 
+static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy);
+
 extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind)
+{
+	/* the caller may reuse a host buffer as soon as we return (the reference's producer refills Cbuff
+	 * right after the consumers pass Bar1, d8psk.c:383): wait for the copy, not for the kernels */
+	return push_impl(h, iq, nsamples, stream_stride_bytes, memkind, true);
+}
+
+/* ---------------------------------------------------------------- ingest ring */
+extern "C" int vdl2gpu_ring_init(vdl2gpu_t *h, size_t slot_samples, int nslots)
+{
+	if (!h || slot_samples == 0 || slot_samples > h->cfg.max_push || nslots < 2 || nslots > 64)
+		return VDL2GPU_EINVAL;
+	if (h->ring_host) {
+		h->err = "vdl2gpu_ring_init: the ring exists already";
+		return VDL2GPU_EINVAL;
+	}
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	h->ring_slot_samples = slot_samples;
+	h->ring_slot_bytes = slot_samples * h->sample_bytes * (size_t)h->S;
+	HIPCHK(h, hipHostMalloc(&h->ring_host, h->ring_slot_bytes * (size_t)nslots, hipHostMallocDefault));
+	h->ring_nslots = nslots;
+	h->ring_copied.resize((size_t)nslots);
+	h->ring_inflight.assign((size_t)nslots, 0);
+	for (int i = 0; i < nslots; ++i)
+		HIPCHK(h, hipEventCreateWithFlags(&h->ring_copied[(size_t)i], hipEventDisableTiming));
+	return VDL2GPU_OK;
+}
+
+extern "C" void *vdl2gpu_ring_acquire(vdl2gpu_t *h, size_t *stream_stride_bytes)
+{
+	if (!h || !h->ring_host || h->ring_acquired)
+		return nullptr;
+	const size_t slot = (size_t)(h->ring_next % (unsigned long long)h->ring_nslots);
+	if (h->ring_inflight[slot]) {	/* its copy to the GPU must have left the slot */
+		if (hipSetDevice(h->cfg.device) != hipSuccess || hipEventSynchronize(h->ring_copied[slot]) != hipSuccess) {
+			h->err = "vdl2gpu_ring_acquire: waiting for the slot failed";
+			return nullptr;
+		}
+		h->ring_inflight[slot] = 0;
+	}
+	if (stream_stride_bytes)
+		*stream_stride_bytes = h->ring_slot_samples * h->sample_bytes;
+	h->ring_acquired = true;
+	return (char *)h->ring_host + slot * h->ring_slot_bytes;
+}
+
+extern "C" int vdl2gpu_ring_commit(vdl2gpu_t *h, size_t nsamples)
+{
+	if (!h || !h->ring_host || !h->ring_acquired || nsamples > h->ring_slot_samples)
+		return VDL2GPU_EINVAL;
+	const size_t slot = (size_t)(h->ring_next % (unsigned long long)h->ring_nslots);
+	h->ring_acquired = false;
+	h->ring_next++;
+	if (nsamples == 0)
+		return VDL2GPU_OK;	/* e.g. a short USB read: the block is dropped (rtl.c:278-281) */
+	const int rc = push_impl(h, (char *)h->ring_host + slot * h->ring_slot_bytes, nsamples,
+				 h->ring_slot_samples * h->sample_bytes, VDL2GPU_MEM_HOST, false);
+	if (rc != VDL2GPU_OK)
+		return rc;
+	HIPCHK(h, hipEventRecord(h->ring_copied[slot], h->in_stream));
+	h->ring_inflight[slot] = 1;
+	return VDL2GPU_OK;
+}
+
+static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy)
 {
 	if (!h || (!iq && nsamples))
 		return VDL2GPU_EINVAL;
@@ -584,28 +670,37 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	}
 	const void *src = iq;
 	size_t stride = stream_stride_bytes;
+	bool staged_in = false;
+	const int stg = (int)(h->pushes & 1);	/* staging buffer of this push; its channeliser's events are k1_done[stg] */
 	if (memkind == VDL2GPU_MEM_HOST) {
 		const size_t per = nsamples * h->sample_bytes;
 		const size_t need = per * (size_t)h->S;
-		if (need > h->raw_bytes) {
-			HIPCHK(h, hipStreamSynchronize(h->k1_stream));
-			(void)hipFree(h->d_raw);
-			h->d_raw = nullptr;
-			h->raw_bytes = 0;
-			HIPCHK(h, hipMalloc(&h->d_raw, need));
-			h->raw_bytes = need;
+		if (!h->in_stream) {
+			HIPCHK(h, hipStreamCreateWithFlags(&h->in_stream, hipStreamNonBlocking));
+			for (int i = 0; i < 2; ++i)
+				HIPCHK(h, hipEventCreateWithFlags(&h->raw_copied[i], hipEventDisableTiming));
 		}
+		if (need > h->raw_bytes[stg]) {
+			HIPCHK(h, hipStreamSynchronize(h->k1_stream));
+			HIPCHK(h, hipStreamSynchronize(h->in_stream));
+			(void)hipFree(h->d_raw[stg]);
+			h->d_raw[stg] = nullptr;
+			h->raw_bytes[stg] = 0;
+			HIPCHK(h, hipMalloc(&h->d_raw[stg], need));
+			h->raw_bytes[stg] = need;
+		}
+		/* the channeliser of the push before last has read this buffer */
+		if (h->k1_rec[stg])
+			HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->k1_done[stg], 0));
 		for (int s = 0; s < h->S; ++s)
-			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw + (size_t)s * per,
+			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw[stg] + (size_t)s * per,
 						 (const char *)iq + (size_t)s * stream_stride_bytes, per,
-						 hipMemcpyHostToDevice, h->k1_stream));
-		/* the caller may reuse its buffer as soon as we return (the reference's producer refills
-		 * Cbuff right after the consumers pass Bar1, d8psk.c:383): wait for the copies only */
-		if (!h->copy_done)
-			HIPCHK(h, hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
-		HIPCHK(h, hipEventRecord(h->copy_done, h->k1_stream));
-		HIPCHK(h, hipEventSynchronize(h->copy_done));
-		src = h->d_raw;
+						 hipMemcpyHostToDevice, h->in_stream));
+		HIPCHK(h, hipEventRecord(h->raw_copied[stg], h->in_stream));
+		if (wait_copy)
+			HIPCHK(h, hipEventSynchronize(h->raw_copied[stg]));
+		staged_in = true;
+		src = h->d_raw[stg];
 		stride = per;
 	} else if (memkind != VDL2GPU_MEM_DEVICE)
 		return VDL2GPU_EINVAL;
@@ -641,6 +736,8 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	 * stream beside the demodulator chain of the previous push, whose one-workgroup-per-channel
 	 * steps leave most of the GPU idle. */
 	hipStream_t ks = h->k1_stream;
+	if (staged_in)
+		HIPCHK(h, hipStreamWaitEvent(ks, h->raw_copied[stg], 0));
 	if (h->k2_rec[par])
 		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_done[par], 0));
 	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* start beside the previous push's candidate sort, not beside its scan */
@@ -717,6 +814,7 @@ extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_
 	}
 	HIPCHK(h, hipEventRecord(pt.e[1], ks));
 	HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
+	h->k1_rec[par] = true;
 	{
 		KInitParams ki{};
 		ki.ctl = h->d_ctl + CTL_STAGE;

@@ -111,6 +111,24 @@ class Receiver:
         self._check(self.L.vdl2gpu_push(self.h, a.ctypes.data_as(C.c_void_p), n, nbytes, _lib.MEM_HOST))
         return n
 
+    # ------------------------------------------------------------------ ingest ring (include/vdl2gpu.h)
+    def ring_init(self, slot_samples: int, nslots: int = 4):
+        self._check(self.L.vdl2gpu_ring_init(self.h, slot_samples, nslots))
+        self._ring_slot_samples = slot_samples
+
+    def ring_acquire(self) -> np.ndarray:
+        """The next slot of page-locked host memory as a [nstreams, slot_bytes] uint8 view: fill it in
+        place (first ``nsamples * sample_bytes`` bytes of every row), then ``ring_commit(nsamples)``."""
+        stride = C.c_size_t(0)
+        p = self.L.vdl2gpu_ring_acquire(self.h, C.byref(stride))
+        if not p:
+            raise RuntimeError("vdl2gpu_ring_acquire: " + self.L.vdl2gpu_last_error(self.h).decode())
+        buf = (C.c_uint8 * (stride.value * self.nstreams)).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.nstreams, stride.value)
+
+    def ring_commit(self, nsamples: int):
+        self._check(self.L.vdl2gpu_ring_commit(self.h, nsamples))
+
     def push_device(self, ptr: int, nsamples: int, stream_stride_bytes: int = 0):
         """Samples already resident in HBM (e.g. ``tensor.data_ptr()``)."""
         self._check(self.L.vdl2gpu_push(self.h, C.c_void_p(ptr), nsamples, stream_stride_bytes, _lib.MEM_DEVICE))
@@ -123,6 +141,19 @@ class Receiver:
         buf = (_lib.BurstT * max_bursts)()
         while True:
             n = self._check(self.L.vdl2gpu_poll(self.h, buf, max_bursts))
+            for i in range(n):
+                b = buf[i]
+                out.append(Burst(b.stream, b.chn, b.Fr, b.nbrow, b.nlbyte, b.df, b.ppm, b.trig_dec, b.end_dec,
+                                 b.trig_sample, b.end_sample, bytes(b.data)))
+            if n < max_bursts:
+                return out
+
+    def poll_ready(self, max_bursts: int = 4096) -> List[Burst]:
+        """Bursts of pushes the GPU has already finished; never waits."""
+        out: List[Burst] = []
+        buf = (_lib.BurstT * max_bursts)()
+        while True:
+            n = self.poll_ready_raw(buf, max_bursts)
             for i in range(n):
                 b = buf[i]
                 out.append(Burst(b.stream, b.chn, b.Fr, b.nbrow, b.nlbyte, b.df, b.ppm, b.trig_dec, b.end_dec,

@@ -24,6 +24,7 @@ F_FRAMES = 16
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
     "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
+    "vdl2gpu_ring_init", "vdl2gpu_ring_acquire", "vdl2gpu_ring_commit",
     "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "vdl2gpu_decode_blocks", "vdl2gpu_poll_frames", "vdl2gpu_poll_frames_ready", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
     "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs",
@@ -99,6 +100,12 @@ def load():
     L.vdl2gpu_destroy.argtypes = [C.c_void_p]
     L.vdl2gpu_push.restype = C.c_int
     L.vdl2gpu_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+    L.vdl2gpu_ring_init.restype = C.c_int
+    L.vdl2gpu_ring_init.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.vdl2gpu_ring_acquire.restype = C.c_void_p
+    L.vdl2gpu_ring_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.vdl2gpu_ring_commit.restype = C.c_int
+    L.vdl2gpu_ring_commit.argtypes = [C.c_void_p, C.c_size_t]
     L.vdl2gpu_sync.restype = C.c_int
     L.vdl2gpu_sync.argtypes = [C.c_void_p]
     L.vdl2gpu_poll.restype = C.c_int
