@@ -27,8 +27,8 @@ for tag, d in (("FETCH_SIZE", "/tmp/pr_f"), ("WRITE_SIZE", "/tmp/pr_w")):
             agg[k] += float(r["Counter_Value"]); cnt[k] += 1
     res[tag + "_KB_per_launch"] = {k: agg[k] / cnt[k] for k in sorted(agg) if k.startswith(("k", "void k"))}
 res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu --no-parity "
-                "--steps 4 --warmup 2`; KB per kernel launch, averaged over launches (k1_fast is launched twice per push, "
-                "with 25 % and 75 % of the periods; the 4 synchronised pushes bench.py adds after its timed region are included)")
+                "--steps 4 --warmup 2`; KB per kernel launch, averaged over launches (one k1_fast launch per push; the synchronised "
+                "pushes and the ingest-ring pushes bench.py adds after its timed region are included)")
 json.dump(res, open(out + "/r01_bench_pmc_hbm.json", "w"), indent=1)
 PY
 python bench.py 2>/dev/null | tail -1 > $OUT/r01_bench_line.json
