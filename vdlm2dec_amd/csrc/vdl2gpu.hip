@@ -401,7 +401,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid_a, hipEventDisableTiming));
 	if (getenv("VDL2GPU_K1_SPLIT"))
 		h->k1_split = atof(getenv("VDL2GPU_K1_SPLIT"));
-	h->ctl_words = CTL_CAND0 + 7 * (size_t)S * VDL2_CS;
+	h->ctl_words = CTL_CAND0 + 8 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
@@ -1209,10 +1209,12 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		e = hipMalloc(&d_fr, (size_t)max_frames * sizeof(vdl2gpu_frame_t));
 	if (e == hipSuccess)
 		e = hipMalloc(&d_cnt, 4 * sizeof(unsigned));
+	/* on the stream the kernel runs on: that stream does not wait for the legacy default stream, and a
+	 * plain hipMemset() that lands after the kernel's first atomics loses frames */
 	if (e == hipSuccess)
-		e = hipMemcpy(d_blk, blocks, (size_t)n * sizeof(vdl2gpu_burst_t), hipMemcpyHostToDevice);
+		e = hipMemcpyAsync(d_blk, blocks, (size_t)n * sizeof(vdl2gpu_burst_t), hipMemcpyHostToDevice, h->copy_stream);
 	if (e == hipSuccess)
-		e = hipMemset(d_cnt, 0, 4 * sizeof(unsigned));
+		e = hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned), h->copy_stream);
 	unsigned cnt[2] = {0, 0};
 	if (e == hipSuccess) {
 		K4Params k4{};
@@ -1232,10 +1234,15 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 			e = hipStreamSynchronize(h->copy_stream);
 	}
 	if (e == hipSuccess)
-		e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+		e = hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->copy_stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(h->copy_stream);
 	const int nf = (int)std::min<unsigned>(cnt[0], (unsigned)max_frames);
-	if (e == hipSuccess && nf > 0)
-		e = hipMemcpy(frames, d_fr, (size_t)nf * sizeof(vdl2gpu_frame_t), hipMemcpyDeviceToHost);
+	if (e == hipSuccess && nf > 0) {
+		e = hipMemcpyAsync(frames, d_fr, (size_t)nf * sizeof(vdl2gpu_frame_t), hipMemcpyDeviceToHost, h->copy_stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(h->copy_stream);
+	}
 	cleanup();
 	if (e != hipSuccess) {
 		h->err = std::string("vdl2gpu_decode_blocks: ") + hipGetErrorString(e);
@@ -1393,9 +1400,9 @@ extern "C" int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	float *d = nullptr;
 	HIPCHK(h, hipMalloc(&d, 3 * n * sizeof(float)));
-	hipError_t e = hipMemcpy(d, y, n * sizeof(float), hipMemcpyHostToDevice);
+	hipError_t e = hipMemcpyAsync(d, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess)
-		e = hipMemcpy(d + n, x, n * sizeof(float), hipMemcpyHostToDevice);
+		e = hipMemcpyAsync(d + n, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_atan2f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, d + n, d + 2 * n, n);
 		e = hipStreamSynchronize(h->stream);
@@ -1418,8 +1425,10 @@ extern "C" int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int
 	if (rc)
 		return rc;
 	HIPCHK(h, hipMemcpy(out, h->d_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-	if (reset)
-		HIPCHK(h, hipMemset(h->d_dbg, 0, 64 * sizeof(unsigned long long)));
+	if (reset) {
+		HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+	}
 	return VDL2GPU_OK;
 }
 

@@ -37,6 +37,10 @@ void k2s_sort(K2Params p)
 	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
 	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
 	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
+	/* repair round: candidates are only ever appended and a cluster depends on nothing but its own
+	 * candidate and the samples, so the clusters of the earlier rounds stand -- only primaries that are new
+	 * (or were not primary before) go to K2b */
+	const int nold = (p.round > 0) ? (int)p.ctl[CTL_NCLUST0 + sc] : 0;
 	for (int j = tid; j < ncand; j += K2S_NT) {
 		const unsigned long long v = sbuf[j];
 		const int key = (int)(v >> 16), idx = (int)(v & 0xffffu);
@@ -53,14 +57,17 @@ void k2s_sort(K2Params p)
 				break;
 			}
 		}
-		if (primary)
+		int2 *head = p.clhead + (size_t)sc * VDL2_CAND_CAP + idx;
+		if (!primary)
+			*head = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
+		else if (idx >= nold || (head->y & 3) == CL_INVALID)
 			prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
-		else
-			p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
 	}
 	__syncthreads();
-	if (tid == 0)
+	if (tid == 0) {
 		p.ctl[CTL_NPRIM0 + sc] = (unsigned)s_np;
+		p.ctl[CTL_NCLUST0 + sc] = (unsigned)ncand;
+	}
 }
 
 /* ====================================================================== K2b

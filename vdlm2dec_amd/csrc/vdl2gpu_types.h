@@ -141,6 +141,7 @@ struct K2Params {
 #define CTL_NSEL0 (CTL_CAND0 + 4 * p.nstreams * VDL2_CS)
 #define CTL_NPRIM0 (CTL_CAND0 + 5 * p.nstreams * VDL2_CS)
 #define CTL_NSEED0 (CTL_CAND0 + 6 * p.nstreams * VDL2_CS)
+#define CTL_NCLUST0 (CTL_CAND0 + 7 * p.nstreams * VDL2_CS)	/* candidates [0, n) had their clusters decided by the previous K2s/K2b of this push */
 
 struct K3Params {
 	const float2 *src;
