@@ -255,10 +255,16 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	if (!h)
 		return;
 	(void)hipSetDevice(h->cfg.device);
+	if (h->in_stream)
+		(void)hipStreamSynchronize(h->in_stream);
 	if (h->k1_stream)
 		(void)hipStreamSynchronize(h->k1_stream);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
+	if (h->pay_stream)
+		(void)hipStreamSynchronize(h->pay_stream);
+	if (h->copy_stream)
+		(void)hipStreamSynchronize(h->copy_stream);
 	for (auto &pt : h->pending)
 		for (auto &e : pt.e)
 			(void)hipEventDestroy(e);
