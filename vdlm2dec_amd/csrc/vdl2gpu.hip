@@ -74,7 +74,6 @@ struct vdl2gpu {
 	uint8_t *d_pn = nullptr;
 	vdl2gpu_burst_t *d_recs[2] = { nullptr, nullptr };	/* output rings, alternating per push */
 	unsigned *d_outc = nullptr;	/* [ring][2] = records written, dropped */
-	hipEvent_t ring_done[2] = { nullptr, nullptr };
 	bool ring_busy[2] = { false, false };
 	uint64_t ring_push[2] = { 0, 0 };	/* which push filled the ring */
 	hipStream_t copy_stream = nullptr;
@@ -296,9 +295,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_fcnt);
 	(void)hipFree(h->d_k4tab);
 	(void)hipFree(h->d_outc);
-	for (auto &e : h->ring_done)
-		if (e)
-			(void)hipEventDestroy(e);
 	if (h->copy_stream)
 		(void)hipStreamDestroy(h->copy_stream);
 	for (int r = 0; r < 2; ++r) {
@@ -383,7 +379,6 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_pn, VDL2_PN_BITS));
 	for (int r = 0; r < 2; ++r) {
 		HIPCHK(h, hipMalloc(&h->d_recs[r], (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
-		HIPCHK(h, hipEventCreateWithFlags(&h->ring_done[r], hipEventDisableTiming));
 	}
 	HIPCHK(h, hipMalloc(&h->d_outc, 8 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 8 * sizeof(unsigned), h->stream));
@@ -746,7 +741,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipStreamWaitEvent(ks, h->raw_copied[stg], 0));
 	if (h->k2_rec[par])
 		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_done[par], 0));
-	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* start beside the previous push's candidate sort, not beside its scan */
+	/* start beside the previous push's candidate sort, not beside its scan: the first period's small kernel
+	 * runs there, so that the big one starts the moment the resolver does (waiting with both until then
+	 * saves an event record, 3 us, and loses 15) */
+	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))
 		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid_a, 0));
 	HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
@@ -988,7 +986,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
 	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
 	h->k2_rec[par] = true;
-	HIPCHK(h, hipEventRecord(h->ring_done[ring], h->stream));
+	/* (the same event tells the host that this push's output ring is complete: ring == par) */
 	h->ring_busy[ring] = true;
 	h->ring_push[ring] = h->pushes;
 	h->pending.push_back(pt);
@@ -1015,7 +1013,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	if (!h->ring_busy[ring])
 		return 0;
 	if (!blocking) {
-		const hipError_t q = hipEventQuery(h->ring_done[ring]);
+		const hipError_t q = hipEventQuery(h->k2_done[ring]);
 		if (q == hipErrorNotReady)
 			return 1;
 		if (q != hipSuccess) {
@@ -1023,7 +1021,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			return VDL2GPU_EHIP;
 		}
 	}
-	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
+	HIPCHK(h, hipEventSynchronize(h->k2_done[ring]));
 	const unsigned c0 = h->h_pin_cnt[24 * ring], c1 = h->h_pin_cnt[24 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
