@@ -71,10 +71,11 @@ void k2s_sort(K2Params p)
 }
 
 /* ====================================================================== K2b
- * One workgroup per trigger candidate (persistent workgroups pull tickets):
- * put the detector in the history-free state at the candidate, run the exact
- * machine through the burst (and any burst that follows before the detector is
- * history-free again) and record where and how the idle search resumes.
+ * One wavefront per primary trigger candidate (persistent workgroups pull tickets):
+ * handle the trigger from what the candidate record says the detector saw, rebuild
+ * the phase ring it returns to, run the exact machine through the 68 evaluations
+ * behind the burst (and any burst that follows before the detector is history-free
+ * again) and record where and how the idle search resumes.
  */
 #ifndef K2B_WAVES
 #define K2B_WAVES 4
