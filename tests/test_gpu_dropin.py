@@ -74,3 +74,40 @@ def test_gpu_front_end_and_gpu_block_path_feed_out(built, tmp_path, name):
             frames.setdefault(int(p[4][1:]) if multi else 0, []).append((int(p[1]), int(p[2]), p[-1]))
     for c in meta["channels"]:
         assert [f for _, _, f in frames.get(c["chn"], [])] == c["frames"], (name, c["chn"])
+
+
+def _fnv(data: bytes) -> int:
+    h = 1469598103934665603
+    for x in data:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_c_speed_caller_ring_and_frames_are_deterministic(built, oracle, tmp_path):
+    """A C program drives the ingest ring (32768-sample blocks, 3 slots) with the block path in the pipeline
+    and collects with the never-waiting calls -- nothing slows the caller down, so copies, kernels of several
+    pushes and read-backs overlap as much as they ever will.  Ten runs must give the oracle's bursts and
+    frames every time."""
+    import scenarios as S
+    from vdlm2dec_amd import synth
+    from vdlm2dec_amd.lib import LIB_PATH
+    exe = str(tmp_path / "ring_stress")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "ctests", "ring_stress.c"), LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(LIB_PATH)])
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 3_000_000, seed=4711, bursts_per_s=30.0, info_max=200)
+    raw = synth.synth_stream(spec, "cu8")
+    iq = str(tmp_path / "iq.raw")
+    raw.tofile(iq)
+    ob = oracle.run_oracle(raw, "cu8", spec.rate, spec.fo, S.FC)
+    want = sorted(["B %d %d %d %016x" % (b.chn, b.nbrow, b.nlbyte, _fnv(bytes(b.data[:b.nbrow * 255]))) for b in ob] +
+                  ["F %d %d %016x" % (b.chn, len(f), _fnv(f)) for b in ob
+                   for f in oracle.frames_of_block(b.nbrow, b.nlbyte, b.data)])
+    assert len(want) >= 60
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for rep in range(10):
+        out = subprocess.run([exe, iq, "cu8", str(spec.rate), str(len(spec.fo))] + [str(f) for f in spec.fo] +
+                             ["32768", "3"], capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert sorted(out.stdout.split("\n")[:-1]) == want, rep
