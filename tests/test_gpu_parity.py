@@ -328,3 +328,28 @@ def test_ingest_ring_equals_push(built, oracle):
                 got += rx.poll_ready()
         got += rx.poll()
     assert _gpu_keys(got) == want and len(want) >= 20
+
+
+def test_ingest_ring_multi_stream(built, oracle):
+    """Ring slots hold one run of samples per stream, `stride` bytes apart."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    specs = [S.eight_channels(seed=520 + i, dur=0.1) for i in range(2)]
+    raws = [synth.synth_stream(sp, "cs16") for sp in specs]
+    n = min(len(r) for r in raws) // 2      # complex samples
+    plans = [plan_channels(S.FC, sp.fo) for sp in specs]
+    blk = 50000
+    with Receiver(2_000_000, plans, fmt="cs16", max_push=blk) as rx:
+        rx.ring_init(blk, nslots=2)
+        got = []
+        for s0 in range(0, n, blk):
+            m = min(blk, n - s0)
+            slot = rx.ring_acquire()
+            for s, r in enumerate(raws):
+                slot[s, :4 * m] = r[2 * s0:2 * (s0 + m)].view(np.uint8)
+            rx.ring_commit(m)
+            got += rx.poll_ready()
+        got += rx.poll()
+    for s, sp in enumerate(specs):
+        want = sorted(b.key() for b in oracle.run_oracle(raws[s][:2 * n], "cs16", sp.rate, sp.fo, S.FC))
+        mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
+        assert mine == want and len(want) >= 8
