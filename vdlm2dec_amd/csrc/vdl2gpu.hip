@@ -1049,7 +1049,6 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			h->ready_pos = 0;
 		}
 		const size_t old = h->ready.size();
-		h->ready.reserve(old + n);
 		for (unsigned done = 0; done < n; done += h->pin_recs) {
 			const unsigned m = std::min(h->pin_recs, n - done);
 			HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_recs[ring] + done, (size_t)m * sizeof(vdl2gpu_burst_t),
