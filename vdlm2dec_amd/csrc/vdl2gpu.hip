@@ -67,6 +67,7 @@ struct vdl2gpu {
 	std::vector<hipEvent_t> ring_copied;
 	std::vector<char> ring_inflight;
 	float2 *d_lo = nullptr;
+	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
 	float2 *d_dec[2] = { nullptr, nullptr };
 	StreamState *d_ss = nullptr;
 	ChanState *d_cs = nullptr;
@@ -107,9 +108,6 @@ struct vdl2gpu {
 	unsigned *d_fmask = nullptr;	/* K2f's redo mask of the push in flight, 16 words */
 	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
-	double k1_split = 0.0;		/* share of the channeliser launched already at k2_mid_a (beside the candidate sort), the rest at
-					 * k2_mid (beside the resolver).  Measured: no throughput difference between 0 and 0.4, and one
-					 * launch keeps k1_fast's own time lower, so 0; VDL2GPU_K1_SPLIT overrides */
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
 	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted 0..4 from how often the serial fallback was needed */
@@ -282,6 +280,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	if (h->in_stream)
 		(void)hipStreamDestroy(h->in_stream);
 	(void)hipFree(h->d_lo);
+	(void)hipFree(h->d_lo_ext);
 	(void)hipFree(h->d_dec[0]);
 	(void)hipFree(h->d_dec[1]);
 	(void)hipFree(h->d_ss);
@@ -373,6 +372,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_dec[1], dec_bytes));
 	HIPCHK(h, hipMemsetAsync(h->d_dec[0], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
+	HIPCHK(h, hipMalloc(&h->d_lo_ext, (size_t)S * VDL2_CS * (L + 48) * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_ss, (size_t)S * sizeof(StreamState)));
 	HIPCHK(h, hipMalloc(&h->d_cs, (size_t)S * VDL2_CS * sizeof(ChanState)));
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
@@ -400,8 +400,6 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_fmask, 16 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_fmask, 0, 16 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid_a, hipEventDisableTiming));
-	if (getenv("VDL2GPU_K1_SPLIT"))
-		h->k1_split = atof(getenv("VDL2GPU_K1_SPLIT"));
 	h->ctl_words = CTL_CAND0 + 8 * (size_t)S * VDL2_CS;
 	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
@@ -455,6 +453,11 @@ static int create_impl(vdl2gpu_t *h)
 			cc[(size_t)s * VDL2_CS + c] = ChanCfg{ ch.chn, ch.Fr, ch.Fo, 0 };
 		}
 	HIPCHK(h, hipMemcpyAsync(h->d_lo, lo.data(), lo.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+	std::vector<float2> loe((size_t)S * VDL2_CS * (L + 48), make_float2(0.f, 0.f));
+	for (size_t sc = 0; sc < (size_t)S * VDL2_CS; ++sc)
+		for (int n = 0; n < L + 48; ++n)
+			loe[sc * (L + 48) + n] = lo[sc * L + ((n + L - 8) % L)];
+	HIPCHK(h, hipMemcpyAsync(h->d_lo_ext, loe.data(), loe.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 	HIPCHK(h, hipMemcpyAsync(h->d_cfg, cc.data(), cc.size() * sizeof(ChanCfg), hipMemcpyHostToDevice, h->stream));
 
 	/* scrambler sequence from seed 0x4D4B (d8psk.c:54-65, 299): identical for every burst */
@@ -765,53 +768,86 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			default: launch_k1<VDL2GPU_FMT_F32R>(q, grid, smem, ks); break;
 			}
 		};
-		const long long periods = J / K1F_PER_OUT;
-		const bool fast = (h->sdrclk == 500 && h->L == 80 && periods >= 4 && !getenv("VDL2GPU_NO_K1_FAST"));
+		/* whole periods of the schedule (4*SDRCLK inputs = 84 outputs, the LO table a whole number of times:
+		 * SDRINRATE = 4000*SDRCLK, air.c:138) on the period-parallel kernel; the first period (carried partial
+		 * window) and the tail on the general one */
+		const long long periods = J / K1P_PER_OUT;
+		const int per_in = 4 * h->sdrclk;
+		bool fast = (per_in % h->L == 0 && periods >= 4 && !getenv("VDL2GPU_NO_K1_FAST"));
+		K1PParams kp{};
 		if (fast) {
-			/* whole 1 ms periods in the middle on the register-resident fast path; the first
-			 * period (carried partial window) and the tail on the general kernel */
-			generic(0, K1F_PER_OUT - 1);
+			auto wend_abs = [&](long long j) { return ((j + 1) * (long long)h->sdrclk - k1.c0 + 20) / 21 - 1; };
+			kp.per_lo = 1;
+			kp.sbase0 = wend_abs(K1P_PER_OUT * kp.per_lo - 1) + 1;
+			/* 16-byte pieces: a period's first sample sits d samples above a 16-byte boundary, the same d for
+			 * every period (a period is a whole number of 16-byte pieces) and every stream */
+			const uintptr_t a0 = (uintptr_t)src + (uintptr_t)kp.sbase0 * h->sample_bytes;
+			if ((a0 % 16) % h->sample_bytes || (h->S > 1 && stride % 16) || ((size_t)per_in * h->sample_bytes) % 16)
+				fast = false;
+			kp.d = (int)((a0 % 16) / h->sample_bytes);
+		}
+		if (fast) {
+			generic(0, K1P_PER_OUT - 1);
 			pt.fast = true;
-			auto launch_fast = [&](long long per_lo, long long per_n, hipEvent_t ev0, hipEvent_t ev1) {
-				k1.per_lo = per_lo;
-				k1.per_n = per_n;
-				(void)hipEventRecord(ev0, ks);
-				/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of
-				 * rounds of the GPU's wave slots (5 per SIMD at this kernel's register count) */
-				{
-					const double work = (double)k1.per_n * K1F_ROLES * h->S;
-					const double slots = (double)h->n_cu * 4 * 5;
-					double rounds = std::ceil(work / (slots * K1F_PB));
-					if (rounds < 1)
-						rounds = 1;
-					long long pb = (long long)std::ceil(work / (slots * rounds));
-					pb = std::max<long long>(8, std::min<long long>(pb, 64));
-					k1.per_pb = (int)pb;
-				}
-				const dim3 grid((unsigned)((k1.per_n + k1.per_pb - 1) / k1.per_pb) * K1F_ROLES, (unsigned)h->S);
-				switch (h->cfg.fmt) {
-				case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CS16>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
-				}
-				(void)hipEventRecord(ev1, ks);
-			};
-			/* One launch beside the previous push's resolver, or (k1_split > 0) a first share already beside
-			 * its candidate sort: the stretches of the demodulator chain that run one workgroup per channel */
-			const long long per_all = periods - 2;
-			long long per_a = (long long)((double)per_all * h->k1_split);
-			per_a = (h->k2_mid_rec && per_all >= 64) ? std::min(per_a, per_all - 1) : 0;
-			pt.fast_parts = 0;
-			if (per_a > 0) {
-				launch_fast(1, per_a, pt.e[11], pt.e[12]);
-				pt.fast_parts++;
+			kp.raw = src;
+			kp.stream_stride = stride;
+			kp.nbch = h->C;
+			kp.per_in = per_in;
+			kp.L = h->L;
+			kp.ph0 = (int)(((long long)k1.no0 + kp.sbase0) % h->L);
+			kp.per_n = (int)(periods - 2);
+			kp.lo_ext = h->d_lo_ext;
+			kp.lo_stride = h->L + 48;
+			kp.dec = k1.dec;
+			kp.cap = h->cap;
+			kp.ss = h->d_ss;
+			auto wend_abs = [&](long long j) { return ((j + 1) * (long long)h->sdrclk - k1.c0 + 20) / 21 - 1; };
+			int nfmin = 1 << 30, nfmax = 0;
+			for (int k = 0; k < K1P_PER_OUT; ++k) {
+				kp.wend[k] = (int)(wend_abs(K1P_PER_OUT * kp.per_lo + k) - kp.sbase0);
+				const int nf = kp.wend[k] - (k ? kp.wend[k - 1] : -1);
+				nfmin = std::min(nfmin, nf);
+				nfmax = std::max(nfmax, nf);
 			}
-			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* the rest beside the previous push's resolver */
+			auto proven = [](int nf) { return nf == 23 || nf == 24 || nf == 59 || nf == 60 || nf == 71 || nf == 72 || nf == 119 || nf == 120; };
+			kp.fast_div = proven(nfmin) && proven(nfmax) && nfmax - nfmin <= 1;
+			kp.nf_lo = nfmin;
+			kp.dbg = getenv("VDL2GPU_K1_DBG") ? atoi(getenv("VDL2GPU_K1_DBG")) : 0;
+			kp.rcp_lo = 1.0f / (float)nfmin;
+			kp.rcp_hi = 1.0f / (float)(nfmin + 1);
+			/* tasks = (blocks of 64 periods) x (runs of wpt windows): enough of them that the last round of
+			 * workgroups is a small share of the launch, as long as possible otherwise */
+			const long long blocks = (kp.per_n + 63) / 64;
+			const int divs[] = {1, 2, 3, 4, 6, 7, 12, 14, 21, 28};
+			const long long resident = (long long)h->n_cu * 3;
+			int best = 1;
+			double best_eff = -1;
+			for (int nsub : divs) {
+				const long long tasks = blocks * nsub * h->S;
+				const long long rounds = (tasks + resident - 1) / resident;
+				const double eff = (double)tasks / (double)(rounds * resident) - 0.004 * nsub;	/* shorter tasks pay their start-up more often */
+				if (eff > best_eff) {
+					best_eff = eff;
+					best = nsub;
+				}
+			}
+			if (getenv("VDL2GPU_K1_NSUB"))
+				best = atoi(getenv("VDL2GPU_K1_NSUB"));
+			kp.nsub = best;
+			kp.wpt = K1P_PER_OUT / best;
+			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
-			launch_fast(1 + per_a, per_all - per_a, pt.e[8], pt.e[9]);
-			pt.fast_parts++;
-			generic((periods - 1) * K1F_PER_OUT, J);
+			(void)hipEventRecord(pt.e[8], ks);
+			const dim3 grid((unsigned)(blocks * kp.nsub), (unsigned)h->S);
+			switch (h->cfg.fmt) {
+			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CU8>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
+			case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CS16>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
+			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CF32>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
+			default: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_F32R>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
+			}
+			(void)hipEventRecord(pt.e[9], ks);
+			pt.fast_parts = 1;
+			generic((periods - 1) * K1P_PER_OUT, J);
 		} else
 			generic(0, J);
 		HIPCHK(h, hipGetLastError());

@@ -120,185 +120,365 @@ void k1_channelise(K1Params p)
 }
 
 
-/* ---- K1 fast path: SDRINRATE 2 MS/s (SDRCLK 500, LO period 80) ------------------------
- * The dump schedule and the LO phase repeat every 2000 inputs = 84 outputs (1 ms of air
- * time).  One WAVEFRONT owns 8 consecutive windows of the period x 8 channels (lane =
- * window*8 + channel) for many periods.  A lane's 23/24 LO values never change, so they
- * live in VGPRs; the ~190 samples the wave's 8 windows cover are fetched by the wave itself
- * (3 coalesced loads per lane), converted once, and parked in a private double-buffered LDS
- * slice, from which each sample is read once per window and broadcast to the 8 channel
- * lanes.  Inner loop: 1 LDS read + 8 VALU ops per sample and channel.  No workgroup
- * barrier anywhere: wavefronts never wait for each other, 16 of them per CU hide HBM latency.
- * 84 = 10*8 + 4, so 11 wave roles cover a period (the last one half empty). */
+/* ---- K1 fast path: whole periods of the schedule, any rate ----------------------------
+ * The dump schedule and the LO phase repeat every PER = 4*SDRCLK inputs = 84 outputs (1 ms of air
+ * time; 2000 inputs at 2 MS/s, 10000 at 10 MS/s), so 64 consecutive periods are 64 copies of the
+ * same program: same window boundaries, same LO value at every step, different samples.  That is
+ * the wavefront: LANE = PERIOD, WAVE = CHANNEL, eight waves (the stream's eight channels) to a
+ * workgroup that shares the samples.
+ *
+ *   LO      wave-uniform, so it lives in SGPRs: one s_load_dwordx16 per 8 samples from the
+ *           channel's table, and the mixer's packed multiplies take it as their scalar operand.
+ *           No LO registers per lane, hence no limit on the window length (119/120 samples at
+ *           10 MS/s cost what 23/24 do at 2 MS/s).
+ *   x       a workgroup fetches a chunk of 32 samples of each of its 64 periods with ONE 16-byte
+ *           load per thread (8 threads cover a period's 128 contiguous bytes), converts once
+ *           (rtl.c:287-289 / SURVEY A.1) and parks float2 in LDS, row = period.  The next chunk is
+ *           in flight in registers while this one is mixed.  Every lane reads its own row: one
+ *           conflict-free ds_read_b64 per sample and wave, nothing to broadcast.
+ *   mixer   per sample and channel the reference's eight roundings as four packed-FP32
+ *           instructions (k1_cmac_s), accumulated in stream order: bit-identical to d8psk.c:368.
+ *   out     a lane finishes a window of ITS period every 23/24 samples; eight of them are parked in
+ *           a wave-private LDS tile [window][period] and leave as 64-byte runs of the channel plane
+ *           (4 lanes x 16 bytes), instead of 8-byte scattered stores.
+ *
+ * A workgroup's task is (64 periods) x (a run of `wpt` windows of the period), so that a push is
+ * several thousand tasks whatever its length.  All control flow is wave-uniform (scalar branches).
+ * Gfx950 issues plain FP32 at 2 cycles and packed FP32 at 4 per wave64, so the mixer costs
+ * 16 issue cycles per sample and channel either way: that, not HBM, bounds this kernel
+ * (scripts/micro/valu_rate.hip measures 4.6-4.9 cycles per packed op with all SIMDs busy). */
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const v16f __attribute__((address_space(4))) *k1_cptr16;	/* constant address space: scalar loads */
 
-/* (re, im) += x * w for complex x, w with the reference's operation order
+/* acc += x * w for complex x (VGPR pair), w (SGPR pair) with the reference's operation order
  *   pr = x.re*w.re - x.im*w.im;  pi = x.re*w.im + x.im*w.re;  acc += (pr, pi)
- * as four packed-FP32 VALU ops (gfx950 issues plain FP32 at half the packed rate):
+ * as four packed-FP32 VALU ops:
  *   a = (x.re*w.re, x.re*w.im)          v_pk_mul_f32, op_sel picks x.re twice
  *   b = (x.im*(-w.im), x.im*w.re)       v_pk_mul_f32, halves of w swapped, low lane negated
  *   acc += (a + b)                      2 x v_pk_add_f32
- * a.lo + b.lo = x.re*w.re + (-(x.im*w.im)) is bit-identical to the subtraction. */
-__device__ __forceinline__ void k1_cmac(v2f &acc, v2f x, v2f w)
+ * a.lo + b.lo = x.re*w.re + (-(x.im*w.im)) is bit-identical to the subtraction.  One volatile
+ * block: the compiler must not turn the uniform branches around it into selects. */
+__device__ __forceinline__ void k1_cmac_s(v2f &acc, v2f x, v2f w)
 {
 	v2f a, b;
-	asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
-	    "v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
-	    : "=&v"(a), "=&v"(b)
-	    : "v"(x), "v"(w));
-	acc += (a + b);
+	asm volatile("v_pk_mul_f32 %1, %3, %4 op_sel_hi:[0,1]\n\t"
+		     "v_pk_mul_f32 %2, %3, %4 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+		     "s_nop 0\n\t"
+		     "v_pk_add_f32 %1, %1, %2\n\t"
+		     "s_nop 0\n\t"
+		     "v_pk_add_f32 %0, %0, %1"
+		     : "+v"(acc), "=&v"(a), "=&v"(b)
+		     : "v"(x), "s"(w));
 }
 
-#define K1F_THREADS 64
-#define K1F_PB 32		/* periods per wavefront */
-#define K1F_DEPTH 4		/* periods of raw samples in flight per wavefront (registers) */
-#define K1F_PER_IN 2000
-#define K1F_PER_OUT 84
-#define K1F_ROLES 11
-#define K1F_SLICE 192		/* >= 8 windows x 24 samples */
-
-template <int FMT> struct K1Raw;
-template <> struct K1Raw<VDL2GPU_FMT_CU8> { typedef unsigned short T; };
-template <> struct K1Raw<VDL2GPU_FMT_CS16> { typedef unsigned int T; };
-template <> struct K1Raw<VDL2GPU_FMT_CF32> { typedef float2 T; };
-template <> struct K1Raw<VDL2GPU_FMT_F32R> { typedef float T; };
-
-template <int FMT> __device__ __forceinline__ typename K1Raw<FMT>::T k1_raw_load(const char *raw, long long i)
+/* real input (air.c:206-208): D += x * wf is (x*w.re, x*w.im), no cross terms (d8psk.c:368 with a float Cbuff) */
+__device__ __forceinline__ void k1_rmac_s(v2f &acc, float x, v2f w)
 {
-	return reinterpret_cast<const typename K1Raw<FMT>::T *>(raw)[i];
+	v2f a;
+	asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
+		     "s_nop 0\n\t"
+		     "v_pk_add_f32 %0, %0, %1"
+		     : "+v"(acc), "=&v"(a)
+		     : "v"((v2f){x, x}), "s"(w));
 }
 
-template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<FMT>::T v)
+/* Eight samples in one block, software-pipelined so that no instruction reads what the one before it
+ * wrote (gfx950 needs a wait state there for packed FP32, and a wave that spends it on s_nop gives the
+ * slot away): A/B = the two products of a sample, T = their sum, S = acc += T, in the order
+ *   A0 B0 A1 B1 T0 A2 B2 T1 S0 A3 B3 T2 S1 ... A7 B7 T6 S5 T7 S6 . S7
+ * -- the S chain is the reference's accumulation order, sample by sample. */
+#define K1_A(t, x, w) "v_pk_mul_f32 " t ", " x ", " w " op_sel_hi:[0,1]\n\t"
+#define K1_B(t, x, w) "v_pk_mul_f32 " t ", " x ", " w " op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+#define K1_T(a, b) "v_pk_add_f32 " a ", " a ", " b "\n\t"
+#define K1_S(a) "v_pk_add_f32 %0, %0, " a "\n\t"
+__device__ __forceinline__ void k1_cmac8_s(v2f &acc, const v2f (&x)[8], const v16f w)
 {
+	v2f a0, b0, a1, b1, a2, b2;
+	asm volatile(
+		K1_A("%1", "%7", "%15") K1_B("%2", "%7", "%15")
+		K1_A("%3", "%8", "%16") K1_B("%4", "%8", "%16")
+		K1_T("%1", "%2")
+		K1_A("%5", "%9", "%17") K1_B("%6", "%9", "%17")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%10", "%18") K1_B("%2", "%10", "%18")
+		K1_T("%5", "%6")
+		K1_S("%3")
+		K1_A("%3", "%11", "%19") K1_B("%4", "%11", "%19")
+		K1_T("%1", "%2")
+		K1_S("%5")
+		K1_A("%5", "%12", "%20") K1_B("%6", "%12", "%20")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%13", "%21") K1_B("%2", "%13", "%21")
+		K1_T("%5", "%6")
+		K1_S("%3")
+		K1_A("%3", "%14", "%22") K1_B("%4", "%14", "%22")
+		K1_T("%1", "%2")
+		K1_S("%5")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		"s_nop 0\n\t"
+		K1_S("%3")
+		: "+v"(acc), "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2)
+		: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+		  "s"((v2f){w[0], w[1]}), "s"((v2f){w[2], w[3]}), "s"((v2f){w[4], w[5]}), "s"((v2f){w[6], w[7]}),
+		  "s"((v2f){w[8], w[9]}), "s"((v2f){w[10], w[11]}), "s"((v2f){w[12], w[13]}), "s"((v2f){w[14], w[15]}));
+}
+
+/* What a block of 8 samples needs, requested in one go and waited for once: the 8 LO values of the wave's
+ * channel (one s_load_dwordx16 into SGPRs) and 8 consecutive float2 of this lane's LDS row -- as eight
+ * ds_read_b64: the LDS serves those at 256 bytes a clock, the ds_read2_b64 the compiler would merge them into
+ * gets half of that, and at one read per sample and wave the LDS is nearly as busy as the VALU. */
+__device__ __forceinline__ void k1_load_block(v16f &w, v2f (&x)[8], const float2 *lo, const unsigned a)
+{
+	asm volatile("s_load_dwordx16 %8, %10, 0x0\n\t"
+		     "ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\t"
+		     "ds_read_b64 %3, %9 offset:24\n\tds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\t"
+		     "ds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56\n\ts_waitcnt lgkmcnt(0)"
+		     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&s"(w)
+		     : "v"(a), "s"(lo)
+		     : "memory");
+}
+
+__device__ __forceinline__ void k1_load_block_nos(v16f &w, v2f (&x)[8], const float2 *lo, const unsigned a)
+{
+	asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\t"
+		     "ds_read_b64 %3, %8 offset:24\n\tds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\t"
+		     "ds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56\n\ts_waitcnt lgkmcnt(0)"
+		     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+		     : "v"(a)
+		     : "memory");
+	w = (v16f)(1.0f);
+}
+__device__ __forceinline__ void k1_load_block_nol(v16f &w, v2f (&x)[8], const float2 *lo, const unsigned a)
+{
+	asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(lo) : "memory");
+#pragma unroll
+	for (int u = 0; u < 8; ++u)
+		x[u] = (v2f){1.0f, 2.0f};
+}
+#define K1P_THREADS 512
+#define K1P_CH 32		/* samples of every period per chunk */
+#define K1P_XROW (K1P_CH + 1)	/* LDS row of a period: +1 keeps the lanes' reads on distinct banks */
+#define K1P_OROW 65
+#define K1P_PER_OUT 84
+
+template <int FMT> struct K1Fmt;
+template <> struct K1Fmt<VDL2GPU_FMT_CU8> { enum { BYTES = 2, SPB = 8 }; };	/* SPB: samples per 16-byte piece */
+template <> struct K1Fmt<VDL2GPU_FMT_CS16> { enum { BYTES = 4, SPB = 4 }; };
+template <> struct K1Fmt<VDL2GPU_FMT_CF32> { enum { BYTES = 8, SPB = 2 }; };
+template <> struct K1Fmt<VDL2GPU_FMT_F32R> { enum { BYTES = 4, SPB = 4 }; };
+
+/* one 16-byte piece of raw samples -> SPB converted samples */
+template <int FMT> __device__ __forceinline__ void k1_piece_cvt(const uint4 v, float2 *out)
+{
+	const unsigned w[4] = {v.x, v.y, v.z, v.w};
 	if constexpr (FMT == VDL2GPU_FMT_CU8) {
-		return make_float2((float)(v & 0xffu) - (float)127.37, (float)(v >> 8) - (float)127.37);
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const unsigned h = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+			out[u] = make_float2((float)(h & 0xffu) - (float)127.37, (float)(h >> 8) - (float)127.37);
+		}
 	} else if constexpr (FMT == VDL2GPU_FMT_CS16) {
-		return make_float2((float)(short)(v & 0xffffu), (float)(short)(v >> 16));
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			out[u] = make_float2((float)(short)(w[u] & 0xffffu), (float)(short)(w[u] >> 16));
 	} else if constexpr (FMT == VDL2GPU_FMT_CF32) {
-		return v;
+		out[0] = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+		out[1] = make_float2(__uint_as_float(w[2]), __uint_as_float(w[3]));
 	} else {
-		return make_float2(v, 0.0f);
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			out[u] = make_float2(__uint_as_float(w[u]), 0.0f);
 	}
 }
 
-template <int FMT> __global__ __launch_bounds__(K1F_THREADS)
-void k1_fast(K1Params p)
+template <int FMT> __global__ __launch_bounds__(K1P_THREADS, 6)
+void k1_pp(K1PParams p)
 {
-	typedef typename K1Raw<FMT>::T raw_t;
-	__shared__ float2 xs[K1F_SLICE];
-	const int lane = threadIdx.x;
+	constexpr int B = K1Fmt<FMT>::BYTES, SPB = K1Fmt<FMT>::SPB;
+	constexpr int NPIECE = K1P_CH / SPB;			/* 16-byte pieces per period and chunk */
+	constexpr int NPT = (64 * NPIECE + K1P_THREADS - 1) / K1P_THREADS;	/* pieces per thread */
+	__shared__ float2 xs[8 + 64 * K1P_XROW + 8];	/* 8 entries of pad on either side: blocks of 8 are read whole */
+	__shared__ float2 os[8][8 * K1P_OROW];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int s = blockIdx.y;
-	const int g = blockIdx.x % K1F_ROLES;
-	/* Wave group w = blockIdx.x / ROLES handles periods per_lo + w, + w + NW, + w + 2 NW, .. (NW =
-	 * number of wave groups): at every loop iteration the whole grid reads one contiguous band of
-	 * NW periods and writes one contiguous band of each plane, which keeps HBM pages open, instead
-	 * of every wave streaming through its own distant range. */
-	const long long nw = (long long)(gridDim.x / K1F_ROLES);
-	const long long wgrp = (long long)(blockIdx.x / K1F_ROLES);
-	const long long pp0 = p.per_lo + wgrp;
-	if (wgrp >= p.per_n)
-		return;
-	const int np = (int)((p.per_n - wgrp + nw - 1) / nw);	/* periods pp0 + q*nw, q < np */
-	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this wave's periods */
-	const int kk = lane >> 3, c = lane & 7;
-	const int k = g * 8 + kk;
-	const bool active = (k < K1F_PER_OUT) && (c < p.nbch);
-	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
+	const int blk = (int)(blockIdx.x / (unsigned)p.nsub), sub = (int)(blockIdx.x % (unsigned)p.nsub);
+	const int k0 = sub * p.wpt, k1 = k0 + p.wpt;		/* this task's windows of the period */
+	const int pb = blk * 64;				/* its first period, counted from per_lo */
+	const int nper = (p.per_n - pb < 64) ? p.per_n - pb : 64;
 	const long long fill = p.ss[s].dec_fill;
-	/* slice of this wave in period pp0: from the first sample of window 8g to the last of window 8g+7 */
-	const long long j0 = pp0 * K1F_PER_OUT + g * 8;		/* >= 84 */
-	const int klast = (g * 8 + 7 < K1F_PER_OUT) ? 7 : (K1F_PER_OUT - 1 - g * 8);
-	const long long sbase = k1_win_end(j0 - 1, p.sdrclk, p.c0) + 1;
-	const int slen = (int)(k1_win_end(j0 + klast, p.sdrclk, p.c0) - sbase + 1);
-	int off = 0, nwin = 0;
-	v2f w[24];
+	const bool active = c < p.nbch;
+	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride + (size_t)p.sbase0 * B;	/* first sample of period per_lo */
+
+	/* loader role: NPT pieces (period lp, piece lj) */
+	const char *lptr[NPT];
+	int lcol[NPT];
+	bool lval[NPT];
 #pragma unroll
-	for (int t = 0; t < 24; ++t)
-		w[t] = (v2f){0.0f, 0.0f};
-	if (active) {
-		const long long j = j0 + kk;
-		const long long a = k1_win_end(j - 1, p.sdrclk, p.c0) + 1;
-		const long long b = k1_win_end(j, p.sdrclk, p.c0);
-		off = (int)(a - sbase);
-		nwin = (int)(b - a + 1);
-		int ph = (int)((p.no0 + a) % 80);
-		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + c) * 80;
+	for (int j = 0; j < NPT; ++j) {
+		const int q = tid + j * K1P_THREADS;
+		const int lp = q / NPIECE, lj = q % NPIECE;
+		lval[j] = q < 64 * NPIECE;
+		const int pp = lp < nper ? lp : nper - 1;	/* lanes beyond the last period re-read it (and store nothing) */
+		lptr[j] = raw + ((long long)(pb + pp) * p.per_in - p.d) * B + lj * 16;
+		lcol[j] = 8 + (lp < 64 ? lp : 63) * K1P_XROW + lj * SPB;
+	}
+
+	int k = k0;
+	int i = (k0 == 0) ? 0 : p.wend[k0 - 1] + 1;		/* period-relative sample index */
+	int wend = p.wend[k0];
+	int nf = wend - i + 1;
+	const int i_stop = p.wend[k1 - 1] + 1;
+	int wi = (p.ph0 + i) % p.L;
+	int slot = 0, kflush = k0;
+	v2f acc = {0.0f, 0.0f};
+	const float2 *lo = p.lo_ext + ((size_t)s * VDL2_CS + (active ? c : 0)) * p.lo_stride + 8;	/* 8 entries of front pad */
+	const unsigned xrow = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xs[8 + lane * K1P_XROW];
+	const int m0 = (i + p.d) / K1P_CH, m1 = (i_stop - 1 + p.d) / K1P_CH;
+	float2 *decp = p.dec + ((size_t)s * VDL2_CS + (active ? c : 0)) * p.cap + fill + (p.per_lo + pb) * K1P_PER_OUT;
+
+	uint4 rr[NPT];
 #pragma unroll
-		for (int t = 0; t < 24; ++t) {
-			const float2 q = lo[ph];
-			w[t] = (v2f){q.x, q.y};
-			ph = (ph + 1 == 80) ? 0 : ph + 1;
+	for (int j = 0; j < NPT; ++j)
+		rr[j] = *reinterpret_cast<const uint4 *>(lptr[j] + (long long)m0 * K1P_CH * B);
+	for (int m = m0; m <= m1; ++m) {
+		if (!(p.dbg & 8))
+			__syncthreads();	/* the previous chunk has been read by every wave */
+#pragma unroll
+		for (int j = 0; j < NPT; ++j)
+			if (lval[j]) {
+				float2 cv[SPB];
+				k1_piece_cvt<FMT>(rr[j], cv);
+#pragma unroll
+				for (int u = 0; u < SPB; ++u)
+					xs[lcol[j] + u] = cv[u];
+			}
+		if (m < m1 && !(p.dbg & 2)) {
+#pragma unroll
+			for (int j = 0; j < NPT; ++j)
+				rr[j] = *reinterpret_cast<const uint4 *>(lptr[j] + (long long)(m + 1) * K1P_CH * B);
 		}
-	}
-	const float fn = (float)nwin;
-	const float rfn = 1.0f / (nwin ? fn : 1.0f);	/* RN(1/nf) for the exact FMA division below */
-	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill + pp0 * K1F_PER_OUT + k;
-	/* lanes fetch samples lane, lane+64, lane+128 of the slice (clamped: the tail lanes of the
-	 * last load re-read the last sample instead of branching) */
-	int li[3];
+		if (!(p.dbg & 8))
+			__syncthreads();
+		if (!active || (p.dbg & 1))
+			continue;
+		const int cb = m * K1P_CH - p.d;	/* period-relative index of the chunk's first sample */
+		const int hi = (i_stop < cb + K1P_CH) ? i_stop : cb + K1P_CH;
+		while (i < hi) {
+			/* a piece: the samples up to the window's or the chunk's end, as blocks of 8 and a tail */
+			const int lim = (hi < wend + 1) ? hi : wend + 1;
+			int n = lim - i;
+			unsigned xa = xrow + (unsigned)(i - cb) * 8u;
+			const float2 *lp = lo + wi;
+			i = lim;
+			wi += n;
+			if (wi >= p.L)
+				wi -= p.L;
+			for (; n >= 8; n -= 8) {
+				v16f w;
+				v2f xr[8];
+				if (p.dbg & 16) {
+					w = (v16f)(1.0f);
 #pragma unroll
-	for (int u = 0; u < 3; ++u) {
-		const int i = lane + u * 64;
-		li[u] = i < slen ? i : slen - 1;
-	}
-	raw_t rr[K1F_DEPTH][3];
+					for (int u = 0; u < 8; ++u)
+						xr[u] = acc;
+				} else if (p.dbg & 512)
+					k1_load_block_nos(w, xr, lp, xa);
+				else if (p.dbg & 1024)
+					k1_load_block_nol(w, xr, lp, xa);
+				else
+					k1_load_block(w, xr, lp, xa);
+				if constexpr (FMT == VDL2GPU_FMT_F32R) {
 #pragma unroll
-	for (int d = 0; d < K1F_DEPTH; ++d)
-#pragma unroll
-		for (int u = 0; u < 3; ++u)
-			rr[d][u] = k1_raw_load<FMT>(raw, sbase + pstride * (d < np ? d : np - 1) + li[u]);
-	for (int q0 = 0; q0 < np; q0 += K1F_DEPTH) {
-#pragma unroll
-		for (int d = 0; d < K1F_DEPTH; ++d) {
-			const int q = q0 + d;
-			if (q < np) {
-				/* period q: registers -> float -> LDS slice, then refill the registers
-				 * with period q+DEPTH so that DEPTH periods stay in flight.  (A second LDS
-				 * slice to take this write off the mixer's critical path measured slower.) */
-#pragma unroll
-				for (int u = 0; u < 3; ++u)
-					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
-				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
-#pragma unroll
-				for (int u = 0; u < 3; ++u)
-					rr[d][u] = k1_raw_load<FMT>(raw, sbase + pstride * qn + li[u]);
-				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
-				if (active) {
-					const v2f *xp = reinterpret_cast<const v2f *>(&xs[off]);
-					v2f acc = {0.0f, 0.0f};
-					if (FMT == VDL2GPU_FMT_F32R) {
-#pragma unroll
-						for (int t = 0; t < 23; ++t) {
-							const float x = xp[t].x;
-							acc += (v2f){x, x} * w[t];
-						}
-						if (nwin == 24) {
-							const float x = xp[23].x;
-							acc += (v2f){x, x} * w[23];
-						}
-					} else {
-#pragma unroll
-						for (int t = 0; t < 23; ++t)
-							k1_cmac(acc, xp[t], w[t]);
-						if (nwin == 24)
-							k1_cmac(acc, xp[23], w[23]);
-					}
-					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
-					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
-					 * checked for nf = 23, 24: tests/ctests/div_check.c); below that, and only
-					 * then, the plain IEEE division is used */
-					float qr, qi;
-					if (__all(fabsf(acc.x) >= 1e-30f && fabsf(acc.y) >= 1e-30f)) {
-						const float q0r = acc.x * rfn, q0i = acc.y * rfn;
-						qr = fmaf(fmaf(-q0r, fn, acc.x), rfn, q0r);
-						qi = fmaf(fmaf(-q0i, fn, acc.y), rfn, q0i);
-					} else {
-						qr = acc.x / fn;
-						qi = acc.y / fn;
-					}
-					dec[(long long)q * K1F_PER_OUT * nw] = make_float2(qr, qi);
+					for (int u = 0; u < 8; ++u)
+						k1_rmac_s(acc, xr[u].x, (v2f){w[2 * u], w[2 * u + 1]});
+				} else if (!(p.dbg & 64))
+					k1_cmac8_s(acc, xr, w);
+				lp += 8;
+				xa += 64;
+			}
+			if (n && !(p.dbg & 128)) {
+				/* the tail: read the 8 entries that END with it (what lies before is the row's or the table's
+				 * front pad or earlier samples) and enter the unrolled sequence n steps before its end */
+				v16f w;
+				v2f xr[8];
+				if (p.dbg & 512)
+					k1_load_block_nos(w, xr, lp - (8 - n), xa - (unsigned)(8 - n) * 8u);
+				else if (p.dbg & 1024)
+					k1_load_block_nol(w, xr, lp - (8 - n), xa - (unsigned)(8 - n) * 8u);
+				else
+					k1_load_block(w, xr, lp - (8 - n), xa - (unsigned)(8 - n) * 8u);
+#define K1_TAIL(u) if constexpr (FMT == VDL2GPU_FMT_F32R) k1_rmac_s(acc, xr[u].x, (v2f){w[2 * (u)], w[2 * (u) + 1]}); \
+		   else k1_cmac_s(acc, xr[u], (v2f){w[2 * (u)], w[2 * (u) + 1]});
+				switch (n) {
+				case 7: K1_TAIL(1)
+				case 6: K1_TAIL(2)
+				case 5: K1_TAIL(3)
+				case 4: K1_TAIL(4)
+				case 3: K1_TAIL(5)
+				case 2: K1_TAIL(6)
+				default: K1_TAIL(7)
 				}
-				__syncthreads();	/* reads done before the slice is overwritten */
+#undef K1_TAIL
+			}
+			if (i > wend && (p.dbg & 256)) {
+				acc = (v2f){0.0f, 0.0f};
+				++k;
+				if (k < k1) {
+					const int e = p.wend[k];
+					nf = e - wend;
+					wend = e;
+				}
+			} else if (i > wend) {
+				/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0) is the
+				 * correctly rounded quotient for every |x| >= 1e-30 and nf in {23,24,59,60,71,72,119,120}
+				 * (exhaustively checked: tests/ctests/div_check.c); otherwise the plain IEEE division */
+				const float fn = (float)nf;
+				float qr, qi;
+				if (p.fast_div && __all(fabsf(acc.x) >= 1e-30f && fabsf(acc.y) >= 1e-30f)) {
+					const float rfn = (nf == p.nf_lo) ? p.rcp_lo : p.rcp_hi;
+					const float q0r = acc.x * rfn, q0i = acc.y * rfn;
+					qr = fmaf(fmaf(-q0r, fn, acc.x), rfn, q0r);
+					qi = fmaf(fmaf(-q0i, fn, acc.y), rfn, q0i);
+				} else {
+					qr = acc.x / fn;
+					qi = acc.y / fn;
+				}
+				os[c][slot * K1P_OROW + lane] = make_float2(qr, qi);
+				acc = (v2f){0.0f, 0.0f};
+				++slot;
+				++k;
+				if (slot == 8 || k == k1) {
+					/* 8 windows x 64 periods -> 64-byte runs of the plane: lane = (period, pair of windows) */
+					__builtin_amdgcn_wave_barrier();
+#pragma unroll
+					for (int it = 0; it < 4; ++it) {
+						const int pp = it * 16 + (lane >> 2), q = lane & 3;
+						if (pp < nper && 2 * q < slot && !(p.dbg & 4)) {
+							const float2 v0 = os[c][(2 * q) * K1P_OROW + pp];
+							float2 *dst = decp + (long long)pp * K1P_PER_OUT + kflush + 2 * q;
+							if (2 * q + 1 < slot) {
+								const float2 v1 = os[c][(2 * q + 1) * K1P_OROW + pp];
+								typedef float k1_v4a8 __attribute__((ext_vector_type(4), aligned(8)));
+								*reinterpret_cast<k1_v4a8 *>(dst) = (k1_v4a8){v0.x, v0.y, v1.x, v1.y};
+							} else
+								*dst = v0;
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+					kflush = k;
+					slot = 0;
+				}
+				if (k < k1) {
+					const int e = p.wend[k];
+					nf = e - wend;
+					wend = e;
+				}
 			}
 		}
 	}

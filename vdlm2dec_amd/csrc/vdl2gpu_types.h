@@ -84,12 +84,34 @@ struct K1Params {
 	int c0, no0, nf0, parity;
 	long long N, J;
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
-	long long per_lo, per_n;	/* fast kernel: whole 84-output periods [per_lo, per_lo+per_n) */
-	int per_pb;		/* periods per wavefront (chosen so that the waves fill the GPU evenly) */
 	const float2 *lo;	/* [S][8][L] */
 	float2 *dec;		/* this push's planes, [S][8][cap] */
 	long long cap;
 	StreamState *ss;
+};
+
+struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs) [per_lo, per_lo + per_n) of a push */
+	const void *raw;
+	size_t stream_stride;
+	int nbch;
+	int per_in;		/* inputs per period */
+	int L;			/* LO table length */
+	int ph0;		/* LO index of a period's first sample */
+	int d;			/* samples between the 16-byte boundary below a period's first sample and that sample */
+	int fast_div;		/* both window lengths are in the set the reciprocal division is proven exact for */
+	int dbg;		/* development: 1 = no mixing, 2 = no sample loads after the first chunk, 4 = no stores */
+	int nf_lo;		/* the shorter of the two window lengths; rcp_lo = RN(1/nf_lo), rcp_hi = RN(1/(nf_lo+1)) */
+	float rcp_lo, rcp_hi;
+	int per_n;
+	int nsub, wpt;		/* a period's 84 windows are split into nsub tasks of wpt */
+	long long per_lo;
+	long long sbase0;	/* push-relative index of the first sample of period per_lo */
+	const float2 *lo_ext;	/* [S][8][lo_stride]: the LO table followed by its first 16 entries again */
+	int lo_stride;
+	float2 *dec;
+	long long cap;
+	StreamState *ss;
+	int wend[84];		/* last sample of each window, relative to the period's first sample */
 };
 
 struct K2Params {
