@@ -326,7 +326,7 @@ def main():
                              "frames are collected like the bursts: what is ready after every push, everything before the clock stops"}
         if host_ring is not None:
             out["host_ring"] = host_ring
-        if os.environ.get("VDL2GPU_DEBUG_COUNTERS"):
+        if os.environ.get("VDL2GPU_DEBUG_COUNTERS") or os.environ.get("VDL2GPU_K1_PROF"):
             out["dbg"] = rx.debug_counters(64)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos, rate=rate)

@@ -786,7 +786,40 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				fast = false;
 			kp.d = (int)((a0 % 16) / h->sample_bytes);
 		}
-		if (fast) {
+		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && !getenv("VDL2GPU_K1_PP");
+		if (fast2m) {
+			/* 2 MS/s: the LO values of a window fit a lane's registers (lane = window x channel) */
+			generic(0, K1F_PER_OUT - 1);
+			pt.fast = true;
+			k1.per_lo = 1;
+			k1.per_n = periods - 2;
+			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
+				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
+			(void)hipEventRecord(pt.e[8], ks);
+			/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of rounds of
+			 * the GPU's wave slots */
+			long long pb;
+			{
+				const double work = (double)k1.per_n * K1F_ROLES * h->S;
+				const double slots = (double)h->n_cu * 4 * (getenv("VDL2GPU_K1F_OCC") ? atoi(getenv("VDL2GPU_K1F_OCC")) : 5);
+				double rounds = std::ceil(work / (slots * K1F_PB));
+				if (rounds < 1)
+					rounds = 1;
+				pb = (long long)std::ceil(work / (slots * rounds));
+				pb = std::max<long long>(8, std::min<long long>(pb, 64));
+			}
+			const long long ngrp = (((k1.per_n + pb - 1) / pb) + 7) / 8 * 8;	/* wave groups: a multiple of 8 (one XCD each, see k1_fast) */
+			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
+			switch (h->cfg.fmt) {
+			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+			case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CS16>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
+			}
+			(void)hipEventRecord(pt.e[9], ks);
+			pt.fast_parts = 1;
+			generic((periods - 1) * K1F_PER_OUT, J);
+		} else if (fast) {
 			generic(0, K1P_PER_OUT - 1);
 			pt.fast = true;
 			kp.raw = src;

@@ -484,4 +484,233 @@ void k1_pp(K1PParams p)
 	}
 }
 
+/* ---- K1 fast path: SDRINRATE 2 MS/s (SDRCLK 500, LO period 80) ------------------------
+ * The dump schedule and the LO phase repeat every 2000 inputs = 84 outputs (1 ms of air
+ * time).  One WAVEFRONT owns 8 consecutive windows of the period x 8 channels (lane =
+ * window*8 + channel) for many periods.  A lane's 23/24 LO values never change, so they
+ * live in VGPRs; the ~190 samples the wave's 8 windows cover are fetched by the wave itself
+ * (3 coalesced loads per lane), converted once, and parked in a private double-buffered LDS
+ * slice, from which each sample is read once per window and broadcast to the 8 channel
+ * lanes.  Inner loop: 1 LDS read + 8 VALU ops per sample and channel.  No workgroup
+ * barrier anywhere: wavefronts never wait for each other, 16 of them per CU hide HBM latency.
+ * 84 = 10*8 + 4, so 11 wave roles cover a period (the last one half empty). */
+
+/* (re, im) += x * w for complex x, w with the reference's operation order
+ *   pr = x.re*w.re - x.im*w.im;  pi = x.re*w.im + x.im*w.re;  acc += (pr, pi)
+ * as four packed-FP32 VALU ops (gfx950 issues plain FP32 at half the packed rate):
+ *   a = (x.re*w.re, x.re*w.im)          v_pk_mul_f32, op_sel picks x.re twice
+ *   b = (x.im*(-w.im), x.im*w.re)       v_pk_mul_f32, halves of w swapped, low lane negated
+ *   acc += (a + b)                      2 x v_pk_add_f32
+ * a.lo + b.lo = x.re*w.re + (-(x.im*w.im)) is bit-identical to the subtraction. */
+__device__ __forceinline__ void k1_cmac(v2f &acc, v2f x, v2f w)
+{
+	v2f a, b;
+	asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+	    "v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+	    : "=&v"(a), "=&v"(b)
+	    : "v"(x), "v"(w));
+	acc += (a + b);
+}
+
+#define K1F_THREADS 64
+#define K1F_PB 32		/* periods per wavefront */
+#define K1F_DEPTH 4		/* periods of raw samples in flight per wavefront (registers) */
+#define K1F_PER_IN 2000
+#define K1F_PER_OUT 84
+#define K1F_ROLES 11
+#define K1F_SLICE 192		/* >= 8 windows x 24 samples */
+
+/* raw samples as the wave's loads deliver them: one 32-bit register per sample (64 for cf32) */
+template <int FMT> struct K1Raw { typedef unsigned T; };
+template <> struct K1Raw<VDL2GPU_FMT_CF32> { typedef unsigned T __attribute__((ext_vector_type(2))); };
+
+/* The sample loads are written in assembly because their waits are: a wave keeps DEPTH periods of samples in
+ * flight, and before it converts one it must only wait until the loads of THAT period have landed -- memory
+ * operations of a wave complete in issue order, so "at most as many outstanding as were issued after them".
+ * The compiler, seeing loads in a loop with a conditional body, waits for everything (vmcnt(0)): every period
+ * then costs a full memory round trip, store acknowledgement included, and the kernel is latency-bound. */
+template <int FMT> __device__ __forceinline__ void k1_raw_issue(typename K1Raw<FMT>::T &r, const unsigned voff, const char *sbase)
+{
+	if constexpr (FMT == VDL2GPU_FMT_CU8)
+		asm volatile("global_load_ushort %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+	else if constexpr (FMT == VDL2GPU_FMT_CF32)
+		asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+	else
+		asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+}
+
+template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<FMT>::T v)
+{
+	if constexpr (FMT == VDL2GPU_FMT_CU8) {
+		return make_float2((float)(v & 0xffu) - (float)127.37, (float)((v >> 8) & 0xffu) - (float)127.37);
+	} else if constexpr (FMT == VDL2GPU_FMT_CS16) {
+		return make_float2((float)(short)(v & 0xffffu), (float)(short)(v >> 16));
+	} else if constexpr (FMT == VDL2GPU_FMT_CF32) {
+		return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+	} else {
+		return make_float2(__uint_as_float(v), 0.0f);
+	}
+}
+
+template <int FMT> __global__ __launch_bounds__(K1F_THREADS)
+void k1_fast(K1Params p)
+{
+	typedef typename K1Raw<FMT>::T raw_t;
+	constexpr int B = (FMT == VDL2GPU_FMT_CU8) ? 2 : (FMT == VDL2GPU_FMT_CF32) ? 8 : 4;
+	__shared__ float2 xs[K1F_SLICE];
+	const int lane = threadIdx.x;
+	const int s = blockIdx.y;
+	/* Wave group w handles periods per_lo + w, + w + NW, + w + 2 NW, .. (NW = number of wave groups): at every
+	 * loop iteration the whole grid reads one contiguous band of NW periods and writes one contiguous band of
+	 * each plane, which keeps HBM pages open, instead of every wave streaming through its own distant range.
+	 * The 11 roles of a wave group write neighbouring 64-byte runs -- halves of the same 128-byte lines -- so
+	 * they must share an L2: workgroup b runs on XCD b % 8, hence b = (group_hi * 11 + role) * 8 + group_lo.
+	 * (With b = group * 11 + role the two halves of a line went through two XCDs' L2s and reached HBM as two
+	 * partial writes; the launch was bound by exactly that.) */
+	const long long nw = (long long)(gridDim.x / K1F_ROLES);	/* a multiple of 8, see the launch */
+#ifdef K1F_NO_XCD_MAP
+	const int g = blockIdx.x % K1F_ROLES;
+	const long long wgrp = (long long)(blockIdx.x / K1F_ROLES);
+#else
+	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
+	const long long wgrp = (long long)(blockIdx.x / (8 * K1F_ROLES)) * 8 + (blockIdx.x & 7);
+#endif
+	const long long pp0 = p.per_lo + wgrp;
+	if (wgrp >= p.per_n)
+		return;
+	const int np = (int)((p.per_n - wgrp + nw - 1) / nw);	/* periods pp0 + q*nw, q < np */
+	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this wave's periods */
+	const int kk = lane >> 3, c = lane & 7;
+	const int k = g * 8 + kk;
+	const bool active = (k < K1F_PER_OUT) && (c < p.nbch);
+	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
+	const long long fill = p.ss[s].dec_fill;
+	/* slice of this wave in period pp0: from the first sample of window 8g to the last of window 8g+7 */
+	const long long j0 = pp0 * K1F_PER_OUT + g * 8;		/* >= 84 */
+	const int klast = (g * 8 + 7 < K1F_PER_OUT) ? 7 : (K1F_PER_OUT - 1 - g * 8);
+	const long long sbase = k1_win_end(j0 - 1, p.sdrclk, p.c0) + 1;
+	const int slen = (int)(k1_win_end(j0 + klast, p.sdrclk, p.c0) - sbase + 1);
+	int off = 0, nwin = 0;
+	v2f w[24];
+#pragma unroll
+	for (int t = 0; t < 24; ++t)
+		w[t] = (v2f){0.0f, 0.0f};
+	if (active) {
+		const long long j = j0 + kk;
+		const long long a = k1_win_end(j - 1, p.sdrclk, p.c0) + 1;
+		const long long b = k1_win_end(j, p.sdrclk, p.c0);
+		off = (int)(a - sbase);
+		nwin = (int)(b - a + 1);
+		int ph = (int)((p.no0 + a) % 80);
+		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + c) * 80;
+#pragma unroll
+		for (int t = 0; t < 24; ++t) {
+			const float2 q = lo[ph];
+			w[t] = (v2f){q.x, q.y};
+			ph = (ph + 1 == 80) ? 0 : ph + 1;
+		}
+	}
+	const float fn = (float)nwin;
+	const float rfn = 1.0f / (nwin ? fn : 1.0f);	/* RN(1/nf) for the exact FMA division below */
+	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill + pp0 * K1F_PER_OUT + k;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* from here on the only memory operations are the counted ones below */
+	/* lanes fetch samples lane, lane+64, lane+128 of the slice (clamped: the tail lanes of the
+	 * last load re-read the last sample instead of branching) */
+	unsigned vo[3];
+#pragma unroll
+	for (int u = 0; u < 3; ++u) {
+		const int i = lane + u * 64;
+		vo[u] = (unsigned)(i < slen ? i : slen - 1) * B;
+	}
+	const char *rbase = raw + sbase * B;		/* the slice in period pp0; wave-uniform */
+	const long long pbytes = pstride * B;
+	raw_t rr[K1F_DEPTH][3];
+#pragma unroll
+	for (int d = 0; d < K1F_DEPTH; ++d)
+#pragma unroll
+		for (int u = 0; u < 3; ++u)
+			k1_raw_issue<FMT>(rr[d][u], vo[u], rbase + pbytes * (d < np ? d : np - 1));
+	for (int q0 = 0; q0 < np; q0 += K1F_DEPTH) {
+#pragma unroll
+		for (int d = 0; d < K1F_DEPTH; ++d) {
+			const int q = q0 + d;
+			if (q < np) {
+				/* period q: registers -> float -> LDS slice, then refill the registers with period q+DEPTH so
+				 * that DEPTH periods stay in flight.  Every iteration issues exactly 3 loads and 1 store: 4 D - 3
+				 * operations have been issued after the loads of period q in the steady state, 3 D - 3 + q in
+				 * the first round (the stricter 3 D - 3 serves all of it). */
+#if defined(K1F_NOLOAD) || defined(K1F_NOSTORE)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+				if (q0 == 0)
+					asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * K1F_DEPTH - 3) : "memory");
+				else
+					asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * K1F_DEPTH - 3) : "memory");
+#endif
+#pragma unroll
+				for (int u = 0; u < 3; ++u)
+					asm volatile("" : "+v"(rr[d][u]));	/* read only behind the wait */
+#pragma unroll
+				for (int u = 0; u < 3; ++u)
+					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
+				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
+#ifndef K1F_NOLOAD
+#pragma unroll
+				for (int u = 0; u < 3; ++u)
+					k1_raw_issue<FMT>(rr[d][u], vo[u], rbase + pbytes * qn);
+#endif
+				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
+				v2f res = {0.0f, 0.0f};
+#ifdef K1F_NOMIX
+				if (active && p.nbch > 8) {
+#else
+				if (active) {
+#endif
+					const v2f *xp = reinterpret_cast<const v2f *>(&xs[off]);
+					v2f acc = {0.0f, 0.0f};
+					if (FMT == VDL2GPU_FMT_F32R) {
+#pragma unroll
+						for (int t = 0; t < 23; ++t) {
+							const float x = xp[t].x;
+							acc += (v2f){x, x} * w[t];
+						}
+						if (nwin == 24) {
+							const float x = xp[23].x;
+							acc += (v2f){x, x} * w[23];
+						}
+					} else {
+#pragma unroll
+						for (int t = 0; t < 23; ++t)
+							k1_cmac(acc, xp[t], w[t]);
+						if (nwin == 24)
+							k1_cmac(acc, xp[23], w[23]);
+					}
+					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
+					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
+					 * checked for nf = 23, 24: tests/ctests/div_check.c); below that, and only
+					 * then, the plain IEEE division is used */
+					if (__all(fabsf(acc.x) >= 1e-30f && fabsf(acc.y) >= 1e-30f)) {
+						const float q0r = acc.x * rfn, q0i = acc.y * rfn;
+						res.x = fmaf(fmaf(-q0r, fn, acc.x), rfn, q0r);
+						res.y = fmaf(fmaf(-q0i, fn, acc.y), rfn, q0i);
+					} else {
+						res.x = acc.x / fn;
+						res.y = acc.y / fn;
+					}
+				}
+				/* exactly one store instruction per iteration (inactive lanes masked off) */
+				{
+					float2 *dst = dec + (long long)q * K1F_PER_OUT * nw;
+#ifndef K1F_NOSTORE
+					if (active)
+						asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(res) : "memory");
+#endif
+				}
+				__syncthreads();	/* reads done before the slice is overwritten */
+			}
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #endif

@@ -84,6 +84,7 @@ struct K1Params {
 	int c0, no0, nf0, parity;
 	long long N, J;
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
+	long long per_lo, per_n;	/* k1_fast: whole 84-output periods [per_lo, per_lo+per_n) */
 	const float2 *lo;	/* [S][8][L] */
 	float2 *dec;		/* this push's planes, [S][8][cap] */
 	long long cap;
