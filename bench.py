@@ -1,32 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the IQ->bursts hot path on MI355X (BASELINE.json metric).
 
-Workload (configs[1] of BASELINE.json): one wideband stream, 8 VDL2 channels on the 25 kHz
-grid, SDRINRATE 2 MS/s, cs16 interleaved IQ, synthetic D8PSK bursts (Poisson arrivals per
-channel, 8..60 LSB amplitude, +-400 Hz carrier offset, AWGN) from vdlm2dec_amd.synth.
-A "step" is one vdl2gpu_push() of `--batch` samples (default 16 x 4.2 MS = 67.2 MS = 33.6 s
-of air time) that is already resident in HBM, plus vdl2gpu_poll() of the decoded bursts.
-`value` = input samples consumed per second with all 8 channels demodulated, whole job.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
 
-N > 1 (weak scaling): the path shards by independent wideband stream, so every
-rank decodes its own stream of the same size; there is no data-path collective.  RCCL is used
-only for the timing barrier / max-reduce and a gather of per-rank burst counts.
+Workloads (BASELINE.json `configs`; config.workload carries the string):
+  --config 2 (default)  configs[1]: 8 channels @ 2 MS/s, one wideband cs16 stream per GPU, 67.2 MS per step
+  --config 3            configs[2]: 8 channels @ 10 MS/s (SDRCLK 2500, LO table 400), 268.8 MS per step
+  --config 4            configs[3]: 512 replayed channels = 64 streams x 8 channels over 8 GPUs: 8 streams per GPU
+                        (weak scaling: every rank decodes 8 streams whatever N is)
+Synthetic D8PSK bursts (vdlm2dec_amd.synth: Poisson arrivals per channel, 8..60 LSB, +-400 Hz carrier offset,
+AWGN).  A "step" is one vdl2gpu_push() of samples already resident in HBM plus delivery of the decoded msgblk
+records to the host; three input buffers at different addresses are pushed in turn (nothing of the 268.8 MB a
+push reads is in the 256 MB Infinity Cache when it is read again).  `value` = wideband input samples consumed
+per second, whole job, all channels demodulated.
+
+N > 1: `--gpus N` starts N ranks itself (python -m torch.distributed.run, 127.0.0.1) unless it is already running
+under one (WORLD_SIZE set, as the driver launches it), and fails if fewer than N GPUs are visible.  The path shards
+by independent wideband stream (vdlm2dec_amd/shard.py): no data-path collective; RCCL carries the
+timing barrier / max, the parity verdicts and the gather of the packed burst records to rank 0.
 
 Extra objects on the JSON line:
-  roofline      channeliser kernel (the only kernel that touches the full-rate stream):
-                algorithmic bytes = 4 B per cs16 sample, read once for all 8 channels
-                (SURVEY.md 8d), divided by its mean launch time from HIP events recorded on
-                the library's stream (vdl2gpu_get_timing).
-  kernels_ms    mean per-step device time of each kernel, same events.
-  cpu_baseline  the oracle (CPU restatement, verified bit-equal to the reference) timed on
-                this host on a bounded sample of the same recording, one thread per channel.
-  parity        GPU bursts of the first tile compared with the oracle's, msgblk_t level.
+  roofline      the channeliser's full-rate kernel (k1_fast at 2 MS/s, k1_pp otherwise -- the only kernel that touches
+                the wideband stream): algorithmic bytes = sample bytes x samples, read once for all 8 channels (SURVEY.md
+                8d), over its mean launch time from HIP events on the library's own stream, inside the timed region.
+                traffic_from_profiles = HBM bytes per launch from the committed rocprofv3 PMC passes of this command.
+  kernels_ms    mean per-step device time of each stage, same events (kernel intervals only).
+  parity        EVERY burst of the timed region compared with the oracle: the stream is tile-periodic, so the oracle's
+                bursts of one steady-state tile are what every tile of the timed region must contain, record for record
+                (channel, instant, nbrow, nlbyte, carrier estimate, all 2040 data bytes).  A mismatch nulls `value` and
+                the process exits 1.
+  cpu_baseline  the oracle (CPU restatement, pinned bit-equal to the reference) on this host's cores on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -37,27 +49,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-RATE = 2_000_000          # default; --rate overrides (10 MS/s = config 3)
 FC = 136_975_000
-TILE = 4_200_000          # samples per generated tile (multiple of the 2000-sample LO/decimator period)
+TILE = 4_200_000          # samples per generated tile: a whole number of schedule periods at every rate
 HBM_PEAK_GBS = 8000.0     # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FO8_10MS = (-2_250_000, -1_750_000, -1_250_000, -300_000, 475_000, 1_000_000, 1_525_000, 2_300_000)
+
+CONFIGS = {
+    2: dict(workload="configs[1]: 8 channels @ 2 MS/s on 1xMI355X, synthetic D8PSK bursts, LDS-staged FIR",
+            rate=2_000_000, streams=1, tiles=16, fos=None),
+    3: dict(workload="configs[2]: 8 channels @ 10 MS/s (airspy-rate) on 1xMI355X, wider decimation chain",
+            rate=10_000_000, streams=1, tiles=64, fos=FO8_10MS),
+    4: dict(workload="configs[3]: 512 replayed channels sharded across 8xMI355X via RCCL/xGMI (offline bulk-decode): "
+                     "8 streams x 8 channels per GPU",
+            rate=2_000_000, streams=8, tiles=4, fos=None),
+}
 
 
-def make_tile(seed: int, fmt: str, rate: int = RATE, fos=None):
+def make_tile(seed: int, fmt: str, rate: int, fos):
     from vdlm2dec_amd import synth
-    fos = fos or synth.DEFAULT_FO_8CH
-    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0 * rate / RATE, info_max=240)
+    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0 * rate / 2_000_000, info_max=240)
     return spec, synth.synth_stream(spec, fmt)
 
 
-def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0, rate: int = RATE):
-    """Oracle ("port" of the reference path) on host cores: one thread per channel, like the
-    reference's one rcv_thread per channel (main.c:228-231)."""
+def cpu_baseline(raw: np.ndarray, fmt: str, fos, rate: int, budget_s: float = 12.0):
+    """Oracle ("port" of the reference path) on host cores: one thread per channel, like the reference's one
+    rcv_thread per channel (main.c:228-231)."""
     from oracle import oracle as O
     O.lib()
     per = O.PER_SAMPLE[fmt]
     n_total = raw.size // per
-    # size the sample so the run takes roughly budget_s: probe one channel on 1 MS first
     probe = min(n_total, 1_000_000)
     ch = O.OracleChannel(rate, fos[0], FC + fos[0])
     t0 = time.perf_counter()
@@ -67,7 +87,6 @@ def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0, rate: i
     ncores = os.cpu_count() or 1
     nthreads = min(len(fos), ncores)
     passes = int(np.ceil(len(fos) / nthreads))
-    # the recording is one tile; feed it repeatedly (the stream simply continues) until ~budget_s
     reps = max(1, int(budget_s / (one * n_total * passes)))
     n = n_total * reps
     chans = [O.OracleChannel(rate, fo, FC + fo, chn=i) for i, fo in enumerate(fos)]
@@ -96,9 +115,62 @@ def cpu_baseline(raw: np.ndarray, fmt: str, fos, budget_s: float = 12.0, rate: i
     except OSError:
         pass
     return {"value": n / dt / 1e6, "unit": "MS/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n} samples ({reps} x the 4.2 MS tile of the same recording), 8 channels, {nthreads} threads "
+            "sample": f"{n} samples ({reps} x the 4.2 MS tile of the same recording), {len(fos)} channels, {nthreads} threads "
                       f"(1 thread/channel), {dt:.1f} s wall, {nb} bursts; single-thread single-channel "
                       f"{1.0 / one / 1e6:.1f} MS/s; host CPU: {model} x{ncores}"}
+
+
+def oracle_stream(tile: np.ndarray, fmt: str, rate: int, fos, ntiles: int):
+    """The oracle over the very stream the GPU is fed -- `ntiles` repetitions of the tile, from the first sample on
+    (the sync detector's timing class is carried from burst to burst, so what a tile decodes to depends on everything
+    before it: there is no shortcut through periodicity).  One thread per channel, like the reference's one rcv_thread
+    per channel (main.c:228-231).  Returns (packed records with absolute instants, seconds of wall time)."""
+    from oracle import oracle as O
+    from vdlm2dec_amd import shard
+    O.lib()
+    out = [None] * len(fos)
+
+    def work(c):
+        ch = O.OracleChannel(rate, fos[c], FC + fos[c], chn=c)
+        for _ in range(ntiles):
+            ch.feed(tile, fmt)          # ctypes releases the GIL
+        out[c] = ch.blocks()
+        ch.close()
+
+    th = [threading.Thread(target=work, args=(c,)) for c in range(len(fos))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    bl = [b for per in out for b in per]
+    rec = np.zeros(len(bl), shard.REC_DTYPE)
+    for i, b in enumerate(bl):
+        rec[i] = (0, b.chn, b.nbrow, b.nlbyte, int(np.float32(b.df).view(np.uint32)), 0, b.trig_dec, b.end_dec,
+                  np.frombuffer(b.data, np.uint8))
+    return rec, dt
+
+
+def canon(recs: np.ndarray) -> bytes:
+    order = np.lexsort((recs["trig_dec"], recs["chn"], recs["stream"]))
+    return recs[order].tobytes()
+
+
+def respawn(args, argv):
+    """`python bench.py --gpus N` on its own: become N ranks."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (no CPU fallback, no oversubscription)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -106,66 +178,80 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--tiles", type=int, default=16, help="tiles of 4.2 MS per step (batch = tiles*4.2 MS)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--tiles", type=int, default=0, help="tiles of 4.2 MS per step and stream (0 = the config's)")
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
-    ap.add_argument("--rate", type=int, default=RATE, help="SDRINRATE (config 3: 10000000)")
-    ap.add_argument("--streams", type=int, default=1, help="independent wideband streams per GPU (config 4: 8)")
+    ap.add_argument("--rate", type=int, default=0, help="override the config's SDRINRATE (5000000 / 6000000)")
+    ap.add_argument("--streams", type=int, default=0, help="override the config's streams per GPU")
     ap.add_argument("--frames", action="store_true",
                     help="also run the block path (RS, HDLC, FCS: SURVEY 8f-1) on every push's bursts and collect the frames")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ring", action="store_true", help="skip the PCIe-inclusive extra pass (ingest ring from pinned host memory)")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
-    from vdlm2dec_amd import synth
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd import shard, synth
     from vdlm2dec_amd.demod import Receiver, plan_channels
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)")
     if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local)
 
-    rate = args.rate
-    fos = synth.DEFAULT_FO_8CH if rate == RATE else tuple(int(f * rate / RATE) // 25000 * 25000 for f in synth.DEFAULT_FO_8CH)
-    nstr = args.streams
-    tiles_np = []
-    for st_i in range(nstr):
-        spec, tile = make_tile(seed=1234 + rank * 64 + st_i, fmt=args.fmt, rate=rate, fos=fos)
-        tiles_np.append(tile)
-    tile = tiles_np[0]
-    batch = args.tiles * TILE
-    dbatch = torch.stack([torch.from_numpy(t).to(dev).repeat(args.tiles) for t in tiles_np]).contiguous()  # [streams, batch*2]
+    cfg = CONFIGS[args.config]
+    rate = args.rate or cfg["rate"]
+    nstr = args.streams or cfg["streams"]
+    ntiles = args.tiles or cfg["tiles"]
+    if rate == 2_000_000:
+        fos = synth.DEFAULT_FO_8CH
+    elif cfg["fos"] and rate == cfg["rate"]:
+        fos = cfg["fos"]
+    else:
+        fos = tuple(int(f * rate / 2_000_000) // 25000 * 25000 for f in synth.DEFAULT_FO_8CH)
+    nstreams_total = nstr * world
+    mine = shard.shard_streams(nstreams_total, rank, world)        # this rank's global stream indices
     sample_bytes = 4 if args.fmt == "cs16" else 2
-    stride_bytes = dbatch.stride(0) * dbatch.element_size()
+    batch = ntiles * TILE
+    tile_dec = TILE * 21 // (rate // 4000)
+
+    tiles_np = [make_tile(seed=1234 + g, fmt=args.fmt, rate=rate, fos=fos)[1] for g in mine]
+    # three copies at different addresses, pushed in turn: what a push reads was last touched two pushes ago
+    NBUF = 3
+    dbufs = [torch.stack([torch.from_numpy(t).to(dev).repeat(ntiles) for t in tiles_np]).contiguous() for _ in range(NBUF)]
+    stride_bytes = dbufs[0].stride(0) * dbufs[0].element_size()
 
     rx = Receiver(rate, [plan_channels(FC, fos)] * nstr, fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18,
                   frames=args.frames)
-    first = []
-    nbursts = 0
-
-    from vdlm2dec_amd import lib as _lib
-    from vdlm2dec_amd.demod import Burst
-    rawbuf = (_lib.BurstT * 16384)()
+    cap = 1 << 20
+    store = (_lib.BurstT * cap)()           # every record of the run lands here, straight from vdl2gpu_poll*()
+    nrec = 0
     framebuf = (_lib.FrameT * 4096)() if args.frames else None
     nframes = [0]
+    npush = [0]
 
-    def drain(collect, ready_only):
-        nonlocal nbursts
+    def drain(ready_only):
+        nonlocal nrec
         while True:
-            n = rx.poll_ready_raw(rawbuf, 16384) if ready_only else rx.poll_raw(rawbuf, 16384)
-            nbursts += n
-            if collect is not None:
-                for i in range(n):
-                    b = rawbuf[i]
-                    collect.append(Burst(b.stream, b.chn, b.Fr, b.nbrow, b.nlbyte, b.df, b.ppm, b.trig_dec,
-                                         b.end_dec, b.trig_sample, b.end_sample, bytes(b.data)))
-            if n < 16384:
+            room = min(16384, cap - nrec)
+            if room <= 0:
+                raise RuntimeError("bench.py: record store full")
+            ptr = C.cast(C.byref(store, nrec * C.sizeof(_lib.BurstT)), C.POINTER(_lib.BurstT))
+            n = rx.poll_ready_raw(ptr, room) if ready_only else rx.poll_raw(ptr, room)
+            nrec += n
+            if n < room:
                 break
         if args.frames:
             while True:
@@ -176,19 +262,13 @@ def main():
                 if m < 4096:
                     break
 
-    def step(collect=None, pipelined=False):
-        # one hand-off of resident samples + delivery of decoded msgblk records to the host.
-        # pipelined: take what earlier pushes have finished (vdl2gpu_poll_ready) while this push
-        # runs; everything is drained inside the timed region after the last step.
-        rx.push_device(dbatch.data_ptr(), batch, stride_bytes)
-        drain(collect, ready_only=pipelined)
-
-    for i in range(args.warmup):
-        step(first if i == 0 else None)
-    if args.warmup == 0:
-        pass
-    rx.timing(reset=True)
-    nbursts = 0
+    def step(pipelined):
+        # one hand-off of resident samples + delivery of decoded msgblk records to the host.  pipelined: take what
+        # earlier pushes have finished (vdl2gpu_poll_ready) while this push runs; everything is drained inside the
+        # timed region after the last step.
+        rx.push_device(dbufs[npush[0] % NBUF].data_ptr(), batch, stride_bytes)
+        npush[0] += 1
+        drain(ready_only=pipelined)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -196,131 +276,182 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    for _ in range(args.warmup):
+        step(False)
+    rx.sync()
+    rx.timing(reset=True)
+    rec0 = nrec
+    first_timed_tile = npush[0] * ntiles
+
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(first if (args.warmup == 0 and i == 0) else None, pipelined=not (args.warmup == 0 and i == 0))
-    drain(None, ready_only=False)       # every burst of every step is on the host before the clock stops
+    for _ in range(args.steps):
+        step(True)
+    drain(False)                        # every burst of every step is on the host before the clock stops
     rx.sync()
     fence()
     dt = time.perf_counter() - t0
-    nbursts_timed = nbursts             # the extra passes below deliver bursts too
+    rec1 = nrec
+    last_timed_tile = npush[0] * ntiles            # exclusive
     tm = rx.timing(reset=True)
     st = rx.stats()
-    # outside the timed region: the same hand-off a few times with nothing else on the GPU (each push
-    # finished before the next starts), to tell what the channeliser does alone from what it does
-    # while it shares the GPU with the previous push's demodulator (the timed region above)
+    # outside the timed region: the same hand-off a few times with nothing else on the GPU (each push finished before
+    # the next starts), to tell what the channeliser does alone from what it does while it shares the GPU with the
+    # previous push's demodulator (the timed region above)
     for _ in range(4):
-        rx.push_device(dbatch.data_ptr(), batch, stride_bytes)
+        rx.push_device(dbufs[npush[0] % NBUF].data_ptr(), batch, stride_bytes)
+        npush[0] += 1
         rx.sync()
-        drain(None, ready_only=False)
+        drain(False)
     tm_iso = rx.timing(reset=True)
-    # also outside the timed region: the same hand-off from page-locked host memory through the ingest
-    # ring -- the PCIe-inclusive rate.  Reported beside `value`, never as `value`.
+    # also outside the timed region: the same hand-off from page-locked host memory through the ingest ring (SURVEY 8
+    # f-2) -- the PCIe-inclusive rate.  Reported beside `value`, never as `value`.
     host_ring = None
-    if rank == 0 and world == 1 and not args.no_ring:
+    if rank == 0 and world == 1 and not args.no_ring and args.config == 2:
         try:
-            hb = dbatch.cpu().numpy().view(np.uint8).reshape(args.streams, -1)
+            hb = dbufs[0].cpu().numpy().view(np.uint8).reshape(nstr, -1)
             rx.ring_init(batch, nslots=3)
             nb = batch * rx.sample_bytes
-            for k in range(3):          # fill the three slots once: the producer's work is not what is measured
+            for _ in range(3):          # fill the three slots once: the producer's work is not what is measured
                 slot = rx.ring_acquire()
                 slot[:, :nb] = hb[:, :nb]
                 rx.ring_commit(batch)
-            drain(None, ready_only=False)
+            drain(False)
             rx.sync()
             th = time.perf_counter()
-            for k in range(6):
+            for _ in range(6):
                 rx.ring_acquire()
                 rx.ring_commit(batch)
-                drain(None, ready_only=True)
-            drain(None, ready_only=False)
+                drain(True)
+            drain(False)
             rx.sync()
             dth = time.perf_counter() - th
-            host_ring = {"value": 6 * batch * args.streams / dth / 1e6, "unit": "MS/s", "pushes": 6,
+            host_ring = {"value": 6 * batch * nstr / dth / 1e6, "unit": "MS/s", "pushes": 6,
                          "note": "samples start in page-locked host memory (vdl2gpu_ring_acquire/commit): H2D copy "
                                  "on its own stream beside the previous push's kernels, bursts delivered to the host"}
             rx.timing(reset=True)
         except Exception as e:      # the extra measurement must not cost the run its line
             host_ring = {"error": str(e)}
+
+    # ---- parity: every record of the timed region against the oracle run over the same stream from its first sample
+    timed = np.frombuffer(store, dtype=shard.BURST_DTYPE, count=rec1)[rec0:]
+    parity = None
+    ok_local = True
+    oracle_time = None
+    if not args.no_parity:
+        # bounded: the oracle handles ~25 MS/s per channel and thread; BENCH_ORACLE_TILES (1200) tiles per stream and at most four streams
+        # per rank keep the check near a minute.  The default run (and the driver's) is covered completely.
+        ncheck_tiles = min(last_timed_tile, int(os.environ.get("BENCH_ORACLE_TILES", "1200")))
+        ncheck_streams = min(nstr, 4)
+        packed = shard.pack_records(timed)
+        tidx = packed["trig_dec"] // tile_dec
+        # tiles wholly inside the timed region and the oracle's run, except the last one (a burst that is still open when
+        # the stream ends is not delivered)
+        t_lo, t_hi = first_timed_tile, min(last_timed_tile, ncheck_tiles) - 1
+        nb_checked, bad, per_stream = 0, [], []
+        oracle_time = 0.0
+        for s in range(ncheck_streams):
+            e, dt_o = oracle_stream(tiles_np[s], args.fmt, rate, fos, ncheck_tiles)
+            oracle_time += dt_o
+            et = e["trig_dec"] // tile_dec
+            e = e[(et >= t_lo) & (et < t_hi)]
+            g = packed[(packed["stream"] == s) & (tidx >= t_lo) & (tidx < t_hi)].copy()
+            g["stream"] = 0
+            nb_checked += len(g)
+            per_stream.append((len(g), len(e)))
+            if canon(g) != canon(e):
+                ge = {(int(r["chn"]), int(r["trig_dec"])): r.tobytes() for r in g}
+                ee = {(int(r["chn"]), int(r["trig_dec"])): r.tobytes() for r in e}
+                diff = sorted(k for k in set(ge) | set(ee) if ge.get(k) != ee.get(k))
+                bad.append({"stream": s, "gpu": len(g), "oracle": len(e), "first_differences": [list(k) for k in diff[:6]]})
+        ok_local = not bad and t_hi > t_lo and nb_checked > 0
+        parity = {"level": "msgblk_t (pre-RS) bit-exact: every burst of the timed region vs the oracle run over the same stream "
+                           "from its first sample (chn, instant, nbrow, nlbyte, df bits, 2040 data bytes)",
+                  "tiles_in_timed_region": last_timed_tile - first_timed_tile, "tiles_checked": max(0, t_hi - t_lo),
+                  "streams_checked": ncheck_streams, "streams": nstr, "bursts_checked": nb_checked,
+                  "gpu_vs_oracle_bursts": per_stream, "mismatches": bad, "equal": ok_local,
+                  "oracle_seconds": oracle_time}
+
+    # ---- collection across ranks: counts, verdicts, and the packed records on rank 0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cnt = torch.tensor([nbursts_timed], device=dev, dtype=torch.int64)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        total_bursts = int(sum(int(c.item()) for c in allc))
+        okt = torch.tensor([1 if ok_local else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok_all = bool(okt.item())
+        allrecs, counts, _ = shard.run_sharded(nstreams_total, lambda idx: shard.pack_records(timed, stream_offset=idx.start))
+        total_bursts = int(sum(counts))
+        gathered = {"records_on_rank0": int(len(allrecs)), "per_rank": counts,
+                    "digest": shard.digest(allrecs).hex()[:16] if rank == 0 else None}
     else:
-        total_bursts = nbursts_timed
+        ok_all = ok_local
+        total_bursts = int(len(timed))
+        gathered = None
 
-    parity = None
-    if rank == 0 and not args.no_parity:
-        from oracle import oracle as O     # checker only
-        want = sorted(b.key() for b in O.run_oracle(tile, args.fmt, rate, fos, FC))
-        got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in first if b.end_sample < TILE and b.stream == 0)
-        # oracle bursts still open at the tile end have no counterpart; both lists hold completed ones
-        parity = {"level": "msgblk_t (pre-RS) bit-exact, first tile", "oracle_bursts": len(want),
-                  "gpu_bursts": len(got), "equal": want == got}
-
+    rc = 0
     if rank == 0:
-        k1_ms = tm["channelise_ms"] / max(1, tm["pushes"])
-        k2_ms = tm["demod_ms"] / max(1, tm["pushes"])
-        k2a_ms = tm["scan_ms"] / max(1, tm["pushes"])
-        k2b_ms = tm["cluster_ms"] / max(1, tm["pushes"])
-        k2c_ms = tm["resolve_ms"] / max(1, tm["pushes"])
-        k3_ms = tm["other_ms"] / max(1, tm["pushes"])
-        # dominant full-rate kernel: k1_fast (all whole 1 ms periods but the first and last of a push)
-        # (a push may split it into two launches that run beside different stretches of the previous push's
-        #  demodulator: bytes and time are per launch, averaged over all launches, like rocprof's average)
+        pushes = max(1, tm["pushes"])
+        k1_ms = tm["channelise_ms"] / pushes
+        k2_ms = tm["demod_ms"] / pushes
+        k2a_ms = tm["scan_ms"] / pushes
+        k2b_ms = tm["cluster_ms"] / pushes
+        k2c_ms = tm["resolve_ms"] / pushes
+        k3_ms = tm["other_ms"] / pushes
+        # the full-rate kernel covers all whole 1 ms periods of a push but the first and the last
+        sdrclk = rate // 4000
+        periods = (batch * 21 // sdrclk) // 84
+        fast_samples = (periods - 2) * 4 * sdrclk * nstr
+        kname = "k1_fast" if rate == 2_000_000 else "k1_pp"
         fast_ms = tm["channelise_fast_ms"] / max(1, tm["fast_pushes"])
-        fast_samples = (batch * 21 // 500 // 84 - 2) * 2000 * nstr
-        alg_bytes = float(fast_samples) * sample_bytes * tm["pushes"] / max(1, tm["fast_pushes"])
+        alg_bytes = float(fast_samples) * sample_bytes
         achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        iso_ms = tm_iso["channelise_fast_ms"] / max(1, tm_iso["fast_pushes"])
         value = world * nstr * batch * args.steps / dt / 1e6
-        # HBM traffic of the same kernel from the committed PMC passes of this very command
-        # (profiles/r01_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs;
-        #  FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as reported)
+        ms_step = dt / args.steps * 1e3
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")))
-            if args.tiles == 16 and args.fmt == "cs16" and nstr == 1 and rate == RATE:
-                fk = [k for k in pm["FETCH_SIZE_KB_per_launch"] if "k1_fast" in k][0]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_pmc_hbm.json")))
+            if args.config == 2 and not args.tiles and args.fmt == "cs16" and not args.rate and not args.streams:
+                fk = [k for k in pm["FETCH_SIZE_KB_per_launch"] if kname in k][0]
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"][fk] + pm["WRITE_SIZE_KB_per_launch"][fk]) * 1024.0
         except (OSError, KeyError, ValueError, IndexError):
             pass
+        parity_ok = ok_all or args.no_parity
         out = {
             "metric": "IQ MS/s demodulated (8 ch, 2 MS/s cs16) + CRC-pass frame parity vs ref",
-            "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value if parity_ok else None, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: 8 channels @ 2 MS/s on 1xMI355X, synthetic D8PSK bursts" if (rate == RATE and nstr == 1)
-                                    else f"non-default: {nstr} stream(s) x 8 channels @ {rate / 1e6:g} MS/s"),
-                       "fmt": args.fmt, "samples_per_step": batch, "air_time_s_per_step": batch / RATE,
-                       "channels": 8, "streams_per_gpu": nstr, "sdrinrate": rate,
+            "config": {"workload": cfg["workload"] + ("" if not (args.rate or args.streams or args.tiles) else
+                                                       f" [overridden: {nstr} stream(s)/GPU, {rate / 1e6:g} MS/s, {ntiles} tiles]"),
+                       "fmt": args.fmt, "samples_per_step": batch * nstr, "air_time_s_per_step": batch / rate,
+                       "channels": 8, "streams_per_gpu": nstr, "streams_total": nstreams_total, "sdrinrate": rate,
                        "bursts_per_step": total_bursts / max(1, args.steps * world),
-                       "x_real_time": value * 1e6 / rate, "parallelism": f"stream-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k1_fast", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "x_real_time": value * 1e6 / rate, "parallelism": f"stream-sharded x{world}",
+                       "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                       "input_buffers": NBUF},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
-                         "alone": (lambda ms, by: {"avg_launch_ms": ms, "achieved": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                                                   "frac": (by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0,
-                                                   "how": "4 pushes after the timed region, each synchronised before the next: "
-                                                          "no other kernel on the GPU"})(
-                             tm_iso["channelise_fast_ms"] / max(1, tm_iso["fast_pushes"]),
-                             float(fast_samples) * sample_bytes * tm_iso["pushes"] / max(1, tm_iso["fast_pushes"])),
-                         "note": "live: HIP events around the k1_fast launches inside the timed region, where they run beside the "
-                                 "previous push's demodulator kernels on a second stream (two launches per push); "
-                                 "algorithmic bytes = 4 B per cs16 input sample, read once for all 8 channels; the "
-                                 "kernel also writes the 84 kS/s planes (2.7 B per input sample), which is "
-                                 "intermediate traffic, not algorithmic (SURVEY.md 8d)"},
+                         "whole_path_frac": (batch * nstr * sample_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                         "alone": {"avg_launch_ms": iso_ms, "achieved": alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0,
+                                   "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else 0.0,
+                                   "how": "4 pushes after the timed region, each synchronised before the next: no other kernel on the GPU"},
+                         "note": "live: HIP events around the one full-rate launch of each push inside the timed region, where it runs "
+                                 "beside the previous push's demodulator kernels on a second stream; algorithmic bytes = sample "
+                                 "bytes x samples, read once for all 8 channels; the kernel also writes the 84 kS/s planes (2.7 B per "
+                                 "input sample at 2 MS/s), which is intermediate traffic, not algorithmic (SURVEY.md 8d); `traffic` is "
+                                 "not measured by this run (PMC counters need rocprofv3): traffic_from_profiles is the committed "
+                                 "measurement of this command (profiles/r02_bench_pmc_hbm.json: 2 x FETCH_SIZE + WRITE_SIZE)"},
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
-                           "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms},
-            "whole_path_GBps": alg_bytes / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9,
+                           "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms, "demod_chain": k2_ms},
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
                                            "candidates", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,
         }
+        if gathered is not None:
+            out["gather"] = gathered
         if args.frames:
             out["frames"] = {"collected": nframes[0], "note": "k4_frames ran on every push's records (VDL2GPU_F_FRAMES); "
                              "frames are collected like the bursts: what is ready after every push, everything before the clock stops"}
@@ -329,11 +460,15 @@ def main():
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS") or os.environ.get("VDL2GPU_K1_PROF"):
             out["dbg"] = rx.debug_counters(64)
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tile, args.fmt, fos, rate=rate)
+            out["cpu_baseline"] = cpu_baseline(tiles_np[0], args.fmt, fos, rate)
         print(json.dumps(out))
+        if not parity_ok:
+            print("bench.py: PARITY FAILED -- value withheld", file=sys.stderr)
+            rc = 1
     rx.close()
     if world > 1:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VDL2GPU_ABI_VERSION 1
+#define VDL2GPU_ABI_VERSION 2
 #define VDL2GPU_MAXCH 8		/* MAXNBCHANNELS vdlm2.h:26 */
 #define VDL2GPU_MAXROWS 8	/* bursts with more rows are rejected, d8psk.c:103 */
 #define VDL2GPU_ROWLEN 255
@@ -50,7 +50,7 @@ enum {
 	VDL2GPU_EINVAL = -1,	/* bad argument / configuration */
 	VDL2GPU_EHIP = -2,	/* a HIP runtime call failed (see vdl2gpu_last_error) */
 	VDL2GPU_ENOMEM = -3,
-	VDL2GPU_EOVERFLOW = -4,	/* more bursts than the record ring holds; oldest kept */
+	VDL2GPU_EOVERFLOW = -4,	/* reserved; record overflow is reported through vdl2gpu_stats_t.overflowed, never as an error */
 	VDL2GPU_ENODEV = -5	/* no usable GPU: the library never falls back to the CPU */
 };
 
@@ -85,11 +85,15 @@ typedef struct {
 	uint32_t flags;		/* VDL2GPU_F_* */
 } vdl2gpu_config_t;
 
-#define VDL2GPU_F_KEEP_DEC 1u	/* keep each push's decimated stream for vdl2gpu_debug_dec() */
+#define VDL2GPU_F_KEEP_DEC 1u	/* accepted for compatibility: the last push's decimated stream is always kept (vdl2gpu_debug_dec) */
 #define VDL2GPU_F_FULLSCAN 4u	/* scan all four FIR sub-phases everywhere instead of probe + regions + verify */
 #define VDL2GPU_F_TEST_NOREGION 8u	/* test hook: drop the region scan; the verify pass must then redo channels serially */
 #define VDL2GPU_F_FRAMES 16u	/* run the block path (RS, HDLC, FCS) on every push's bursts as well: vdl2gpu_poll_frames() */
 #define VDL2GPU_F_SERIAL 2u	/* diagnostics: skip the parallel sync tables, one serial machine per channel */
+#define VDL2GPU_F_RTL_QUIRK 32u	/* cu8 only: reproduce in_callback() as written (rtl.c:285-292): in every hand-off block of
+				 * 32768 samples, sample k is stored at index k+1, index 0 stays 0 and the last sample is
+				 * lost -- what the reference decodes on a real RTL stick.  Every push must
+				 * then be a whole number of 32768-sample blocks (RTLINBUFSZ/2, vdlm2.h:35). */
 
 /* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */
 typedef struct {
@@ -118,7 +122,8 @@ typedef struct {
 	uint64_t candidates;	/* sync-trigger candidates found by the parallel scan (all timing hypotheses) */
 	uint64_t serial_redos;	/* channel-pushes redone serially because the verify pass found an unlisted event */
 	uint64_t serial_samples;	/* 84 kS/s samples handled by the serial machine (history-dependent stretches) */
-	uint64_t overflowed;	/* records dropped because the ring was full */
+	uint64_t overflowed;	/* burst records dropped: device ring full, or host queue never drained */
+	uint64_t frames_dropped;	/* VDL2GPU_F_FRAMES: frames dropped (arena full, more than 12 frames in a burst, host queue never drained) */
 } vdl2gpu_stats_t;
 
 typedef struct {
@@ -144,7 +149,12 @@ void vdl2gpu_destroy(vdl2gpu_t *h);
  * (const char*)iq + s*stream_stride_bytes.  Asynchronous: returns once the
  * work is enqueued on the handle's HIP stream.  Replaces one Bar2/Bar1
  * hand-off of Cbuff (d8psk.c:360-383) for all channels at once, with any
- * block length instead of the fixed 32768. */
+ * block length instead of the fixed 32768.
+ * Buffer lifetime: a VDL2GPU_MEM_HOST buffer may be reused as soon as the call returns (it has been copied).
+ * A VDL2GPU_MEM_DEVICE buffer is read in place by the channeliser, asynchronously: it must stay valid and
+ * unchanged until the second push after this one has been issued, or until vdl2gpu_sync() / vdl2gpu_poll()
+ * returns -- whichever comes first (at most two pushes are in flight).
+ * Errors are sticky: after a call has returned VDL2GPU_EHIP the handle only accepts vdl2gpu_destroy(). */
 int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind);
 
 /* Ingest ring: replaces the producer side of the hand-off -- in_callback()
@@ -162,7 +172,10 @@ int vdl2gpu_ring_commit(vdl2gpu_t *h, size_t nsamples);
 /* Wait until everything pushed so far has been demodulated. */
 int vdl2gpu_sync(vdl2gpu_t *h);
 /* Collect finished bursts (waits for everything pushed so far).  Bursts come out ordered by
- * (end_sample, stream, chn).  Returns the count (>=0) or a negative error. */
+ * (end_sample, stream, chn).  Returns the count (>=0) or a negative error.
+ * The host keeps what has been fetched from the GPU and not yet handed out in two bounded queues (bursts;
+ * with VDL2GPU_F_FRAMES also frames): a consumer that drains only one of them loses the OLDEST entries of the
+ * other once it holds more than 4 x max_bursts (counted in vdl2gpu_stats_t.overflowed / frames dropped). */
 int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Same, but never waits: hands out only the bursts of pushes the GPU has already finished.  Lets
  * a caller keep the next push running while it consumes the previous one (two pushes can be in
@@ -177,8 +190,10 @@ const char *vdl2gpu_last_error(vdl2gpu_t *h);
 const char *vdl2gpu_strerror(int code);
 
 /* Fill a reference msgblk_t (vdlm2.h:39-47, LP64 layout: prev@0 chn@8 Fr@12
- * tv@16 ppm@32 nbrow@36 nlbyte@40 data@44, sizeof 16624) from a burst record.
- * `msgblk` must point at sizeof(msgblk_t) zeroed bytes (calloc, as vdlm2.c:201). */
+ * tv@16 ppm@32 nbrow@36 nlbyte@40 data@44, sizeof 16624 -- the x86-64 / aarch64 Linux layout; the offsets
+ * are compile-time constants of this library, so a host with another ABI must copy the fields itself)
+ * from a burst record.  `msgblk` must point at sizeof(msgblk_t) zeroed bytes (calloc, as vdlm2.c:201);
+ * msgblk_size is checked against 16624. */
 int vdl2gpu_burst_to_msgblk(const vdl2gpu_burst_t *b, void *msgblk, size_t msgblk_size);
 
 /* ---- block path: what the reference's blk_thread does with a msgblk_t ----
@@ -223,6 +238,21 @@ int vdl2gpu_lo_table(unsigned sdrinrate, int fo_hz, float *out_re_im, int max_co
 /* Integrate-and-dump schedule of one push (d8psk.c:374-381 in closed form). */
 int vdl2gpu_plan(uint64_t total_in, uint64_t n, unsigned sdrclk, unsigned lo_len,
 		 int *c0, int *no0, int *nf0, int64_t *nout);
+/* Frequency planning: the tuner centre the reference picks for a list of channel
+ * frequencies, and the per-channel mixer offsets Fo it derives (thread_param_t.Fo).
+ *   rtl: chooseFc() of rtl.c:123-160 -- the highest Fc (1 Hz steps, downwards from max + 50 kHz) that keeps every
+ *        channel within SDRINRATE/2 - 50 kHz, none closer than 50 kHz, and no two adjacent (sorted) channels
+ *        mirror images of each other; Fo = Fr - Fc (rtl.c:245-247).  Returns 0 and Fc = 0 when the channels span
+ *        more than SDRINRATE - 100 kHz, like the reference.
+ *   air: chooseFc() of air.c:47-70 -- the midpoint rounded to the 25 kHz grid, at 5 MS/s (Airspy R2) shifted by
+ *        the R820T2 filter pair that just covers the span; Fo = Fr - (Fc + SDRINRATE/4) (air.c:182-184).  The two
+ *        tuner register values the reference writes (R10 = 0xB0 | (15-j), R11 = 0xE0 | (15-i)) are returned as
+ *        well (0 when none is written).
+ * fr[] is NOT reordered (the reference sorts a scratch copy, rtl.c:218-241).  Parity: unpinned -- rtl.c / air.c
+ * need the SDR vendor headers and cannot be compiled in the build container; tested against hand-derived
+ * cases and an independent brute-force statement of the same rules. */
+int vdl2gpu_choose_fc_rtl(const unsigned *fr, int nbch, unsigned sdrinrate, unsigned *fc, int *fo);
+int vdl2gpu_choose_fc_air(const unsigned *fr, int nbch, unsigned sdrinrate, unsigned *fc, int *fo, int *r10, int *r11);
 
 /* ---- diagnostics (P3 taps, tests only) ---- */
 /* Decimated samples of the LAST push of (stream, channel index), interleaved

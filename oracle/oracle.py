@@ -201,9 +201,10 @@ def build_ref() -> bool:
 
 
 def run_ref(path: str, fmt: str, rate: int, fo: int, fr: int, out_path: str, quirk: int = 0,
-            tap_path: str = ""):
-    """One channel through the REAL reference (oracle/_ref/ref_rtl or ref_air)."""
-    exe = os.path.join(REF_DIR, "ref_air" if fmt == "f32" else "ref_rtl")
+            tap_path: str = "", ofast: bool = False):
+    """One channel through the REAL reference (oracle/_ref/ref_rtl or ref_air; ofast: the build with the
+    reference's own -Ofast -march=native, CMakeLists.txt:4)."""
+    exe = os.path.join(REF_DIR, ("ref_air" if fmt == "f32" else "ref_rtl") + ("_ofast" if ofast else ""))
     subprocess.check_call([exe, path, fmt, str(rate), str(fo), str(fr), out_path, str(quirk), tap_path])
     blocks, frames = [], []
     with open(out_path) as f:

@@ -40,6 +40,8 @@ CASES = {
     "air_f32_5ms": (S.single_short(5_000_000, 375_000, seed=6, info_len=12, blocks=5), "f32", 0),
     "cs16_10ms": (S.single_short(10_000_000, -1_250_000, seed=7, info_len=20, blocks=6), "cs16", 0),
     "short_cf32_2ms": (S.single_short(2_000_000, 100_000, seed=9, info_len=8, blocks=2), "cf32", 0),
+    # BASELINE.json configs[2]: 8 channels @ 10 MS/s (SDRCLK 2500)
+    "eight_cs16_10ms": (S.eight_channels(rate=10_000_000, seed=10, dur=0.05, info=(3, 9, 5, 12, 7, 4, 6, 8), fo=S.FO8_10MS), "cs16", 0),
 }
 SHARE_IQ = {"regimes_cu8_2ms_quirk": "regimes_cu8_2ms"}
 

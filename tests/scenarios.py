@@ -27,7 +27,13 @@ def regimes(rate=2_000_000, fo=(-50_000, 250_000), seed=3, infos=(1, 2, 3, 28, 3
     return synth.StreamSpec(rate=rate, fo=tuple(fo), nsamples=ns, bursts=bursts, noise=noise, seed=seed)
 
 
-def eight_channels(rate=2_000_000, seed=8, dur=0.16, info=(3, 17, 40, 64, 90, 130, 5, 75)):
+# config 3 (BASELINE.json configs[2]): 8 channels at 10 MS/s (SDRCLK 2500, LO table 400), spread over +-2.3 MHz on the
+# 25 kHz grid; and the Airspy shape (air.c:134-138): real samples at 5 MS/s, channels above the mixer centre
+FO8_10MS = (-2_250_000, -1_750_000, -1_250_000, -300_000, 475_000, 1_000_000, 1_525_000, 2_300_000)
+FO8_AIR_5MS = (150_000, 425_000, 700_000, 1_000_000, 1_300_000, 1_575_000, 1_850_000, 2_200_000)
+
+
+def eight_channels(rate=2_000_000, seed=8, dur=0.16, info=(3, 17, 40, 64, 90, 130, 5, 75), fo=None):
     """Config-2 shape: 8 channels, bursts overlapping in time on different channels."""
     rng = np.random.default_rng(seed)
     bursts = []
@@ -42,7 +48,7 @@ def eight_channels(rate=2_000_000, seed=8, dur=0.16, info=(3, 17, 40, 64, 90, 13
                          amp=float(rng.uniform(10, 40)), cfo=float(rng.uniform(-400, 400)))
         if b2.t0 + b2.duration() < dur - 0.002:
             bursts.append(b2)
-    return synth.StreamSpec(rate=rate, fo=FO8, nsamples=_pad(int(dur * rate)), bursts=bursts, noise=1.6, seed=seed)
+    return synth.StreamSpec(rate=rate, fo=tuple(fo) if fo else FO8, nsamples=_pad(int(dur * rate)), bursts=bursts, noise=1.6, seed=seed)
 
 
 def single_short(rate, fo, seed=5, info_len=10, amp=40.0, blocks=4, t0=0.002):

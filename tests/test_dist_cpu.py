@@ -45,14 +45,29 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
     specs, raws = _streams()
-    mine = shard.shard_streams(NSTREAMS, rank, world)
-    bursts = _decode(O, specs, raws, mine)
-    recs = shard.pack_bursts(bursts)
-    allrecs, counts = shard.gather_bursts(recs, dst=0)
+    # the decoder is injected: here the oracle, on the GPU box a Receiver (bench.py) -- sharding + gather are shared
+    allrecs, counts, mine = shard.run_sharded(NSTREAMS, lambda idx: shard.pack_bursts(_decode(O, specs, raws, idx)), dst=0)
+    assert list(mine) == list(shard.shard_streams(NSTREAMS, rank, world))
     dist.barrier()
     if rank == 0:
         q.put((counts, shard.digest(allrecs), len(allrecs)))
     dist.destroy_process_group()
+
+
+def test_packed_record_layout_matches_the_c_struct(built):
+    """shard.BURST_DTYPE is vdl2gpu_burst_t byte for byte (ctypes mirror in vdlm2dec_amd.lib)."""
+    import ctypes as C
+    from vdlm2dec_amd import lib
+    assert shard.BURST_DTYPE.itemsize == C.sizeof(lib.BurstT) == 2104
+    for name, _ in lib.BurstT._fields_:
+        assert shard.BURST_DTYPE.fields[name][1] == getattr(lib.BurstT, name).offset, name
+    buf = (lib.BurstT * 3)()
+    buf[1].stream, buf[1].chn, buf[1].nbrow, buf[1].nlbyte, buf[1].df, buf[1].trig_dec, buf[1].end_dec = 2, 5, 3, 77, -0.4, 123456789012, 123456789999
+    buf[1].data[7][254] = 0xAB
+    raw = np.frombuffer(buf, dtype=shard.BURST_DTYPE)
+    r = shard.pack_records(raw, stream_offset=10)[1]
+    assert (r["stream"], r["chn"], r["nbrow"], r["nlbyte"], r["trig_dec"], r["end_dec"]) == (12, 5, 3, 77, 123456789012, 123456789999)
+    assert r["df_bits"] == np.float32(-0.4).view(np.uint32) and r["data"][8 * 255 - 1] == 0xAB
 
 
 def test_shard_partition_is_exact():

@@ -15,7 +15,7 @@ from vdlm2dec_amd import synth
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.json")) if "quirk" not in p)
+CASES = sorted(glob.glob(os.path.join(HERE, "golden", "*.json")))
 
 
 def _rx(rate, fos, fmt, **kw):
@@ -39,7 +39,9 @@ def _frames(O, bursts):
 def test_golden_vectors_from_the_reference(built, oracle, path, block):
     meta = json.load(open(path))
     raw = np.load(os.path.join(HERE, "golden", meta["iq"] + ".npz"))["raw"]
-    with _rx(meta["rate"], meta["fo"], meta["fmt"], max_push=1 << 21) as rx:
+    if meta["quirk"] and block == 50001:
+        pytest.skip("VDL2GPU_F_RTL_QUIRK takes whole 32768-sample blocks (rtl.c:278-281 drops anything else)")
+    with _rx(meta["rate"], meta["fo"], meta["fmt"], max_push=1 << 21, rtl_quirk=bool(meta["quirk"])) as rx:
         got = rx.run(raw, block=block)
     want = sorted((c["chn"], b["nbrow"], b["nlbyte"], bytes.fromhex(b["data"])) for c in meta["channels"] for b in c["blocks"])
     assert _gpu_keys(got) == want                                   # msgblk_t level (pre-RS)
@@ -66,6 +68,10 @@ SCEN = {
     "ten_ms": (lambda: S.single_short(10_000_000, 2_400_000, seed=306, info_len=33, blocks=6), "cs16"),
     "air_real": (lambda: S.single_short(6_000_000, 1_200_000, seed=307, info_len=14, blocks=5), "f32"),
     "cf32": (lambda: S.regimes(seed=308, infos=(7, 35, 80)), "cf32"),
+    # BASELINE.json configs[2] at its stated size: 8 channels @ 10 MS/s; and the Airspy shape, 8 channels of real f32 @ 5 MS/s
+    "eight_cs16_10ms": (lambda: S.eight_channels(rate=10_000_000, seed=309, dur=0.06, info=(3, 17, 40, 24, 30, 13, 5, 45), fo=S.FO8_10MS), "cs16"),
+    "eight_f32_5ms": (lambda: S.eight_channels(rate=5_000_000, seed=311, dur=0.06, info=(3, 17, 40, 24, 30, 13, 5, 45), fo=S.FO8_AIR_5MS), "f32"),
+    "eight_cu8_6ms": (lambda: S.eight_channels(rate=6_000_000, seed=312, dur=0.05, info=(3, 9, 5, 12, 7, 4, 6, 8), fo=S.FO8_AIR_5MS), "cu8"),
 }
 
 
@@ -91,6 +97,37 @@ def test_against_oracle_all_levels(built, oracle, name):
         st = rx.stats()
         assert st["bursts"] == len(want) and st["overflowed"] == 0
     assert _frames(oracle, got) == _frames(oracle, want)
+
+
+def test_rtl_quirk_mode_equals_the_oracle(built, oracle):
+    """VDL2GPU_F_RTL_QUIRK = in_callback() as written (rtl.c:285-292): per 32768-sample block sample k lands in slot
+    k+1, slot 0 is 0, the last sample is lost.  Against the oracle's cu8_quirk conversion (pinned to the real
+    reference's quirk build in test_oracle_vs_ref.py and tests/golden/regimes_cu8_2ms_quirk.json), at every
+    level including the 84 kS/s stream; pushes of one and of several blocks."""
+    spec = S.regimes(seed=320, infos=(5, 40, 70, 250))
+    raw = synth.synth_stream(spec, "cu8")
+    want = oracle.run_oracle(raw, "cu8_quirk", spec.rate, spec.fo, S.FC)
+    assert len(want) >= 3
+    for block in (32768, 3 * 32768, None):
+        with _rx(spec.rate, spec.fo, "cu8", max_push=spec.nsamples, rtl_quirk=True) as rx:
+            got = rx.run(raw, block=block)
+            assert _gpu_keys(got) == sorted(b.key() for b in want)
+            assert sorted((b.chn, b.trig_dec, np.float32(b.df).view(np.uint32).item()) for b in got) == \
+                sorted((b.chn, b.trig_dec, np.float32(b.df).view(np.uint32).item()) for b in want)
+    with _rx(spec.rate, spec.fo, "cu8", max_push=spec.nsamples, rtl_quirk=True) as rx:
+        rx.push(raw)
+        for c, fo in enumerate(spec.fo):
+            ch = oracle.OracleChannel(spec.rate, fo, S.FC + fo, tap_dec=True)
+            ch.feed(raw, "cu8_quirk")
+            d, g = ch.dec(), rx.debug_dec(0, c)
+            assert len(d) == len(g) and np.array_equal(d.view(np.uint32), g.view(np.uint32))
+            ch.close()
+        from vdlm2dec_amd import lib
+        with pytest.raises(lib.Vdl2GpuError):
+            rx.push(raw[:2 * 1000])         # not a whole block
+    from vdlm2dec_amd import lib
+    with pytest.raises(lib.Vdl2GpuError):
+        _rx(spec.rate, spec.fo, "cs16", rtl_quirk=True)     # the quirk is in_callback's: cu8 only
 
 
 @pytest.mark.parametrize("blocks", [[1], [1, 2, 3, 5, 7, 11], [23], [24], [2000], [4096, 1, 4095], [100000, 17]])

@@ -41,7 +41,7 @@ struct PushTiming {
 	uint64_t samples;
 	bool fast;
 	bool staged;
-	int fast_parts;		/* k1_fast launches of this push: e[11]..e[12] (if two) and e[8]..e[9] */
+	int fast_parts;		/* fast-kernel launches of this push (e[8]..e[9]); e[11] = end of the first period's general launch */
 };
 
 struct vdl2gpu {
@@ -97,6 +97,7 @@ struct vdl2gpu {
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int force_serial = 0;
+	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
 	int n_cu = 256;
 	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
 	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown) */
@@ -131,13 +132,14 @@ struct vdl2gpu {
 	unsigned frame_cap = 0;	/* bytes of a frame buffer (slots + arena) */
 
 	std::vector<uint8_t> fready;		/* compact frame entries as k4_frames wrote them, storage order */
-	std::vector<uint32_t> fready_idx;	/* hand-out order: byte offsets into `fready`, consumed from fready_pos */
+	std::vector<size_t> fready_idx;	/* hand-out order: byte offsets into `fready`, consumed from fready_pos */
 	size_t fready_pos = 0;
 	uint64_t frames_dropped = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
 	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [24*ring + {0..6}] counters, [24*ring + 8 ..] redo mask */
 	unsigned *d_pin_cnt = nullptr;	/* its device address */
 	unsigned pin_recs = 0;
+	bool failed = false;	/* a HIP call failed while work was being enqueued: device and host state no longer agree */
 	std::string err;
 };
 
@@ -186,6 +188,99 @@ extern "C" int vdl2gpu_plan(uint64_t total_in, uint64_t n, unsigned sdrclk, unsi
 	const uint64_t first = (uint64_t)((num + 20) / 21);
 	*nf0 = (int)(total_in - first);
 	*nout = (int64_t)(((uint64_t)*c0 + 21ull * n) / sdrclk);
+	return VDL2GPU_OK;
+}
+
+/* chooseFc() of rtl.c:123-160 (the tuner centre for a list of channel frequencies) and the mixer offsets of
+ * rtl.c:245-247.  The reference walks Fc down in 1 Hz steps from max + 50 kHz to min - 50 kHz and takes the first
+ * value at which every channel is within SDRINRATE/2 - 50 kHz of Fc, none is closer than 50 kHz, and no two
+ * neighbouring (sorted) channels are mirror images; if none qualifies the loop ends with Fc = min - 50 kHz, which
+ * the reference then uses (reproduced, not fixed).  Parity unpinned: rtl.c needs rtl-sdr.h. */
+extern "C" int vdl2gpu_choose_fc_rtl(const unsigned *fr, int nbch, unsigned sdrinrate, unsigned *fc, int *fo)
+{
+	if (!fr || !fc || nbch < 1 || nbch > VDL2GPU_MAXCH || sdrinrate < 200000)
+		return VDL2GPU_EINVAL;
+	const int step = 25000;		/* STEPRATE, vdlm2.h:33 */
+	unsigned fd[VDL2GPU_MAXCH];
+	for (int n = 0; n < nbch; ++n)
+		fd[n] = fr[n];
+	std::sort(fd, fd + nbch);	/* rtl.c:128-140 */
+	*fc = 0;
+	if (fd[nbch - 1] - fd[0] > sdrinrate - 4u * step) {	/* rtl.c:142-145: "Frequencies too far apart" */
+		if (fo)
+			for (int n = 0; n < nbch; ++n)
+				fo[n] = 0;
+		return VDL2GPU_OK;
+	}
+	int c, n = 0;
+	for (c = (int)fd[nbch - 1] + 2 * step; c > (int)fd[0] - 2 * step; --c) {	/* rtl.c:147-158, int arithmetic as there */
+		for (n = 0; n < nbch; ++n) {
+			if (std::abs(c - (int)fd[n]) > (int)(sdrinrate / 2) - 2 * step)
+				break;
+			if (std::abs(c - (int)fd[n]) < 2 * step)
+				break;
+			if (n > 0 && c - (int)fd[n - 1] == (int)fd[n] - c)
+				break;
+		}
+		if (n == nbch)
+			break;
+	}
+	*fc = (unsigned)c;
+	if (fo)
+		for (int i = 0; i < nbch; ++i)
+			fo[i] = (int)fr[i] - c;	/* rtl.c:245-247 */
+	return VDL2GPU_OK;
+}
+
+/* chooseFc() of air.c:47-70 and the mixer offsets of air.c:182-184.  Parity unpinned: air.c needs airspy.h. */
+extern "C" int vdl2gpu_choose_fc_air(const unsigned *fr, int nbch, unsigned sdrinrate, unsigned *fc, int *fo, int *r10, int *r11)
+{
+	if (!fr || !fc || nbch < 1 || nbch > VDL2GPU_MAXCH)
+		return VDL2GPU_EINVAL;
+	static const unsigned hf[] = {1953050, 1980748, 2001344, 2032592, 2060291, 2087988};	/* r820t_hf, air.c:44 */
+	static const unsigned lf[] = {525548, 656935, 795424, 898403, 1186034, 1502073, 1715133, 1853622};	/* r820t_lf, air.c:45 */
+	const unsigned step = 25000;
+	unsigned minf = 140000000u, maxf = 0;	/* air.c:77, 96-97 */
+	for (int n = 0; n < nbch; ++n) {
+		minf = std::min(minf, fr[n]);
+		maxf = std::max(maxf, fr[n]);
+	}
+	const unsigned bw = maxf - minf + 2 * step;
+	unsigned off = 0;
+	if (r10)
+		*r10 = 0;
+	if (r11)
+		*r11 = 0;
+	*fc = 0;
+	if (sdrinrate == 5000000) {	/* the R820T2 of the Airspy R2, air.c:53-66 */
+		int i, j;
+		for (i = 7; i >= 0; --i)
+			if (hf[5] - lf[i] >= bw)
+				break;
+		if (i < 0) {	/* air.c:57: return 0 */
+			if (fo)
+				for (int n = 0; n < nbch; ++n)
+					fo[n] = 0;
+			return VDL2GPU_OK;
+		}
+		for (j = 5; j >= 0; --j)
+			if (hf[j] - lf[i] <= bw)
+				break;
+		++j;
+		if (j > 5)	/* cannot happen: hf[5] - lf[i] >= bw and the test is <=; only equality leaves j = 5 -> 6 */
+			j = 5;
+		off = (hf[j] + lf[i]) / 2 - sdrinrate / 4;
+		if (r10)
+			*r10 = 0xB0 | (15 - j);
+		if (r11)
+			*r11 = 0xE0 | (15 - i);
+	}
+	*fc = ((maxf + minf) / 2 + off + step / 2) / step * step;	/* air.c:69 */
+	if (fo) {
+		const unsigned f0 = *fc + sdrinrate / 4;	/* air.c:182 */
+		for (int n = 0; n < nbch; ++n)
+			fo[n] = (int)(fr[n] - f0);
+	}
 	return VDL2GPU_OK;
 }
 
@@ -422,6 +517,7 @@ static int create_impl(vdl2gpu_t *h)
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
 		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
+	h->quirk = (cfg.flags & VDL2GPU_F_RTL_QUIRK) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
 	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 48 * sizeof(unsigned), hipHostMallocMapped));
@@ -500,6 +596,8 @@ extern "C" int vdl2gpu_create(const vdl2gpu_config_t *cfg, vdl2gpu_t **out)
 		return VDL2GPU_EINVAL;
 	if (fmt_bytes(cfg->fmt) == 0 || cfg->sdrinrate < 100000 || cfg->sdrinrate % 25000)
 		return VDL2GPU_EINVAL;
+	if ((cfg->flags & VDL2GPU_F_RTL_QUIRK) && cfg->fmt != VDL2GPU_FMT_CU8)
+		return VDL2GPU_EINVAL;	/* the quirk is in_callback()'s, and that only ever sees cu8 */
 	const unsigned sdrclk = cfg->sdrclk ? cfg->sdrclk : cfg->sdrinrate / 4000;
 	if (sdrclk <= 21 || sdrclk > 1000000)
 		return VDL2GPU_EINVAL;
@@ -549,6 +647,13 @@ static int harvest_timing(vdl2gpu_t *h)
 				break;
 			HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : pt.e[i], pt.e[i + 1]));
 		}
+		if (pt.fast) {	/* kernel intervals only: first period | (wait for the previous push's resolver) | fast kernel | tail */
+			float a = 0, b = 0, c = 0;
+			HIPCHK(h, hipEventElapsedTime(&a, pt.e[0], pt.e[11]));
+			HIPCHK(h, hipEventElapsedTime(&b, pt.e[8], pt.e[9]));
+			HIPCHK(h, hipEventElapsedTime(&c, pt.e[9], pt.e[1]));
+			d[0] = a + b + c;
+		}
 		h->tm.channelise_ms += d[0];
 		h->tm.scan_ms += d[1] + d[4];
 		h->tm.cluster_ms += d[2];
@@ -559,12 +664,7 @@ static int harvest_timing(vdl2gpu_t *h)
 			float f = 0;
 			HIPCHK(h, hipEventElapsedTime(&f, pt.e[8], pt.e[9]));
 			h->tm.channelise_fast_ms += f;
-			h->tm.fast_pushes++;	/* counts k1_fast launches */
-			if (pt.fast_parts > 1) {
-				HIPCHK(h, hipEventElapsedTime(&f, pt.e[11], pt.e[12]));
-				h->tm.channelise_fast_ms += f;
-				h->tm.fast_pushes++;
-			}
+			h->tm.fast_pushes++;	/* counts fast-kernel launches */
 		}
 		h->tm.pushes++;
 		h->tm.samples += pt.samples;
@@ -583,11 +683,23 @@ template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t sm
 
 static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy);
 
+static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy)
+{
+	if (h && h->failed) {
+		h->err = "an earlier HIP error left the handle unusable: " + h->err;
+		return VDL2GPU_EHIP;
+	}
+	const int rc = push_impl(h, iq, nsamples, stream_stride_bytes, memkind, wait_copy);
+	if (rc == VDL2GPU_EHIP)
+		h->failed = true;	/* part of the push may be enqueued: nothing after it can be trusted */
+	return rc;
+}
+
 extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind)
 {
 	/* the caller may reuse a host buffer as soon as we return (the reference's producer refills Cbuff
 	 * right after the consumers pass Bar1, d8psk.c:383): wait for the copy, not for the kernels */
-	return push_impl(h, iq, nsamples, stream_stride_bytes, memkind, true);
+	return push_checked(h, iq, nsamples, stream_stride_bytes, memkind, true);
 }
 
 /* ---------------------------------------------------------------- ingest ring */
@@ -638,13 +750,18 @@ extern "C" int vdl2gpu_ring_commit(vdl2gpu_t *h, size_t nsamples)
 	h->ring_next++;
 	if (nsamples == 0)
 		return VDL2GPU_OK;	/* e.g. a short USB read: the block is dropped (rtl.c:278-281) */
-	const int rc = push_impl(h, (char *)h->ring_host + slot * h->ring_slot_bytes, nsamples,
-				 h->ring_slot_samples * h->sample_bytes, VDL2GPU_MEM_HOST, false);
-	if (rc != VDL2GPU_OK)
-		return rc;
-	HIPCHK(h, hipEventRecord(h->ring_copied[slot], h->in_stream));
-	h->ring_inflight[slot] = 1;
-	return VDL2GPU_OK;
+	const int rc = push_checked(h, (char *)h->ring_host + slot * h->ring_slot_bytes, nsamples,
+				    h->ring_slot_samples * h->sample_bytes, VDL2GPU_MEM_HOST, false);
+	if (h->in_stream) {	/* whatever was enqueued from the slot, its end is marked: acquire() waits for it */
+		if (hipEventRecord(h->ring_copied[slot], h->in_stream) == hipSuccess)
+			h->ring_inflight[slot] = 1;
+		else if (rc == VDL2GPU_OK) {
+			h->err = "hipEventRecord(ring_copied)";
+			h->failed = true;
+			return VDL2GPU_EHIP;
+		}
+	}
+	return rc;
 }
 
 static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy)
@@ -657,6 +774,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		return VDL2GPU_EINVAL;
 	if (h->S > 1 && stream_stride_bytes < nsamples * h->sample_bytes)
 		return VDL2GPU_EINVAL;
+	if (h->quirk && nsamples % 32768) {
+		h->err = "VDL2GPU_F_RTL_QUIRK: every push must be whole 32768-sample blocks";
+		return VDL2GPU_EINVAL;
+	}
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	if (h->pending.size() >= 256) {	/* bound the event backlog */
 		HIPCHK(h, hipStreamSynchronize(h->k1_stream));
@@ -721,6 +842,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	k1.L = h->L;
 	k1.maxwin = h->maxwin;
 	k1.parity = par;
+	k1.quirk = h->quirk;
 	k1.N = (long long)nsamples;
 	k1.J = J;
 	k1.lo = h->d_lo;
@@ -773,7 +895,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		 * window) and the tail on the general one */
 		const long long periods = J / K1P_PER_OUT;
 		const int per_in = 4 * h->sdrclk;
-		bool fast = (per_in % h->L == 0 && periods >= 4 && !getenv("VDL2GPU_NO_K1_FAST"));
+		bool fast = (per_in % h->L == 0 && periods >= 4 && !h->quirk && !getenv("VDL2GPU_NO_K1_FAST"));
 		K1PParams kp{};
 		if (fast) {
 			auto wend_abs = [&](long long j) { return ((j + 1) * (long long)h->sdrclk - k1.c0 + 20) / 21 - 1; };
@@ -790,6 +912,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (fast2m) {
 			/* 2 MS/s: the LO values of a window fit a lane's registers (lane = window x channel) */
 			generic(0, K1F_PER_OUT - 1);
+			(void)hipEventRecord(pt.e[11], ks);	/* the wait for the resolver that follows is not channeliser time */
 			pt.fast = true;
 			k1.per_lo = 1;
 			k1.per_n = periods - 2;
@@ -821,6 +944,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			generic((periods - 1) * K1F_PER_OUT, J);
 		} else if (fast) {
 			generic(0, K1P_PER_OUT - 1);
+			(void)hipEventRecord(pt.e[11], ks);
 			pt.fast = true;
 			kp.raw = src;
 			kp.stream_stride = stride;
@@ -1112,9 +1236,26 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		h->repairs_seen = repairs;
 	}
 	if (n) {
+		/* bounded: a consumer that never collects bursts (only frames) loses the oldest ones, counted */
+		const size_t qmax = 4 * (size_t)h->rec_cap;
+		if (h->ready_idx.size() - h->ready_pos > qmax) {
+			const size_t drop = h->ready_idx.size() - h->ready_pos - qmax;
+			h->ready_pos += drop;
+			h->overflowed += drop;
+		}
 		if (h->ready_pos == h->ready_idx.size()) {	/* everything handed out: recycle storage */
 			h->ready.clear();
 			h->ready_idx.clear();
+			h->ready_pos = 0;
+		} else if (h->ready_pos > 2 * qmax) {	/* a long-lived backlog: drop the handed-out prefix of the storage */
+			std::vector<vdl2gpu_burst_t> keep;
+			keep.reserve(h->ready_idx.size() - h->ready_pos);
+			for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
+				keep.push_back(h->ready[h->ready_idx[i]]);
+			h->ready.swap(keep);
+			h->ready_idx.resize(h->ready.size());
+			for (size_t i = 0; i < h->ready_idx.size(); ++i)
+				h->ready_idx[i] = (uint32_t)i;
 			h->ready_pos = 0;
 		}
 		const size_t old = h->ready.size();
@@ -1173,9 +1314,30 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		const unsigned nbytes = std::min(h->h_pin_cnt[24 * ring + 6], h->frame_cap - arena0);
 		h->frames_dropped += h->h_pin_cnt[24 * ring + 5];
 		if (n) {
+			{	/* bounded like the burst queue: the oldest frames go, counted */
+				const size_t qmax = 4 * (size_t)h->rec_cap;
+				if (h->fready_idx.size() - h->fready_pos > qmax) {
+					const size_t drop = h->fready_idx.size() - h->fready_pos - qmax;
+					h->fready_pos += drop;
+					h->frames_dropped += drop;
+				}
+			}
 			if (h->fready_pos == h->fready_idx.size()) {
 				h->fready.clear();
 				h->fready_idx.clear();
+				h->fready_pos = 0;
+			} else if (h->fready_pos > 8 * (size_t)h->rec_cap) {	/* compact: entries are self-delimiting */
+				std::vector<uint8_t> keep;
+				std::vector<size_t> kidx;
+				const size_t hdr0 = offsetof(vdl2gpu_frame_t, data);
+				for (size_t i = h->fready_pos; i < h->fready_idx.size(); ++i) {
+					const uint8_t *e = h->fready.data() + h->fready_idx[i];
+					const size_t sz = (hdr0 + (size_t)reinterpret_cast<const vdl2gpu_frame_t *>(e)->len + 7) & ~(size_t)7;
+					kidx.push_back(keep.size());
+					keep.insert(keep.end(), e, e + sz);
+				}
+				h->fready.swap(keep);
+				h->fready_idx.swap(kidx);
 				h->fready_pos = 0;
 			}
 			const size_t old = h->fready.size();
@@ -1219,7 +1381,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 				off += (hdr + (size_t)f->len + 7) & ~(size_t)7;
 			}
 			const uint8_t *fd = h->fready.data();
-			std::sort(h->fready_idx.begin() + iold, h->fready_idx.end(), [fd](uint32_t x, uint32_t y) {
+			std::sort(h->fready_idx.begin() + iold, h->fready_idx.end(), [fd](size_t x, size_t y) {
 				const vdl2gpu_frame_t &a = *reinterpret_cast<const vdl2gpu_frame_t *>(fd + x);
 				const vdl2gpu_frame_t &b = *reinterpret_cast<const vdl2gpu_frame_t *>(fd + y);
 				if (a.end_dec != b.end_dec)
@@ -1378,6 +1540,8 @@ extern "C" int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	if (!h || (max > 0 && !out) || max < 0)
 		return VDL2GPU_EINVAL;
+	if (h->failed)
+		return VDL2GPU_EHIP;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	int rc = harvest_all(h, true);
 	if (rc)
@@ -1389,6 +1553,8 @@ extern "C" int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	if (!h || (max > 0 && !out) || max < 0)
 		return VDL2GPU_EINVAL;
+	if (h->failed)
+		return VDL2GPU_EHIP;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	int rc = harvest_all(h, false);
 	if (rc)
@@ -1421,6 +1587,7 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 			out->serial_redos += x.n_redo;
 		}
 	out->overflowed = h->overflowed;
+	out->frames_dropped = h->frames_dropped;
 	return VDL2GPU_OK;
 }
 

@@ -608,6 +608,8 @@ void k4_frames(K4Params p)
 		K4_SYNC();
 		if (lane == 0) {	/* frames in stream order (there is almost never more than one) */
 			int nf0 = sh.ctl[1] < 12 ? sh.ctl[1] : 12;
+			if (sh.ctl[1] > 12)	/* more CRC-clean frames in one burst than the table holds: counted, not silent */
+				atomicAdd(p.nframes + 1, (unsigned)(sh.ctl[1] - 12));
 			for (int i = 1; i < nf0; ++i)
 				for (int j = i; j > 0 && sh.ctl[2 + j] < sh.ctl[1 + j]; --j) {
 					const int t = sh.ctl[2 + j];

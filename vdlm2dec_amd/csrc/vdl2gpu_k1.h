@@ -74,6 +74,15 @@ void k1_channelise(K1Params p)
 		const long long in_hi = (jhi == p.J) ? p.N - 1 : k1_win_end(jhi, p.sdrclk, p.c0);
 		const int cnt = (int)(in_hi - in_lo + 1);
 		__syncthreads();
+		if (FMT == VDL2GPU_FMT_CU8 && p.quirk) {
+			/* rtl.c:285-292 as written: within every hand-off block of 32768 samples, sample k lands in slot
+			 * k + 1, slot 0 stays 0 (BSS) and the block's last sample is lost.  Pushes are whole
+			 * blocks in this mode, so the position in the block is the position in the push modulo 32768. */
+			for (int i = tid; i < cnt; i += K1_THREADS) {
+				const long long gi = in_lo + i;
+				xs[i] = (gi & 32767) ? k1_load<FMT>(raw, gi - 1) : make_float2(0.0f, 0.0f);
+			}
+		} else
 		for (int i = tid; i < cnt; i += K1_THREADS)
 			xs[i] = k1_load<FMT>(raw, in_lo + i);
 		__syncthreads();

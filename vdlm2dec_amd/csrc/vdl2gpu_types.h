@@ -82,6 +82,7 @@ struct K1Params {
 	int fmt, nbch;
 	int sdrclk, L, maxwin;
 	int c0, no0, nf0, parity;
+	int quirk;		/* cu8 only: the store-index off-by-one of rtl.c:291, per 32768-sample block */
 	long long N, J;
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
 	long long per_lo, per_n;	/* k1_fast: whole 84-output periods [per_lo, per_lo+per_n) */

@@ -58,7 +58,7 @@ class Receiver:
     def __init__(self, sdrinrate: int, channels: Sequence[ThreadParam] | Sequence[Sequence[ThreadParam]],
                  fmt: str = "cu8", max_push: int = 1 << 22, device: int = 0, sdrclk: int = 0,
                  max_bursts: int = 0, keep_dec: bool = False, serial: bool = False, full_scan: bool = False,
-                 frames: bool = False, flags: int = 0):
+                 frames: bool = False, rtl_quirk: bool = False, flags: int = 0):
         self.L = _lib.load()
         if channels and isinstance(channels[0], ThreadParam):
             channels = [list(channels)]
@@ -84,7 +84,7 @@ class Receiver:
         cfg.max_push = max_push
         cfg.device = device
         cfg.max_bursts = max_bursts
-        cfg.flags = (_lib.F_KEEP_DEC if keep_dec else 0) | (_lib.F_SERIAL if serial else 0) | (_lib.F_FULLSCAN if full_scan else 0) | (_lib.F_FRAMES if frames else 0) | flags
+        cfg.flags = (_lib.F_KEEP_DEC if keep_dec else 0) | (_lib.F_SERIAL if serial else 0) | (_lib.F_FULLSCAN if full_scan else 0) | (_lib.F_FRAMES if frames else 0) | (_lib.F_RTL_QUIRK if rtl_quirk else 0) | flags
         self.max_push = max_push
         self.h = C.c_void_p()
         rc = self.L.vdl2gpu_create(C.byref(cfg), C.byref(self.h))
@@ -268,6 +268,33 @@ class Receiver:
             self.close()
         except Exception:
             pass
+
+
+def choose_fc(freqs: Sequence[int], sdrinrate: int = 2_000_000, tuner: str = "rtl"):
+    """The reference's frequency plan for a list of channel frequencies in Hz.
+
+    tuner "rtl": chooseFc() of rtl.c:123-160, Fo = Fr - Fc (rtl.c:245-247); returns (Fc, [ThreadParam...]).
+    tuner "air": chooseFc() of air.c:47-70, Fo = Fr - (Fc + SDRINRATE/4) (air.c:182-184); returns
+    (Fc, [ThreadParam...], (r10, r11)) with the two R820T2 filter registers the reference writes at 5 MS/s.
+    Fc == 0 means the reference refuses the list ("Frequencies too far apart")."""
+    L = _lib.load()
+    n = len(freqs)
+    fr = (C.c_uint * n)(*[int(f) for f in freqs])
+    fo = (C.c_int * n)()
+    fc = C.c_uint(0)
+    if tuner == "rtl":
+        rc = L.vdl2gpu_choose_fc_rtl(fr, n, sdrinrate, C.byref(fc), fo)
+        extra = None
+    elif tuner == "air":
+        r10, r11 = C.c_int(0), C.c_int(0)
+        rc = L.vdl2gpu_choose_fc_air(fr, n, sdrinrate, C.byref(fc), fo, C.byref(r10), C.byref(r11))
+        extra = (r10.value, r11.value)
+    else:
+        raise ValueError("tuner must be 'rtl' or 'air'")
+    if rc < 0:
+        raise _lib.Vdl2GpuError("vdl2gpu_choose_fc failed: " + L.vdl2gpu_strerror(rc).decode())
+    plan = [ThreadParam(chn=i, Fr=int(freqs[i]), Fo=int(fo[i])) for i in range(n)]
+    return (fc.value, plan) if extra is None else (fc.value, plan, extra)
 
 
 def lo_table(sdrinrate: int, fo: int) -> np.ndarray:

@@ -20,6 +20,7 @@ F_SERIAL = 2
 F_FULLSCAN = 4
 F_TEST_NOREGION = 8
 F_FRAMES = 16
+F_RTL_QUIRK = 32
 
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
@@ -27,6 +28,7 @@ EXPORTS = (
     "vdl2gpu_ring_init", "vdl2gpu_ring_acquire", "vdl2gpu_ring_commit",
     "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "vdl2gpu_decode_blocks", "vdl2gpu_poll_frames", "vdl2gpu_poll_frames_ready", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
+    "vdl2gpu_choose_fc_rtl", "vdl2gpu_choose_fc_air",
     "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs",
 )
 
@@ -58,7 +60,8 @@ class FrameT(C.Structure):
 
 class StatsT(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples_in", "dec_samples", "sync_evals", "triggers",
-                                          "header_rejects", "bursts", "deferrals", "candidates", "serial_redos", "serial_samples", "overflowed")]
+                                          "header_rejects", "bursts", "deferrals", "candidates", "serial_redos", "serial_samples", "overflowed",
+                                          "frames_dropped")]
 
 
 class TimingT(C.Structure):
@@ -138,6 +141,11 @@ def load():
     L.vdl2gpu_plan.restype = C.c_int
     L.vdl2gpu_plan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.POINTER(C.c_int),
                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.vdl2gpu_choose_fc_rtl.restype = C.c_int
+    L.vdl2gpu_choose_fc_rtl.argtypes = [C.POINTER(C.c_uint), C.c_int, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    L.vdl2gpu_choose_fc_air.restype = C.c_int
+    L.vdl2gpu_choose_fc_air.argtypes = [C.POINTER(C.c_uint), C.c_int, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.vdl2gpu_debug_dec.restype = C.c_int64
     L.vdl2gpu_debug_dec.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
     L.vdl2gpu_debug_lo.restype = C.c_int

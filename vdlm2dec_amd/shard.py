@@ -19,6 +19,23 @@ REC_DTYPE = np.dtype([("stream", "<i4"), ("chn", "<i4"), ("nbrow", "<i4"), ("nlb
                       ("data", "u1", (8 * 255,))])
 
 
+# vdl2gpu_burst_t (include/vdl2gpu.h) as a numpy record: what vdl2gpu_poll*() writes, read without a Python loop
+BURST_DTYPE = np.dtype({"names": ["stream", "chn", "Fr", "nbrow", "nlbyte", "df", "ppm", "trig_dec", "end_dec",
+                                  "trig_sample", "end_sample", "data"],
+                        "formats": ["<i4", "<i4", "<i4", "<i4", "<i4", "<f4", "<f4", "<i8", "<i8", "<i8", "<i8", ("u1", (8 * 255,))],
+                        "offsets": [0, 4, 8, 12, 16, 20, 24, 32, 40, 48, 56, 64], "itemsize": 2104})
+
+
+def pack_records(raw: np.ndarray, stream_offset: int = 0) -> np.ndarray:
+    """vdl2gpu_burst_t records (BURST_DTYPE) -> the packed form that travels between ranks."""
+    out = np.zeros(len(raw), REC_DTYPE)
+    out["stream"] = raw["stream"] + stream_offset
+    for k in ("chn", "nbrow", "nlbyte", "trig_dec", "end_dec", "data"):
+        out[k] = raw[k]
+    out["df_bits"] = raw["df"].view(np.uint32)
+    return out
+
+
 def shard_streams(nstreams: int, rank: int, world: int) -> range:
     """Contiguous, balanced block of stream indices owned by `rank` (first ranks get the remainder)."""
     base, rem = divmod(nstreams, world)
@@ -40,6 +57,21 @@ def digest(recs: np.ndarray) -> bytes:
     """Order-independent digest of a set of burst records (for cross-rank / cross-run comparison)."""
     order = np.lexsort((recs["trig_dec"], recs["chn"], recs["stream"]))
     return hashlib.sha256(recs[order].tobytes()).digest()
+
+
+def run_sharded(nstreams: int, decode, dst: int = 0, group=None):
+    """The N > 1 path: every rank decodes its own contiguous block of the `nstreams` wideband
+    streams -- no data-path collective, streams share nothing -- and the results are collected on `dst`.
+
+    decode(stream_indices: range) -> packed records (REC_DTYPE, `stream` = GLOBAL stream index) of those streams;
+    on the GPU box that is a vdlm2dec_amd.demod.Receiver over the rank's device (bench.py, tests/test_gpu_multi.py),
+    in the CPU tests the oracle stands in (tests/test_dist_cpu.py): the sharding and the gather are the same code.
+    Returns (records on dst / empty elsewhere, per-rank counts, this rank's stream range)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = shard_streams(nstreams, rank, world)
+    recs = decode(mine)
+    allrecs, counts = gather_bursts(recs, dst, group)
+    return allrecs, counts, mine
 
 
 def _device(group=None) -> torch.device:
