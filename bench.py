@@ -67,7 +67,7 @@ CONFIGS = {
 
 def make_tile(seed: int, fmt: str, rate: int, fos):
     from vdlm2dec_amd import synth
-    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0 * rate / 2_000_000, info_max=240)
+    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0, info_max=240)   # the same traffic per channel-second at every rate
     return spec, synth.synth_stream(spec, fmt)
 
 

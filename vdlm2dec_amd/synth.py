@@ -397,3 +397,44 @@ def random_scenario(rate: int, fo: Sequence[int], nsamples: int, seed: int,
             bursts.append(b)
             t += d + 0.0015 + rng.exponential(1.0 / bursts_per_s)
     return StreamSpec(rate=rate, fo=tuple(fo), nsamples=nsamples, bursts=bursts, noise=noise, seed=seed)
+
+
+# --------------------------------------------------------------------------- command line
+def _cli(argv=None) -> int:
+    """python -m vdlm2dec_amd.synth -- write a synthetic VDL2 recording and its ground truth.
+
+    The reference has no transmitter and no file input: this is the tool that makes every
+    fixture, benchmark stream and BER curve of this repository reproducible from a seed."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(prog="python -m vdlm2dec_amd.synth", description=_cli.__doc__)
+    ap.add_argument("out", help="raw IQ file to write (interleaved I,Q in --fmt; real samples for f32)")
+    ap.add_argument("--fmt", default="cu8", choices=["cu8", "cs16", "cf32", "f32"])
+    ap.add_argument("--rate", type=int, default=2_000_000, help="SDRINRATE (2000000 rtl; 5000000/6000000 airspy; 10000000)")
+    ap.add_argument("--fo", type=int, nargs="+", default=list(DEFAULT_FO_8CH), help="channel offsets from the tuner centre, Hz")
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--bursts-per-s", type=float, default=4.0, help="arrival rate per channel behind each burst")
+    ap.add_argument("--info-max", type=int, default=240, help="AVLC info field: 1..N random bytes")
+    ap.add_argument("--amp", type=float, nargs=2, default=(8.0, 60.0), metavar=("MIN", "MAX"), help="amplitude, LSB at cu8 scale")
+    ap.add_argument("--noise", type=float, default=1.7, help="AWGN sigma per component, LSB at cu8 scale")
+    ap.add_argument("--cfo", type=float, default=400.0, help="carrier offsets uniform in +-CFO Hz")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--truth", help="JSON file: every burst sent (channel, start, AVLC info, the frame out() must see, msgblk rows)")
+    a = ap.parse_args(argv)
+    ns = (int(a.seconds * a.rate) + 32767) // 32768 * 32768      # whole RTL hand-off blocks (vdlm2.h:35)
+    spec = random_scenario(a.rate, a.fo, ns, seed=a.seed, bursts_per_s=a.bursts_per_s, info_max=a.info_max,
+                           noise=a.noise, amp_range=tuple(a.amp), cfo_max=a.cfo)
+    synth_stream(spec, a.fmt).tofile(a.out)
+    if a.truth:
+        tr = []
+        for b in sorted(spec.bursts, key=lambda b: b.t0):
+            nbrow, nlbyte, rows = received_rows(b.payload())
+            tr.append(dict(chan=b.chan, fo=int(a.fo[b.chan]), t0=b.t0, amp=b.amp, cfo=b.cfo, info=b.info.hex(),
+                           payload=b.payload().hex(), nbrow=nbrow, nlbyte=nlbyte, symbols=b.n_symbols()))
+        json.dump(dict(rate=a.rate, fmt=a.fmt, fo=list(a.fo), nsamples=ns, noise=a.noise, seed=a.seed, bursts=tr), open(a.truth, "w"))
+    print(f"{a.out}: {ns} samples @ {a.rate} S/s {a.fmt}, {len(a.fo)} channels, {len(spec.bursts)} bursts")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(_cli())
