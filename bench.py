@@ -398,10 +398,13 @@ def main():
         k2b_ms = tm["cluster_ms"] / pushes
         k2c_ms = tm["resolve_ms"] / pushes
         k3_ms = tm["other_ms"] / pushes
-        # the full-rate kernel covers all whole 1 ms periods of a push but the first and the last
+        # the full-rate kernel covers all whole periods of a push (1 ms; k1_fast: superperiods of 4 ms) but the first and the last
         sdrclk = rate // 4000
         periods = (batch * 21 // sdrclk) // 84
-        fast_samples = (periods - 2) * 4 * sdrclk * nstr
+        if rate == 2_000_000:
+            fast_samples = (periods // 4 - 2) * 16 * sdrclk * nstr
+        else:
+            fast_samples = (periods - 2) * 4 * sdrclk * nstr
         kname = "k1_fast" if rate == 2_000_000 else "k1_pp"
         fast_ms = tm["channelise_fast_ms"] / max(1, tm["fast_pushes"])
         alg_bytes = float(fast_samples) * sample_bytes

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-flush-denormals-to-zero -fPIC -shared -I include"
 cp vdlm2dec_amd/libvdl2gpu.so /tmp/keep.so
-for v in "" "-DK1F_NO_XCD_MAP" "-DK1F_NOMIX" "-DK1F_NOMIX -DK1F_NO_XCD_MAP" "-DK1F_NOSTORE" "-DK1F_NOLOAD -DK1F_NOSTORE"; do
+for v in ${K1F_VARIANTS:-"" "-DK1F_NO_XCD_MAP" "-DK1F_NOMIX" "-DK1F_NOMIX -DK1F_NO_XCD_MAP" "-DK1F_NOSTORE" "-DK1F_NOLOAD -DK1F_NOSTORE"}; do
   /opt/rocm/bin/hipcc $F $v vdlm2dec_amd/csrc/vdl2gpu.hip -o vdlm2dec_amd/libvdl2gpu.so 2>/dev/null || echo build failed
   python bench.py --no-cpu --no-ring --no-parity --steps 6 --warmup 2 2>/dev/null | tail -1 > /tmp/b.json
   python -c "

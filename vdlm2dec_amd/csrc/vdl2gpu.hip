@@ -461,7 +461,7 @@ static int create_impl(vdl2gpu_t *h)
 	}
 	const int S = h->S, L = h->L;
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
-	h->cap = VDL2_CARRY_FRAMES + jmax + 64;
+	h->cap = (VDL2_CARRY_FRAMES + jmax + 64 + 15) / 16 * 16;	/* planes start on 128-byte lines */
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
 	HIPCHK(h, hipMalloc(&h->d_dec[0], dec_bytes));
 	HIPCHK(h, hipMalloc(&h->d_dec[1], dec_bytes));
@@ -908,30 +908,33 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				fast = false;
 			kp.d = (int)((a0 % 16) / h->sample_bytes);
 		}
-		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && !getenv("VDL2GPU_K1_PP");
+		const long long nsp = periods / 4;	/* superperiods of 4 periods = 336 outputs = 21 lines of the planes */
+		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && nsp >= 3 && !getenv("VDL2GPU_K1_PP");
 		if (fast2m) {
-			/* 2 MS/s: the LO values of a window fit a lane's registers (lane = window x channel) */
+			/* 2 MS/s: the LO values of a window fit a lane's registers (lane = window x channel).  Whole superperiods in
+			 * the middle; the first one (carried partial window) and the tail on the general kernel */
 			generic(0, K1F_PER_OUT - 1);
 			(void)hipEventRecord(pt.e[11], ks);	/* the wait for the resolver that follows is not channeliser time */
 			pt.fast = true;
 			k1.per_lo = 1;
-			k1.per_n = periods - 2;
+			k1.per_n = nsp - 2;
 			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
 			(void)hipEventRecord(pt.e[8], ks);
-			/* periods per wavefront: waves = roles * ceil(periods / pb) should fill a whole number of rounds of
-			 * the GPU's wave slots */
+			/* superperiods per workgroup: workgroups = roles * ceil(superperiods / pb) should fill a whole number of
+			 * rounds of the GPU's slots (2 wavefronts each, 4 or 5 wavefronts per SIMD at this kernel's register count) */
 			long long pb;
 			{
 				const double work = (double)k1.per_n * K1F_ROLES * h->S;
-				const double slots = (double)h->n_cu * 4 * (getenv("VDL2GPU_K1F_OCC") ? atoi(getenv("VDL2GPU_K1F_OCC")) : 5);
-				double rounds = std::ceil(work / (slots * K1F_PB));
+				const double slots = (double)h->n_cu * 2 * (getenv("VDL2GPU_K1F_OCC") ? atoi(getenv("VDL2GPU_K1F_OCC")) : 5);
+				const int pbt = getenv("VDL2GPU_K1F_PB") ? atoi(getenv("VDL2GPU_K1F_PB")) : K1F_PB;
+				double rounds = std::ceil(work / (slots * pbt));
 				if (rounds < 1)
 					rounds = 1;
 				pb = (long long)std::ceil(work / (slots * rounds));
-				pb = std::max<long long>(8, std::min<long long>(pb, 64));
+				pb = std::max<long long>(2, std::min<long long>(pb, 64));
 			}
-			const long long ngrp = (((k1.per_n + pb - 1) / pb) + 7) / 8 * 8;	/* wave groups: a multiple of 8 (one XCD each, see k1_fast) */
+			const long long ngrp = (((k1.per_n + pb - 1) / pb) + 7) / 8 * 8;	/* workgroup groups: a multiple of 8 (one XCD each, see k1_fast) */
 			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
@@ -941,7 +944,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			}
 			(void)hipEventRecord(pt.e[9], ks);
 			pt.fast_parts = 1;
-			generic((periods - 1) * K1F_PER_OUT, J);
+			generic((nsp - 1) * K1F_PER_OUT, J);
 		} else if (fast) {
 			generic(0, K1P_PER_OUT - 1);
 			(void)hipEventRecord(pt.e[11], ks);

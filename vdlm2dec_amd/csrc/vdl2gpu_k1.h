@@ -521,13 +521,99 @@ __device__ __forceinline__ void k1_cmac(v2f &acc, v2f x, v2f w)
 	acc += (a + b);
 }
 
-#define K1F_THREADS 64
-#define K1F_PB 32		/* periods per wavefront */
-#define K1F_DEPTH 4		/* periods of raw samples in flight per wavefront (registers) */
-#define K1F_PER_IN 2000
-#define K1F_PER_OUT 84
-#define K1F_ROLES 11
-#define K1F_SLICE 192		/* >= 8 windows x 24 samples */
+/* Eight (seven) samples with the LO values in VGPRs, ordered so that no instruction reads what the one before it wrote
+ * (A/B = the two products of a sample, T = their sum, S = acc += T in sample order; see k1_cmac8_s). */
+__device__ __forceinline__ void k1_cmac8_v(v2f &acc, const v2f (&x)[8], const v2f *w)
+{
+	v2f a0, b0, a1, b1, a2, b2;
+	asm volatile(
+		K1_A("%1", "%7", "%15") K1_B("%2", "%7", "%15")
+		K1_A("%3", "%8", "%16") K1_B("%4", "%8", "%16")
+		K1_T("%1", "%2")
+		K1_A("%5", "%9", "%17") K1_B("%6", "%9", "%17")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%10", "%18") K1_B("%2", "%10", "%18")
+		K1_T("%5", "%6")
+		K1_S("%3")
+		K1_A("%3", "%11", "%19") K1_B("%4", "%11", "%19")
+		K1_T("%1", "%2")
+		K1_S("%5")
+		K1_A("%5", "%12", "%20") K1_B("%6", "%12", "%20")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%13", "%21") K1_B("%2", "%13", "%21")
+		K1_T("%5", "%6")
+		K1_S("%3")
+		K1_A("%3", "%14", "%22") K1_B("%4", "%14", "%22")
+		K1_T("%1", "%2")
+		K1_S("%5")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		"s_nop 0\n\t"
+		K1_S("%3")
+		: "+v"(acc), "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2)
+		: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+		  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+}
+__device__ __forceinline__ void k1_cmac7_v(v2f &acc, const v2f (&x)[8], const v2f *w)
+{
+	v2f a0, b0, a1, b1, a2, b2;
+	asm volatile(
+		K1_A("%1", "%7", "%14") K1_B("%2", "%7", "%14")
+		K1_A("%3", "%8", "%15") K1_B("%4", "%8", "%15")
+		K1_T("%1", "%2")
+		K1_A("%5", "%9", "%16") K1_B("%6", "%9", "%16")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%10", "%17") K1_B("%2", "%10", "%17")
+		K1_T("%5", "%6")
+		K1_S("%3")
+		K1_A("%3", "%11", "%18") K1_B("%4", "%11", "%18")
+		K1_T("%1", "%2")
+		K1_S("%5")
+		K1_A("%5", "%12", "%19") K1_B("%6", "%12", "%19")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%13", "%20") K1_B("%2", "%13", "%20")
+		K1_T("%5", "%6")
+		K1_S("%3")
+		K1_T("%1", "%2")
+		K1_S("%5")
+		"s_nop 0\n\t"
+		K1_S("%1")
+		: "+v"(acc), "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2)
+		: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]),
+		  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]));
+}
+__device__ __forceinline__ void k1_cmac1_v(v2f &acc, v2f x, v2f w)
+{
+	v2f a, b;
+	asm volatile(K1_A("%1", "%3", "%4") K1_B("%2", "%3", "%4") "s_nop 0\n\t" K1_T("%1", "%2") "s_nop 0\n\t" K1_S("%1")
+		     : "+v"(acc), "=&v"(a), "=&v"(b)
+		     : "v"(x), "v"(w));
+}
+/* eight consecutive float2 from LDS, requested and not waited for (ds_read_b64: 256 bytes a clock; the ds_read2_b64 the
+ * compiler merges neighbouring reads into gets half of that) */
+__device__ __forceinline__ void k1_lds_issue8(v2f (&x)[8], const unsigned a)
+{
+	asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\t"
+		     "ds_read_b64 %3, %8 offset:24\n\tds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\t"
+		     "ds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56"
+		     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+		     : "v"(a)
+		     : "memory");
+}
+
+#define K1F_THREADS 128		/* two wavefronts: channels 0-3 and 4-7 of the same 16 windows */
+#define K1F_PB 24		/* superperiods per workgroup */
+#ifndef K1F_DEPTH
+#define K1F_DEPTH 4		/* superperiods of raw samples in flight per wavefront (registers) */
+#endif
+#define K1F_PER_IN 8000		/* a SUPERPERIOD: 4 periods of the schedule = 336 outputs = 21 lines of 16 */
+#define K1F_PER_OUT 336
+#define K1F_ROLES 21
+#define K1F_SLICE 392		/* >= 16 windows x 24 samples (3 loads per thread cover 384) */
 
 /* raw samples as the wave's loads deliver them: one 32-bit register per sample (64 for cf32) */
 template <int FMT> struct K1Raw { typedef unsigned T; };
@@ -540,12 +626,17 @@ template <> struct K1Raw<VDL2GPU_FMT_CF32> { typedef unsigned T __attribute__((e
  * then costs a full memory round trip, store acknowledgement included, and the kernel is latency-bound. */
 template <int FMT> __device__ __forceinline__ void k1_raw_issue(typename K1Raw<FMT>::T &r, const unsigned voff, const char *sbase)
 {
+#ifdef K1F_LOAD_NT
+#define K1F_LD_MOD " nt"
+#else
+#define K1F_LD_MOD ""
+#endif
 	if constexpr (FMT == VDL2GPU_FMT_CU8)
-		asm volatile("global_load_ushort %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+		asm volatile("global_load_ushort %0, %1, %2" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
 	else if constexpr (FMT == VDL2GPU_FMT_CF32)
-		asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+		asm volatile("global_load_dwordx2 %0, %1, %2" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
 	else
-		asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+		asm volatile("global_load_dword %0, %1, %2" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
 }
 
 template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<FMT>::T v)
@@ -561,57 +652,63 @@ template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<F
 	}
 }
 
-template <int FMT> __global__ __launch_bounds__(K1F_THREADS)
+/* one global_store_dwordx2 that is always ISSUED (the waits count it), with only the `on` lanes enabled */
+__device__ __forceinline__ void k1_store_masked(float2 *dst, v2f v, bool on)
+{
+	const unsigned long long m = __ballot(on);
+	asm volatile("s_mov_b64 s[2:3], exec\n\t"
+		     "s_mov_b64 exec, %2\n\t"
+		     "global_store_dwordx2 %0, %1, off\n\t"
+		     "s_mov_b64 exec, s[2:3]"
+		     :: "v"(dst), "v"(v), "s"(m) : "memory", "s2", "s3");
+}
+
+template <int FMT> __global__ __launch_bounds__(K1F_THREADS, 4)
 void k1_fast(K1Params p)
 {
 	typedef typename K1Raw<FMT>::T raw_t;
 	constexpr int B = (FMT == VDL2GPU_FMT_CU8) ? 2 : (FMT == VDL2GPU_FMT_CF32) ? 8 : 4;
-	__shared__ float2 xs[K1F_SLICE];
-	const int lane = threadIdx.x;
+	/* LDS: every window has its own row of 25 float2 (24 samples + 1 of padding: rows of 50 dwords put the 8 windows of
+	 * a half-wave read on 8 different bank pairs; laid end to end, windows 4 apart -- 95 or 96 samples -- shared banks),
+	 * two copies used in turn (one barrier per iteration) */
+	__shared__ float2 xs[2][16 * 25 + 8];
+	__shared__ int wstart[17];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wv = tid >> 6;
 	const int s = blockIdx.y;
-	/* Wave group w handles periods per_lo + w, + w + NW, + w + 2 NW, .. (NW = number of wave groups): at every
-	 * loop iteration the whole grid reads one contiguous band of NW periods and writes one contiguous band of
-	 * each plane, which keeps HBM pages open, instead of every wave streaming through its own distant range.
-	 * The 11 roles of a wave group write neighbouring 64-byte runs -- halves of the same 128-byte lines -- so
-	 * they must share an L2: workgroup b runs on XCD b % 8, hence b = (group_hi * 11 + role) * 8 + group_lo.
-	 * (With b = group * 11 + role the two halves of a line went through two XCDs' L2s and reached HBM as two
-	 * partial writes; the launch was bound by exactly that.) */
+	/* A workgroup owns 16 consecutive outputs -- ONE 128-byte line of every channel plane -- of a superperiod (4
+	 * periods of the schedule: 8000 inputs, 336 outputs, 21 lines) for many superperiods: lane = (window, channel),
+	 * 16 windows x 4 channels to a wavefront, the two wavefronts share the windows' ~381 samples through LDS.  A
+	 * wavefront's store is four whole, aligned lines.  (Runs of 64 bytes -- 8 windows per wavefront -- reached HBM as
+	 * partial lines once the read stream pushed them out of the L2 before their other halves arrived: the same
+	 * traffic moved in 128 us instead of 86, scripts/micro/store_shape.hip.)
+	 * Workgroup group w handles superperiods per_lo + w, + w + NW, + w + 2 NW, ..: at every iteration the grid reads
+	 * one contiguous band of NW superperiods and writes one contiguous band of each plane.  Workgroup b runs on XCD
+	 * b % 8: b = (group_hi * 21 + role) * 8 + group_lo keeps a group's roles -- neighbouring lines -- on one L2. */
 	const long long nw = (long long)(gridDim.x / K1F_ROLES);	/* a multiple of 8, see the launch */
-#ifdef K1F_NO_XCD_MAP
-	const int g = blockIdx.x % K1F_ROLES;
-	const long long wgrp = (long long)(blockIdx.x / K1F_ROLES);
-#else
 	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
 	const long long wgrp = (long long)(blockIdx.x / (8 * K1F_ROLES)) * 8 + (blockIdx.x & 7);
-#endif
 	const long long pp0 = p.per_lo + wgrp;
 	if (wgrp >= p.per_n)
 		return;
-	const int np = (int)((p.per_n - wgrp + nw - 1) / nw);	/* periods pp0 + q*nw, q < np */
-	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this wave's periods */
-	const int kk = lane >> 3, c = lane & 7;
-	const int k = g * 8 + kk;
-	const bool active = (k < K1F_PER_OUT) && (c < p.nbch);
+	const int np = (int)((p.per_n - wgrp + nw - 1) / nw);	/* superperiods pp0 + q*nw, q < np */
+	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this workgroup's superperiods */
+	const int kk = lane >> 2, c = wv * 4 + (lane & 3);
+	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
 	const long long fill = p.ss[s].dec_fill;
-	/* slice of this wave in period pp0: from the first sample of window 8g to the last of window 8g+7 */
-	const long long j0 = pp0 * K1F_PER_OUT + g * 8;		/* >= 84 */
-	const int klast = (g * 8 + 7 < K1F_PER_OUT) ? 7 : (K1F_PER_OUT - 1 - g * 8);
+	/* slice of this workgroup in superperiod pp0: from the first sample of window 16g to the last of window 16g+15 */
+	const long long j0 = pp0 * K1F_PER_OUT + g * 16;
 	const long long sbase = k1_win_end(j0 - 1, p.sdrclk, p.c0) + 1;
-	const int slen = (int)(k1_win_end(j0 + klast, p.sdrclk, p.c0) - sbase + 1);
-	int off = 0, nwin = 0;
+	if (tid <= 16)
+		wstart[tid] = (int)(k1_win_end(j0 + tid - 1, p.sdrclk, p.c0) + 1 - sbase);	/* [16] = the slice's length */
+	__syncthreads();
+	const int slen = wstart[16];
+	const int off = wstart[kk], nwin = wstart[kk + 1] - wstart[kk];
 	v2f w[24];
-#pragma unroll
-	for (int t = 0; t < 24; ++t)
-		w[t] = (v2f){0.0f, 0.0f};
-	if (active) {
-		const long long j = j0 + kk;
-		const long long a = k1_win_end(j - 1, p.sdrclk, p.c0) + 1;
-		const long long b = k1_win_end(j, p.sdrclk, p.c0);
-		off = (int)(a - sbase);
-		nwin = (int)(b - a + 1);
-		int ph = (int)((p.no0 + a) % 80);
-		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + c) * 80;
+	{
+		int ph = (int)((p.no0 + sbase + off) % 80);
+		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + (active ? c : 0)) * 80;
 #pragma unroll
 		for (int t = 0; t < 24; ++t) {
 			const float2 q = lo[ph];
@@ -620,18 +717,25 @@ void k1_fast(K1Params p)
 		}
 	}
 	const float fn = (float)nwin;
-	const float rfn = 1.0f / (nwin ? fn : 1.0f);	/* RN(1/nf) for the exact FMA division below */
-	float2 *dec = p.dec + ((size_t)s * VDL2_CS + c) * p.cap + fill + pp0 * K1F_PER_OUT + k;
+	const float rfn = 1.0f / fn;	/* RN(1/nf) for the exact FMA division below */
+	float2 *dec = p.dec + ((size_t)s * VDL2_CS + (active ? c : 0)) * p.cap + fill + pp0 * K1F_PER_OUT + g * 16 + kk;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* from here on the only memory operations are the counted ones below */
-	/* lanes fetch samples lane, lane+64, lane+128 of the slice (clamped: the tail lanes of the
-	 * last load re-read the last sample instead of branching) */
+	/* threads fetch samples tid, tid+128, tid+256 of the slice (clamped: the tail re-reads the last sample) and park
+	 * each in the row of the window it belongs to */
 	unsigned vo[3];
+	int xd[3];
 #pragma unroll
 	for (int u = 0; u < 3; ++u) {
-		const int i = lane + u * 64;
-		vo[u] = (unsigned)(i < slen ? i : slen - 1) * B;
+		int i = tid + u * K1F_THREADS;
+		i = i < slen ? i : slen - 1;
+		vo[u] = (unsigned)i * B;
+		int k = 0;
+#pragma unroll
+		for (int m = 1; m < 16; ++m)
+			k += (i >= wstart[m]) ? 1 : 0;
+		xd[u] = k * 25 + (i - wstart[k]);
 	}
-	const char *rbase = raw + sbase * B;		/* the slice in period pp0; wave-uniform */
+	const char *rbase = raw + sbase * B;		/* the slice in superperiod pp0; workgroup-uniform */
 	const long long pbytes = pstride * B;
 	raw_t rr[K1F_DEPTH][3];
 #pragma unroll
@@ -644,10 +748,10 @@ void k1_fast(K1Params p)
 		for (int d = 0; d < K1F_DEPTH; ++d) {
 			const int q = q0 + d;
 			if (q < np) {
-				/* period q: registers -> float -> LDS slice, then refill the registers with period q+DEPTH so
-				 * that DEPTH periods stay in flight.  Every iteration issues exactly 3 loads and 1 store: 4 D - 3
-				 * operations have been issued after the loads of period q in the steady state, 3 D - 3 + q in
-				 * the first round (the stricter 3 D - 3 serves all of it). */
+				/* superperiod q: registers -> float -> LDS slice, then refill the registers with superperiod q+DEPTH so
+				 * that DEPTH of them stay in flight.  Every iteration issues exactly 3 loads and 1 store per wavefront:
+				 * 4 D - 3 operations have been issued after the loads of iteration q in the steady state, 3 D - 3 + q
+				 * in the first round (the stricter 3 D - 3 serves all of it). */
 #if defined(K1F_NOLOAD) || defined(K1F_NOSTORE)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
@@ -659,23 +763,24 @@ void k1_fast(K1Params p)
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
 					asm volatile("" : "+v"(rr[d][u]));	/* read only behind the wait */
+				float2 *xb = xs[q & 1];
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
-					xs[lane + u * 64] = k1_raw_cvt<FMT>(rr[d][u]);
+					xb[xd[u]] = k1_raw_cvt<FMT>(rr[d][u]);
 				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
 #ifndef K1F_NOLOAD
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
 					k1_raw_issue<FMT>(rr[d][u], vo[u], rbase + pbytes * qn);
 #endif
-				__syncthreads();	/* single-wave workgroup: LDS write -> read ordering */
+				__syncthreads();	/* the slice is written */
 				v2f res = {0.0f, 0.0f};
 #ifdef K1F_NOMIX
-				if (active && p.nbch > 8) {
+				if (p.nbch > 8) {
 #else
-				if (active) {
+				{
 #endif
-					const v2f *xp = reinterpret_cast<const v2f *>(&xs[off]);
+					const v2f *xp = reinterpret_cast<const v2f *>(&xb[kk * 25]);
 					v2f acc = {0.0f, 0.0f};
 					if (FMT == VDL2GPU_FMT_F32R) {
 #pragma unroll
@@ -688,11 +793,23 @@ void k1_fast(K1Params p)
 							acc += (v2f){x, x} * w[23];
 						}
 					} else {
-#pragma unroll
-						for (int t = 0; t < 23; ++t)
-							k1_cmac(acc, xp[t], w[t]);
+						/* three blocks of 8 samples; every block is mixed while the next one's samples are on their way
+						 * from LDS (reads return in order: at most 8 outstanding = the previous block is there) */
+						const unsigned xa = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xb[kk * 25];
+						v2f x0[8], x1[8];
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						k1_lds_issue8(x0, xa);
+						k1_lds_issue8(x1, xa + 64u);
+						asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+						k1_cmac8_v(acc, x0, &w[0]);
+						v2f x2[8];
+						k1_lds_issue8(x2, xa + 128u);
+						asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+						k1_cmac8_v(acc, x1, &w[8]);
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						k1_cmac7_v(acc, x2, &w[16]);
 						if (nwin == 24)
-							k1_cmac(acc, xp[23], w[23]);
+							k1_cmac1_v(acc, x2[7], w[23]);
 					}
 					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
 					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
@@ -707,15 +824,17 @@ void k1_fast(K1Params p)
 						res.y = acc.y / fn;
 					}
 				}
-				/* exactly one store instruction per iteration (inactive lanes masked off) */
+				/* exactly one store instruction per iteration and wavefront: four whole lines (channels beyond nbch
+				 * masked off; a wavefront without any channel still issues it, with no lane enabled, so that the
+				 * count above holds) */
 				{
 					float2 *dst = dec + (long long)q * K1F_PER_OUT * nw;
 #ifndef K1F_NOSTORE
-					if (active)
-						asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(res) : "memory");
+					k1_store_masked(dst, res, active);
 #endif
 				}
-				__syncthreads();	/* reads done before the slice is overwritten */
+				/* no second barrier: the next iteration writes the other copy, and the one after that writes this one only
+				 * behind the next iteration's barrier, which every wave reaches after its reads here */
 			}
 		}
 	}
