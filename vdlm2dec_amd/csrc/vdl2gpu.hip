@@ -100,7 +100,9 @@ struct vdl2gpu {
 	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
 	int n_cu = 256;
 	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
-	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown) */
+	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown): an event record between two kernels of the chain
+					 * costs ~3 us, so only every stage_every-th push carries them (the sums are scaled up in harvest) */
+	int stage_every = 4;
 	hipStream_t k1_stream = nullptr;	/* channeliser of push N+1 runs beside the demodulator of push N */
 	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
 	bool k2_rec[2] = {false, false};
@@ -514,6 +516,8 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	HIPCHK(h, hipMalloc(&h->d_seeds, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
+	if (getenv("VDL2GPU_STAGE_EVERY"))
+		h->stage_every = std::max(1, atoi(getenv("VDL2GPU_STAGE_EVERY")));
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
 		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
@@ -655,11 +659,14 @@ static int harvest_timing(vdl2gpu_t *h)
 			d[0] = a + b + c;
 		}
 		h->tm.channelise_ms += d[0];
-		h->tm.scan_ms += d[1] + d[4];
-		h->tm.cluster_ms += d[2];
-		h->tm.resolve_ms += d[3] + d[5];
-		h->tm.demod_ms += d[1] + d[2] + d[3] + d[4] + d[5];
-		h->tm.other_ms += d[6];
+		if (pt.staged) {	/* one push in stage_every carries the chain's events: it stands for all of them */
+			const double k = (double)h->stage_every;
+			h->tm.scan_ms += k * (d[1] + d[4]);
+			h->tm.cluster_ms += k * d[2];
+			h->tm.resolve_ms += k * (d[3] + d[5]);
+			h->tm.demod_ms += k * (d[1] + d[2] + d[3] + d[4] + d[5]);
+			h->tm.other_ms += k * d[6];
+		}
 		if (pt.fast) {
 			float f = 0;
 			HIPCHK(h, hipEventElapsedTime(&f, pt.e[8], pt.e[9]));
@@ -856,7 +863,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		return rc;
 	pt.samples = nsamples;
 	pt.fast = false;
-	pt.staged = h->stage_events;
+	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
+	const bool staged = pt.staged;
 	/* Two streams.  The channeliser of this push only needs the plane set it writes to be free
 	 * (the demodulator of the push before last has finished with it), so it runs on its own
 	 * stream beside the demodulator chain of the previous push, whose one-workgroup-per-channel
@@ -1028,7 +1036,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, h->stream, ki);
 	}
 	HIPCHK(h, hipStreamWaitEvent(h->stream, h->k1_done[par], 0));
-	if (h->stage_events)
+	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[10], h->stream));
 	{
 		K2Params k2{};
@@ -1087,12 +1095,12 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(h->k2_mid_a, h->stream));
 		if (!serial)
 			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
-		if (h->stage_events)
+		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
 		if (!serial)
 			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
-		if (h->stage_events)
+		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
 		HIPCHK(h, hipEventRecord(h->k2_mid, h->stream));
 		h->k2_mid_rec = true;
@@ -1109,7 +1117,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
 			HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
 		}
-		if (h->stage_events)
+		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
 		if (!serial)
 			hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
@@ -1130,7 +1138,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			}
 			HIPCHK(h, hipGetLastError());
 		}
-		if (h->stage_events)
+		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
 		if (h->ring_spec[ring])
@@ -1157,7 +1165,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			HIPCHK(h, hipGetLastError());
 		}
 	}
-	if (h->stage_events)
+	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
 	{
 		K3Params k3{};
@@ -1178,7 +1186,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 	}
-	if (h->stage_events)
+	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
 	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
 	h->k2_rec[par] = true;
