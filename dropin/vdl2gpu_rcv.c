@@ -50,9 +50,11 @@ static void deliver(vdl2gpu_t *h)
 	static vdl2gpu_burst_t b[64];
 	static vdl2gpu_frame_t f[128];
 	static msgblk_t blk;	/* what out() reads of it: chn, Fr, tv, ppm, nbrow, nlbyte */
-	int n, nf, i;
+	int n, nf, i, dropped = 0;
 	while ((n = vdl2gpu_poll(h, b, 64)) > 0) {
-		nf = vdl2gpu_decode_blocks(h, b, n, f, 128, NULL);
+		nf = vdl2gpu_decode_blocks(h, b, n, f, 128, &dropped);
+		if (dropped)	/* more frames than the buffer holds (or than 12 in one burst): never silent */
+			fprintf(stderr, "vdl2gpu_decode_blocks: %d frame(s) dropped\n", dropped);
 		for (i = 0; i < nf; i++) {
 			memset(&blk, 0, sizeof blk);
 			vdl2gpu_burst_to_msgblk(&b[f[i].block], &blk, sizeof blk);
