@@ -304,6 +304,23 @@ def test_repair_rounds_rescan_around_verify_hits(built, oracle, monkeypatch):
     assert _gpu_keys(got) == want and len(want) >= 15
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("drop", [1, 2, 3])
+def test_resolver_builds_the_clusters_it_is_not_given(built, oracle, monkeypatch, drop):
+    """K2s withholds every drop-th candidate from K2b (VDL2GPU_PRIM_DROP): the resolver must replay
+    those stretches itself and end up where the oracle does -- which cluster is precomputed is a cost
+    decision, never a correctness one.  (drop=1: no cluster at all; the second trigger of a push used
+    to spin in this path.)"""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv("VDL2GPU_PRIM_DROP", str(drop))
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 1 << 21, seed=97 + drop, bursts_per_s=12.0, info_max=90)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20) as rx:
+        got = rx.run(raw, block=700_000)
+    assert _gpu_keys(got) == want and len(want) >= 20
+
+
 def test_pipelined_polling_delivers_everything_once(built, oracle):
     """vdl2gpu_poll_ready (non-blocking) + a final vdl2gpu_poll: two pushes in flight, every burst
     handed out exactly once, in stream-time order per poll."""

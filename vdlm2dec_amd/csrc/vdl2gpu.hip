@@ -96,6 +96,7 @@ struct vdl2gpu {
 	int *d_seeds = nullptr;
 	int full_scan = 0;
 	unsigned stage_cap = 0;
+	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
 	int force_serial = 0;
 	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
 	int n_cu = 256;
@@ -518,6 +519,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	if (getenv("VDL2GPU_STAGE_EVERY"))
 		h->stage_every = std::max(1, atoi(getenv("VDL2GPU_STAGE_EVERY")));
+	if (getenv("VDL2GPU_PRIM_DROP"))
+		h->prim_drop = atoi(getenv("VDL2GPU_PRIM_DROP"));
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
 		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
@@ -1065,6 +1068,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		 * than through the scan's ten launches: the parallel path only pays from a few thousand frames on. */
 		const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !(h->cfg.flags & VDL2GPU_F_TEST_NOREGION));
 		k2.force_serial = serial ? 1 : 0;
+		k2.prim_drop = h->prim_drop;
 		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
 		k2.full_scan = h->full_scan;
 		k2.test_noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) ? 1 : 0;

@@ -57,6 +57,8 @@ void k2s_sort(K2Params p)
 				break;
 			}
 		}
+		if (p.prim_drop > 0 && j % p.prim_drop == p.prim_drop - 1)
+			primary = false;
 		int2 *head = p.clhead + (size_t)sc * VDL2_CAND_CAP + idx;
 		if (!primary)
 			*head = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
@@ -518,10 +520,12 @@ void k2c_resolve(K2Params p)
 			break;
 		}
 		if (status == CL_INVALID) {
-			/* staging pool was full: replay this stretch here */
+			/* staging pool was full: replay this stretch here, until the detector is history-free again
+			 * behind at least this one trigger (out counts the whole push's: one more than it holds now;
+			 * a plain 1 returned at once, without progress, when an earlier trigger had been counted) */
 			st.pos = ncand_t;
 			mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
-			const int rc = machine_run<K2_NT, false>(sh, cx, st, true, 1, 1 << 30, 1, out);
+			const int rc = machine_run<K2_NT, false>(sh, cx, st, true, out.ntrig + 1, 1 << 30, 1, out);
 			if (rc != MR_STEADY)
 				break;
 			continue;

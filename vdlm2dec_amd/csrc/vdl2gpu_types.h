@@ -139,6 +139,7 @@ struct K2Params {
 	unsigned *fmask;	/* [16] bit per (stream, channel slot) that K2f redid serially in this push */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
+	int prim_drop;		/* test handicap: every prim_drop-th candidate gets no precomputed cluster (the resolver builds it) */
 	int full_scan;		/* scan all four sub-phases everywhere (no regions / verify) */
 	int test_noregion;	/* test hook: skip the region scan so that K2a-verify must catch the misses */
 	int2 *regs;		/* [S*8][REG_CAP] (lo, count) stream-relative */
