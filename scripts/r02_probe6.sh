@@ -1,0 +1,12 @@
+#!/bin/bash
+# k1_fast ablations (superperiod layout): rebuild with -D switches on the box
+cd "$(dirname "$0")/.."
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-flush-denormals-to-zero -fPIC -shared -I include"
+cp vdlm2dec_amd/libvdl2gpu.so /tmp/keep.so
+while read -r v; do
+  /opt/rocm/bin/hipcc $F $v vdlm2dec_amd/csrc/vdl2gpu.hip -o vdlm2dec_amd/libvdl2gpu.so 2>/dev/null || echo build failed
+  python bench.py --no-cpu --no-ring --no-parity --steps 6 --warmup 2 2>/dev/null | tail -1 > /tmp/b.json
+  python -c "
+import json; d=json.load(open('/tmp/b.json')); print('variant [$v]', 'k1 live', round(d['roofline']['avg_launch_ms'],4), 'alone', round(d['roofline']['alone']['avg_launch_ms'],4), 'step', round(d['ms_per_step'],4))"
+done
+cp /tmp/keep.so vdlm2dec_amd/libvdl2gpu.so

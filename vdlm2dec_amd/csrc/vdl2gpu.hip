@@ -347,6 +347,25 @@ static size_t fmt_bytes(int fmt)
 
 extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 {
+#ifdef K1F_PROF
+	{
+		static unsigned raw[K1F_PROF_SLOTS][8];
+		(void)hipDeviceSynchronize();
+		if (hipMemcpyFromSymbol(raw, HIP_SYMBOL(k1f_prof), sizeof raw) == hipSuccess) {
+			double pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (int b = 0; b < K1F_PROF_SLOTS; ++b)
+				for (int i = 0; i < 8; ++i)
+					pf[i] += raw[b][i];
+			const char *nm[7] = {"prologue", "wait samples", "convert+park+issue", "barrier", "mix+divide", "store issue", "drain"};
+			if (pf[7] > 0) {
+				fprintf(stderr, "k1_fast phases, shader cycles per wavefront-iteration (%.0f wavefront-iterations in the last launch):", pf[7]);
+				for (int i = 0; i < 7; ++i)
+					fprintf(stderr, " %s %.0f;", nm[i], pf[i] / pf[7]);
+				fprintf(stderr, "\n");
+			}
+		}
+	}
+#endif
 	if (!h)
 		return;
 	(void)hipSetDevice(h->cfg.device);
@@ -920,7 +939,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			kp.d = (int)((a0 % 16) / h->sample_bytes);
 		}
 		const long long nsp = periods / 4;	/* superperiods of 4 periods = 336 outputs = 21 lines of the planes */
-		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && nsp >= 3 && !getenv("VDL2GPU_K1_PP");
+		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && nsp >= 3 && !getenv("VDL2GPU_K1_PP") &&
+				    (size_t)h->cap * VDL2_CS * sizeof(float2) < (1ull << 32);	/* k1_fast addresses a stream's planes with 32-bit offsets */
 		if (fast2m) {
 			/* 2 MS/s: the LO values of a window fit a lane's registers (lane = window x channel).  Whole superperiods in
 			 * the middle; the first one (carried partial window) and the tail on the general kernel */
@@ -932,20 +952,17 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
 			(void)hipEventRecord(pt.e[8], ks);
-			/* superperiods per workgroup: workgroups = roles * ceil(superperiods / pb) should fill a whole number of
-			 * rounds of the GPU's slots (2 wavefronts each, 4 or 5 wavefronts per SIMD at this kernel's register count) */
-			long long pb;
+			/* the grid is resident as a whole (or in `rounds` equal waves of workgroups): n_cu * 2 * K1F_WAVES_OF(fmt) workgroups of
+			 * two wavefronts fit; groups of 21 roles, a multiple of 8 groups (one XCD each, see k1_fast), every group
+			 * takes every ngrp-th superperiod */
+			long long ngrp;
 			{
-				const double work = (double)k1.per_n * K1F_ROLES * h->S;
-				const double slots = (double)h->n_cu * 2 * (getenv("VDL2GPU_K1F_OCC") ? atoi(getenv("VDL2GPU_K1F_OCC")) : 5);
-				const int pbt = getenv("VDL2GPU_K1F_PB") ? atoi(getenv("VDL2GPU_K1F_PB")) : K1F_PB;
-				double rounds = std::ceil(work / (slots * pbt));
-				if (rounds < 1)
-					rounds = 1;
-				pb = (long long)std::ceil(work / (slots * rounds));
-				pb = std::max<long long>(2, std::min<long long>(pb, 64));
+				const long long slots = (long long)h->n_cu * 2 * K1F_WAVES_OF(h->cfg.fmt);
+				const int rounds = getenv("VDL2GPU_K1F_ROUNDS") ? std::max(1, atoi(getenv("VDL2GPU_K1F_ROUNDS"))) : 1;
+				ngrp = slots * rounds / ((long long)K1F_ROLES * h->S) / 8 * 8;
+				ngrp = std::max<long long>(8, std::min<long long>(ngrp, (k1.per_n + 1) / 2 / 8 * 8));	/* at least two superperiods each */
+				ngrp = std::max<long long>(8, ngrp);
 			}
-			const long long ngrp = (((k1.per_n + pb - 1) / pb) + 7) / 8 * 8;	/* workgroup groups: a multiple of 8 (one XCD each, see k1_fast) */
 			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;

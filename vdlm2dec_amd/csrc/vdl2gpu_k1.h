@@ -605,15 +605,67 @@ __device__ __forceinline__ void k1_lds_issue8(v2f (&x)[8], const unsigned a)
 		     : "memory");
 }
 
+/* four consecutive float2 from LDS at byte offset OFS behind address a, requested and not waited for (the offset is an
+ * immediate: as part of the address the compiler keeps one register per block and copy of the slice) */
+template <int OFS> __device__ __forceinline__ void k1_lds_issue4(v2f (&x)[4], const unsigned a)
+{
+	asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\tds_read_b64 %2, %4 offset:%7\n\tds_read_b64 %3, %4 offset:%8"
+		     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+		     : "v"(a), "n"(OFS), "n"(OFS + 8), "n"(OFS + 16), "n"(OFS + 24)
+		     : "memory");
+}
+/* Four (three) samples with the LO values in VGPRs and two pairs of temporaries; no instruction reads what the one
+ * before it wrote (the packed operations' forwarding hazard), one s_nop where that cannot be arranged. */
+__device__ __forceinline__ void k1_cmac4_v(v2f &acc, const v2f (&x)[4], const v2f *w)
+{
+	v2f a0, b0, a1, b1;
+	asm volatile(
+		K1_A("%1", "%5", "%9") K1_B("%2", "%5", "%9")
+		K1_A("%3", "%6", "%10") K1_B("%4", "%6", "%10")
+		K1_T("%1", "%2")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%7", "%11")
+		K1_S("%3")
+		K1_B("%2", "%7", "%11")
+		K1_A("%3", "%8", "%12") K1_B("%4", "%8", "%12")
+		K1_T("%1", "%2")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		"s_nop 0\n\t"
+		K1_S("%3")
+		: "+v"(acc), "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1)
+		: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+}
+__device__ __forceinline__ void k1_cmac3_v(v2f &acc, const v2f (&x)[4], const v2f *w)
+{
+	v2f a0, b0, a1, b1;
+	asm volatile(
+		K1_A("%1", "%5", "%8") K1_B("%2", "%5", "%8")
+		K1_A("%3", "%6", "%9") K1_B("%4", "%6", "%9")
+		K1_T("%1", "%2")
+		K1_T("%3", "%4")
+		K1_S("%1")
+		K1_A("%1", "%7", "%10")
+		K1_S("%3")
+		K1_B("%2", "%7", "%10")
+		"s_nop 0\n\t"
+		K1_T("%1", "%2")
+		"s_nop 0\n\t"
+		K1_S("%1")
+		: "+v"(acc), "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1)
+		: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(w[0]), "v"(w[1]), "v"(w[2]));
+}
+
 #define K1F_THREADS 128		/* two wavefronts: channels 0-3 and 4-7 of the same 16 windows */
-#define K1F_PB 24		/* superperiods per workgroup */
+#define K1F_WAVES_OF(FMT_) ((FMT_) == VDL2GPU_FMT_CF32 ? 4 : 5)	/* wavefronts per SIMD the kernel is built for: 96 registers (cf32 holds its
+								 * raw samples in twice as many: 128, 4 wavefronts) */
 #ifndef K1F_DEPTH
-#define K1F_DEPTH 4		/* superperiods of raw samples in flight per wavefront (registers) */
+#define K1F_DEPTH 2		/* superperiods of raw samples in flight per wavefront (registers) */
 #endif
 #define K1F_PER_IN 8000		/* a SUPERPERIOD: 4 periods of the schedule = 336 outputs = 21 lines of 16 */
 #define K1F_PER_OUT 336
 #define K1F_ROLES 21
-#define K1F_SLICE 392		/* >= 16 windows x 24 samples (3 loads per thread cover 384) */
 
 /* raw samples as the wave's loads deliver them: one 32-bit register per sample (64 for cf32) */
 template <int FMT> struct K1Raw { typedef unsigned T; };
@@ -624,7 +676,7 @@ template <> struct K1Raw<VDL2GPU_FMT_CF32> { typedef unsigned T __attribute__((e
  * operations of a wave complete in issue order, so "at most as many outstanding as were issued after them".
  * The compiler, seeing loads in a loop with a conditional body, waits for everything (vmcnt(0)): every period
  * then costs a full memory round trip, store acknowledgement included, and the kernel is latency-bound. */
-template <int FMT> __device__ __forceinline__ void k1_raw_issue(typename K1Raw<FMT>::T &r, const unsigned voff, const char *sbase)
+template <int FMT, int OFS = 0> __device__ __forceinline__ void k1_raw_issue(typename K1Raw<FMT>::T &r, const unsigned voff, const char *sbase)
 {
 #ifdef K1F_LOAD_NT
 #define K1F_LD_MOD " nt"
@@ -632,11 +684,11 @@ template <int FMT> __device__ __forceinline__ void k1_raw_issue(typename K1Raw<F
 #define K1F_LD_MOD ""
 #endif
 	if constexpr (FMT == VDL2GPU_FMT_CU8)
-		asm volatile("global_load_ushort %0, %1, %2" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+		asm volatile("global_load_ushort %0, %1, %2 offset:%3" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFS) : "memory");
 	else if constexpr (FMT == VDL2GPU_FMT_CF32)
-		asm volatile("global_load_dwordx2 %0, %1, %2" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+		asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFS) : "memory");
 	else
-		asm volatile("global_load_dword %0, %1, %2" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+		asm volatile("global_load_dword %0, %1, %2 offset:%3" K1F_LD_MOD : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFS) : "memory");
 }
 
 template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<FMT>::T v)
@@ -652,22 +704,34 @@ template <int FMT> __device__ __forceinline__ float2 k1_raw_cvt(typename K1Raw<F
 	}
 }
 
-/* one global_store_dwordx2 that is always ISSUED (the waits count it), with only the `on` lanes enabled */
-__device__ __forceinline__ void k1_store_masked(float2 *dst, v2f v, bool on)
+/* one global_store_dwordx2 that is always ISSUED (the waits count it), with only the `on` lanes enabled; the address is
+ * a workgroup-uniform base (scalar registers) plus the lane's 32-bit byte offset */
+__device__ __forceinline__ void k1_store_masked(const float2 *sbase, unsigned voff, v2f v, bool on)
 {
 	const unsigned long long m = __ballot(on);
 	asm volatile("s_mov_b64 s[2:3], exec\n\t"
-		     "s_mov_b64 exec, %2\n\t"
-		     "global_store_dwordx2 %0, %1, off\n\t"
+		     "s_mov_b64 exec, %3\n\t"
+		     "global_store_dwordx2 %0, %1, %2\n\t"
 		     "s_mov_b64 exec, s[2:3]"
-		     :: "v"(dst), "v"(v), "s"(m) : "memory", "s2", "s3");
+		     :: "v"(voff), "v"(v), "s"(sbase), "s"(m) : "memory", "s2", "s3");
 }
 
-template <int FMT> __global__ __launch_bounds__(K1F_THREADS, 4)
+#ifdef K1F_PROF
+#define K1F_PROF_SLOTS 32768
+__device__ unsigned k1f_prof[K1F_PROF_SLOTS][8];	/* development: shader cycles a wavefront spends in each phase (last launch) */
+#define K1F_STAMP(I_) do { const unsigned t_ = (unsigned)__builtin_amdgcn_readfirstlane((int)clock64()); pf[I_] += t_ - tl; tl = t_; } while (0)
+#else
+#define K1F_STAMP(I_) do { } while (0)
+#endif
+template <int FMT> __global__ __launch_bounds__(K1F_THREADS, K1F_WAVES_OF(FMT))
 void k1_fast(K1Params p)
 {
 	typedef typename K1Raw<FMT>::T raw_t;
 	constexpr int B = (FMT == VDL2GPU_FMT_CU8) ? 2 : (FMT == VDL2GPU_FMT_CF32) ? 8 : 4;
+#ifdef K1F_PROF
+	unsigned pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane((int)clock64());
+#endif
 	/* LDS: every window has its own row of 25 float2 (24 samples + 1 of padding: rows of 50 dwords put the 8 windows of
 	 * a half-wave read on 8 different bank pairs; laid end to end, windows 4 apart -- 95 or 96 samples -- shared banks),
 	 * two copies used in turn (one barrier per iteration) */
@@ -684,7 +748,14 @@ void k1_fast(K1Params p)
 	 * traffic moved in 128 us instead of 86, scripts/micro/store_shape.hip.)
 	 * Workgroup group w handles superperiods per_lo + w, + w + NW, + w + 2 NW, ..: at every iteration the grid reads
 	 * one contiguous band of NW superperiods and writes one contiguous band of each plane.  Workgroup b runs on XCD
-	 * b % 8: b = (group_hi * 21 + role) * 8 + group_lo keeps a group's roles -- neighbouring lines -- on one L2. */
+	 * b % 8: b = (group_hi * 21 + role) * 8 + group_lo keeps a group's roles -- neighbouring lines -- on one L2.
+	 *
+	 * The kernel is built around what a SIMD needs to stay busy: one wavefront issues a packed operation every 9 cycles
+	 * at best, four of them together one every 3.5 (scripts/micro/clock_rate.hip) -- three to four wavefronts per SIMD
+	 * must be mixing at any time.  Hence 96 registers (5 wavefronts per SIMD: the 24 LO values of the lane's window take
+	 * 48 of them, samples come from LDS four at a time), and a grid that is resident as a whole (the launch sizes it;
+	 * a workgroup's start-up -- window table, LO values, first samples: three memory round trips -- is paid once
+	 * per ~70 iterations instead of once per 23). */
 	const long long nw = (long long)(gridDim.x / K1F_ROLES);	/* a multiple of 8, see the launch */
 	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
 	const long long wgrp = (long long)(blockIdx.x / (8 * K1F_ROLES)) * 8 + (blockIdx.x & 7);
@@ -696,33 +767,20 @@ void k1_fast(K1Params p)
 	const int kk = lane >> 2, c = wv * 4 + (lane & 3);
 	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
-	const long long fill = p.ss[s].dec_fill;
-	/* slice of this workgroup in superperiod pp0: from the first sample of window 16g to the last of window 16g+15 */
-	const long long j0 = pp0 * K1F_PER_OUT + g * 16;
-	const long long sbase = k1_win_end(j0 - 1, p.sdrclk, p.c0) + 1;
+	/* The schedule repeats exactly every superperiod (336 * SDRCLK = 21 * 8000): window jr of ANY superperiod ends
+	 * e(jr) samples behind the superperiod's nominal start pp * 8000, e(jr) = ceil(((jr + 1) * 500 - c0) / 21) - 1
+	 * (k1_win_end with the superperiod's 168000 taken out; 21 * 32 keeps the division's numerator positive).
+	 * The slice of this workgroup: from the first sample of window 16g to the last of window 16g + 15. */
+	auto e_rel = [&](int jr) { return ((jr + 1) * p.sdrclk - p.c0 + 20 + 21 * 32) / 21 - 32 - 1; };
+	const int e0 = e_rel(g * 16 - 1);
 	if (tid <= 16)
-		wstart[tid] = (int)(k1_win_end(j0 + tid - 1, p.sdrclk, p.c0) + 1 - sbase);	/* [16] = the slice's length */
+		wstart[tid] = e_rel(g * 16 + tid - 1) - e0;	/* [16] = the slice's length */
 	__syncthreads();
 	const int slen = wstart[16];
 	const int off = wstart[kk], nwin = wstart[kk + 1] - wstart[kk];
-	v2f w[24];
-	{
-		int ph = (int)((p.no0 + sbase + off) % 80);
-		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + (active ? c : 0)) * 80;
-#pragma unroll
-		for (int t = 0; t < 24; ++t) {
-			const float2 q = lo[ph];
-			w[t] = (v2f){q.x, q.y};
-			ph = (ph + 1 == 80) ? 0 : ph + 1;
-		}
-	}
-	const float fn = (float)nwin;
-	const float rfn = 1.0f / fn;	/* RN(1/nf) for the exact FMA division below */
-	float2 *dec = p.dec + ((size_t)s * VDL2_CS + (active ? c : 0)) * p.cap + fill + pp0 * K1F_PER_OUT + g * 16 + kk;
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* from here on the only memory operations are the counted ones below */
 	/* threads fetch samples tid, tid+128, tid+256 of the slice (clamped: the tail re-reads the last sample) and park
 	 * each in the row of the window it belongs to */
-	unsigned vo[3];
+	unsigned vo[3];	/* [1] = [0] + 128 B is never clamped: the loads use [0] with an immediate offset */
 	int xd[3];
 #pragma unroll
 	for (int u = 0; u < 3; ++u) {
@@ -735,14 +793,37 @@ void k1_fast(K1Params p)
 			k += (i >= wstart[m]) ? 1 : 0;
 		xd[u] = k * 25 + (i - wstart[k]);
 	}
-	const char *rbase = raw + sbase * B;		/* the slice in superperiod pp0; workgroup-uniform */
+	const char *rbase = raw + (pp0 * K1F_PER_IN + e0 + 1) * B;	/* the slice in superperiod pp0; workgroup-uniform */
 	const long long pbytes = pstride * B;
 	raw_t rr[K1F_DEPTH][3];
 #pragma unroll
-	for (int d = 0; d < K1F_DEPTH; ++d)
+	for (int d = 0; d < K1F_DEPTH; ++d) {
+		const char *rb = rbase + pbytes * (d < np ? d : np - 1);
+		k1_raw_issue<FMT>(rr[d][0], vo[0], rb);
+		k1_raw_issue<FMT, K1F_THREADS * B>(rr[d][1], vo[0], rb);
+		k1_raw_issue<FMT>(rr[d][2], vo[2], rb);
+	}
+	/* the lane's LO values, behind the first samples' loads (one round trip for both) */
+	v2f w[24];
+	{
+		int ph = (p.no0 + e0 + 1 + off + 80) % 80;	/* 8000 = 100 LO periods: the same in every superperiod; e0 + 1 >= -23 */
+		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + (active ? c : 0)) * 80;
 #pragma unroll
-		for (int u = 0; u < 3; ++u)
-			k1_raw_issue<FMT>(rr[d][u], vo[u], rbase + pbytes * (d < np ? d : np - 1));
+		for (int t = 0; t < 24; ++t) {
+			const float2 q = lo[ph];
+			w[t] = (v2f){q.x, q.y};
+			ph = (ph + 1 == 80) ? 0 : ph + 1;
+		}
+	}
+	const float fn = (float)nwin;
+	const float rfn = 1.0f / fn;	/* RN(1/nf) for the exact FMA division below */
+	const float2 *dec = p.dec + (size_t)s * VDL2_CS * p.cap + p.ss[s].dec_fill + pp0 * K1F_PER_OUT + g * 16;	/* workgroup-uniform */
+	const unsigned dvo = (unsigned)(((size_t)(active ? c : 0) * p.cap + kk) * sizeof(float2));	/* planes are < 4 GB apart */
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* from here on the only memory operations are the counted ones below */
+#pragma unroll
+	for (int t = 0; t < 24; ++t)
+		asm volatile("" : "+v"(w[t]));	/* loaded in front of the loop, once */
+	K1F_STAMP(0);	/* prologue */
 	for (int q0 = 0; q0 < np; q0 += K1F_DEPTH) {
 #pragma unroll
 		for (int d = 0; d < K1F_DEPTH; ++d) {
@@ -750,16 +831,14 @@ void k1_fast(K1Params p)
 			if (q < np) {
 				/* superperiod q: registers -> float -> LDS slice, then refill the registers with superperiod q+DEPTH so
 				 * that DEPTH of them stay in flight.  Every iteration issues exactly 3 loads and 1 store per wavefront:
-				 * 4 D - 3 operations have been issued after the loads of iteration q in the steady state, 3 D - 3 + q
-				 * in the first round (the stricter 3 D - 3 serves all of it). */
+				 * 4 D - 3 operations have been issued after the loads of iteration q in the steady state (fewer in the
+				 * first round, whose loads the wait in front of the loop has seen land). */
 #if defined(K1F_NOLOAD) || defined(K1F_NOSTORE)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-				if (q0 == 0)
-					asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * K1F_DEPTH - 3) : "memory");
-				else
-					asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * K1F_DEPTH - 3) : "memory");
+				asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * K1F_DEPTH - 3) : "memory");
 #endif
+				K1F_STAMP(1);	/* wait for the samples */
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
 					asm volatile("" : "+v"(rr[d][u]));	/* read only behind the wait */
@@ -769,11 +848,16 @@ void k1_fast(K1Params p)
 					xb[xd[u]] = k1_raw_cvt<FMT>(rr[d][u]);
 				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
 #ifndef K1F_NOLOAD
-#pragma unroll
-				for (int u = 0; u < 3; ++u)
-					k1_raw_issue<FMT>(rr[d][u], vo[u], rbase + pbytes * qn);
+				{
+					const char *rb = rbase + pbytes * qn;
+					k1_raw_issue<FMT>(rr[d][0], vo[0], rb);
+					k1_raw_issue<FMT, K1F_THREADS * B>(rr[d][1], vo[0], rb);
+					k1_raw_issue<FMT>(rr[d][2], vo[2], rb);
+				}
 #endif
+				K1F_STAMP(2);	/* convert, park, issue the next loads */
 				__syncthreads();	/* the slice is written */
+				K1F_STAMP(3);	/* barrier */
 				v2f res = {0.0f, 0.0f};
 #ifdef K1F_NOMIX
 				if (p.nbch > 8) {
@@ -793,23 +877,31 @@ void k1_fast(K1Params p)
 							acc += (v2f){x, x} * w[23];
 						}
 					} else {
-						/* three blocks of 8 samples; every block is mixed while the next one's samples are on their way
-						 * from LDS (reads return in order: at most 8 outstanding = the previous block is there) */
+						/* six blocks of 4 samples; every block is mixed while the next one's samples are on their way
+						 * from LDS (reads return in order: at most 4 outstanding = the previous block is there) */
 						const unsigned xa = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xb[kk * 25];
-						v2f x0[8], x1[8];
+						v2f x0[4], x1[4];
 						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						k1_lds_issue8(x0, xa);
-						k1_lds_issue8(x1, xa + 64u);
-						asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-						k1_cmac8_v(acc, x0, &w[0]);
-						v2f x2[8];
-						k1_lds_issue8(x2, xa + 128u);
-						asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-						k1_cmac8_v(acc, x1, &w[8]);
+						k1_lds_issue4<0>(x0, xa);
+						k1_lds_issue4<32>(x1, xa);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x0, &w[0]);
+						k1_lds_issue4<64>(x0, xa);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x1, &w[4]);
+						k1_lds_issue4<96>(x1, xa);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x0, &w[8]);
+						k1_lds_issue4<128>(x0, xa);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x1, &w[12]);
+						k1_lds_issue4<160>(x1, xa);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x0, &w[16]);
 						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						k1_cmac7_v(acc, x2, &w[16]);
+						k1_cmac3_v(acc, x1, &w[20]);
 						if (nwin == 24)
-							k1_cmac1_v(acc, x2[7], w[23]);
+							k1_cmac1_v(acc, x1[3], w[23]);
 					}
 					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
 					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
@@ -824,21 +916,30 @@ void k1_fast(K1Params p)
 						res.y = acc.y / fn;
 					}
 				}
+				K1F_STAMP(4);	/* mix + divide */
 				/* exactly one store instruction per iteration and wavefront: four whole lines (channels beyond nbch
 				 * masked off; a wavefront without any channel still issues it, with no lane enabled, so that the
 				 * count above holds) */
 				{
-					float2 *dst = dec + (long long)q * K1F_PER_OUT * nw;
 #ifndef K1F_NOSTORE
-					k1_store_masked(dst, res, active);
+					k1_store_masked(dec + (long long)q * K1F_PER_OUT * nw, dvo, res, active);
 #endif
 				}
+				K1F_STAMP(5);	/* store issue */
 				/* no second barrier: the next iteration writes the other copy, and the one after that writes this one only
 				 * behind the next iteration's barrier, which every wave reaches after its reads here */
 			}
 		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef K1F_PROF
+	K1F_STAMP(6);	/* drain */
+	if (lane == 0 && blockIdx.y == 0 && blockIdx.x * 2 + wv < K1F_PROF_SLOTS) {
+		for (int i = 0; i < 7; ++i)
+			k1f_prof[blockIdx.x * 2 + wv][i] = pf[i];
+		k1f_prof[blockIdx.x * 2 + wv][7] = (unsigned)np;
+	}
+#endif
 }
 
 #endif
