@@ -349,19 +349,63 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 {
 #ifdef K1F_PROF
 	{
-		static unsigned raw[K1F_PROF_SLOTS][8];
+		static unsigned raw[K1F_PROF_SLOTS][12];
 		(void)hipDeviceSynchronize();
 		if (hipMemcpyFromSymbol(raw, HIP_SYMBOL(k1f_prof), sizeof raw) == hipSuccess) {
-			double pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			for (int b = 0; b < K1F_PROF_SLOTS; ++b)
-				for (int i = 0; i < 8; ++i)
+			double pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			unsigned first = 0xffffffffu, last_start = 0, last_end = 0;
+			int nwaves = 0;
+			for (int b = 0; b < K1F_PROF_SLOTS; ++b) {
+				if (!raw[b][7])
+					continue;
+				++nwaves;
+				for (int i = 0; i < 9; ++i)
 					pf[i] += raw[b][i];
+				first = std::min(first, raw[b][9]);
+				last_start = std::max(last_start, raw[b][9]);
+				last_end = std::max(last_end, raw[b][9] + raw[b][8]);
+			}
 			const char *nm[7] = {"prologue", "wait samples", "convert+park+issue", "barrier", "mix+divide", "store issue", "drain"};
 			if (pf[7] > 0) {
-				fprintf(stderr, "k1_fast phases, shader cycles per wavefront-iteration (%.0f wavefront-iterations in the last launch):", pf[7]);
+				double cyc = 0;
+				for (int i = 0; i < 7; ++i)
+					cyc += pf[i];
+				fprintf(stderr, "k1_fast phases, shader cycles per wavefront-iteration (%.0f wavefront-iterations, %d wavefronts in the last launch):", pf[7], nwaves);
 				for (int i = 0; i < 7; ++i)
 					fprintf(stderr, " %s %.0f;", nm[i], pf[i] / pf[7]);
-				fprintf(stderr, "\n");
+				{
+					double a = 0, b = 0;
+					for (int bb = 0; bb < K1F_PROF_SLOTS; ++bb)
+						if (raw[bb][7]) {
+							a += raw[bb][10];
+							b += raw[bb][11];
+						}
+					cyc += a + b;
+					fprintf(stderr, " [prologue per wavefront: window table %.0f, addresses + first loads %.0f, LO values + wait %.0f]", a / nwaves, b / nwaves, pf[0] / nwaves);
+				}
+				fprintf(stderr, " shader clock %.0f MHz; a wavefront lives %.1f us; first start to last start %.1f us, to last end %.1f us\n",
+					cyc / (pf[8] / 100.0), pf[8] / nwaves / 100.0, (last_start - first) / 100.0, (last_end - first) / 100.0);
+				std::vector<unsigned> life;
+				double by_xcd[8] = {0}, by_role[K1F_ROLES] = {0}, by_wv[2] = {0};
+				int n_xcd[8] = {0}, n_role[K1F_ROLES] = {0}, n_wv[2] = {0};
+				for (int b = 0; b < K1F_PROF_SLOTS; ++b) {
+					if (!raw[b][7])
+						continue;
+					life.push_back(raw[b][8]);
+					const int blk = b / 2;
+					by_xcd[blk & 7] += raw[b][8]; ++n_xcd[blk & 7];
+					by_role[(blk >> 3) % K1F_ROLES] += raw[b][8]; ++n_role[(blk >> 3) % K1F_ROLES];
+					by_wv[b & 1] += raw[b][8]; ++n_wv[b & 1];
+				}
+				std::sort(life.begin(), life.end());
+				fprintf(stderr, "   lifetime us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n   by XCD:", life[0] / 100.0, life[life.size() / 10] / 100.0,
+					life[life.size() / 2] / 100.0, life[life.size() * 9 / 10] / 100.0, life[life.size() * 99 / 100] / 100.0, life.back() / 100.0);
+				for (int i = 0; i < 8; ++i)
+					fprintf(stderr, " %.1f", by_xcd[i] / std::max(1, n_xcd[i]) / 100.0);
+				fprintf(stderr, "\n   by role:");
+				for (int i = 0; i < K1F_ROLES; ++i)
+					fprintf(stderr, " %.1f", by_role[i] / std::max(1, n_role[i]) / 100.0);
+				fprintf(stderr, "\n   by wavefront of the workgroup: %.1f %.1f\n", by_wv[0] / std::max(1, n_wv[0]) / 100.0, by_wv[1] / std::max(1, n_wv[1]) / 100.0);
 			}
 		}
 	}
@@ -949,6 +993,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			pt.fast = true;
 			k1.per_lo = 1;
 			k1.per_n = nsp - 2;
+			k1.lo_ext = h->d_lo_ext;
+			k1.lo_stride = h->L + 48;
 			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
 			(void)hipEventRecord(pt.e[8], ks);
@@ -963,6 +1009,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				ngrp = std::max<long long>(8, std::min<long long>(ngrp, (k1.per_n + 1) / 2 / 8 * 8));	/* at least two superperiods each */
 				ngrp = std::max<long long>(8, ngrp);
 			}
+			k1.per_q = (int)(k1.per_n / ngrp);
+			k1.per_r = (int)(k1.per_n % ngrp);
 			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;

@@ -718,7 +718,7 @@ __device__ __forceinline__ void k1_store_masked(const float2 *sbase, unsigned vo
 
 #ifdef K1F_PROF
 #define K1F_PROF_SLOTS 32768
-__device__ unsigned k1f_prof[K1F_PROF_SLOTS][8];	/* development: shader cycles a wavefront spends in each phase (last launch) */
+__device__ unsigned k1f_prof[K1F_PROF_SLOTS][12];	/* development: shader cycles a wavefront spends in each phase (last launch) */
 #define K1F_STAMP(I_) do { const unsigned t_ = (unsigned)__builtin_amdgcn_readfirstlane((int)clock64()); pf[I_] += t_ - tl; tl = t_; } while (0)
 #else
 #define K1F_STAMP(I_) do { } while (0)
@@ -729,14 +729,14 @@ void k1_fast(K1Params p)
 	typedef typename K1Raw<FMT>::T raw_t;
 	constexpr int B = (FMT == VDL2GPU_FMT_CU8) ? 2 : (FMT == VDL2GPU_FMT_CF32) ? 8 : 4;
 #ifdef K1F_PROF
-	unsigned pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane((int)clock64());
+	const unsigned wall0 = (unsigned)__builtin_amdgcn_readfirstlane((int)wall_clock64());
 #endif
 	/* LDS: every window has its own row of 25 float2 (24 samples + 1 of padding: rows of 50 dwords put the 8 windows of
 	 * a half-wave read on 8 different bank pairs; laid end to end, windows 4 apart -- 95 or 96 samples -- shared banks),
 	 * two copies used in turn (one barrier per iteration) */
 	__shared__ float2 xs[2][16 * 25 + 8];
-	__shared__ int wstart[17];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int s = blockIdx.y;
@@ -756,42 +756,44 @@ void k1_fast(K1Params p)
 	 * 48 of them, samples come from LDS four at a time), and a grid that is resident as a whole (the launch sizes it;
 	 * a workgroup's start-up -- window table, LO values, first samples: three memory round trips -- is paid once
 	 * per ~70 iterations instead of once per 23). */
-	const long long nw = (long long)(gridDim.x / K1F_ROLES);	/* a multiple of 8, see the launch */
+	const int nw = (int)(gridDim.x / K1F_ROLES);	/* groups: a multiple of 8, see the launch */
 	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
-	const long long wgrp = (long long)(blockIdx.x / (8 * K1F_ROLES)) * 8 + (blockIdx.x & 7);
+	const int wgrp = (int)(blockIdx.x / (8 * K1F_ROLES)) * 8 + (int)(blockIdx.x & 7);
 	const long long pp0 = p.per_lo + wgrp;
-	if (wgrp >= p.per_n)
+	const int np = p.per_q + (wgrp < p.per_r ? 1 : 0);	/* superperiods pp0 + q*nw, q < np */
+	if (np <= 0)
 		return;
-	const int np = (int)((p.per_n - wgrp + nw - 1) / nw);	/* superperiods pp0 + q*nw, q < np */
 	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this workgroup's superperiods */
 	const int kk = lane >> 2, c = wv * 4 + (lane & 3);
 	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
 	/* The schedule repeats exactly every superperiod (336 * SDRCLK = 21 * 8000): window jr of ANY superperiod ends
 	 * e(jr) samples behind the superperiod's nominal start pp * 8000, e(jr) = ceil(((jr + 1) * 500 - c0) / 21) - 1
-	 * (k1_win_end with the superperiod's 168000 taken out; 21 * 32 keeps the division's numerator positive).
+	 * (k1_win_end with the superperiod's 168000 taken out; 21 * 32 keeps the division's numerator positive), and the
+	 * sample at `rel` belongs to window ceil((21 (rel + 1) + c0 - 20) / 500) - 1.  Everything in front of the loop is
+	 * 32-bit arithmetic on these two, no table and no barrier: every instruction here is executed exactly once and
+	 * fetched cold (~330 cycles per 64-byte line of code), so this part is written for size.
 	 * The slice of this workgroup: from the first sample of window 16g to the last of window 16g + 15. */
-	auto e_rel = [&](int jr) { return ((jr + 1) * p.sdrclk - p.c0 + 20 + 21 * 32) / 21 - 32 - 1; };
+	const int c0 = p.c0;
+	auto e_rel = [c0](int jr) { return ((jr + 1) * 500 - c0 + 20 + 21 * 32) / 21 - 32 - 1; };
 	const int e0 = e_rel(g * 16 - 1);
-	if (tid <= 16)
-		wstart[tid] = e_rel(g * 16 + tid - 1) - e0;	/* [16] = the slice's length */
-	__syncthreads();
-	const int slen = wstart[16];
-	const int off = wstart[kk], nwin = wstart[kk + 1] - wstart[kk];
+	const int slen = e_rel(g * 16 + 15) - e0;
+	const int ek = e_rel(g * 16 + kk - 1);
+	const int off = ek - e0, nwin = e_rel(g * 16 + kk) - ek;
 	/* threads fetch samples tid, tid+128, tid+256 of the slice (clamped: the tail re-reads the last sample) and park
 	 * each in the row of the window it belongs to */
 	unsigned vo[3];	/* [1] = [0] + 128 B is never clamped: the loads use [0] with an immediate offset */
 	int xd[3];
-#pragma unroll
+#pragma unroll 1
 	for (int u = 0; u < 3; ++u) {
 		int i = tid + u * K1F_THREADS;
 		i = i < slen ? i : slen - 1;
-		vo[u] = (unsigned)i * B;
-		int k = 0;
-#pragma unroll
-		for (int m = 1; m < 16; ++m)
-			k += (i >= wstart[m]) ? 1 : 0;
-		xd[u] = k * 25 + (i - wstart[k]);
+		const int rel = e0 + 1 + i;
+		const int jr = (21 * (rel + 1) + c0 - 20 + 499) / 500 - 1;	/* numerator > 0 for every sample of the slice */
+		const int x = (jr - g * 16) * 25 + (rel - e_rel(jr - 1) - 1);
+		if (u == 0) { vo[0] = (unsigned)i * B; xd[0] = x; }
+		else if (u == 1) { vo[1] = (unsigned)i * B; xd[1] = x; }
+		else { vo[2] = (unsigned)i * B; xd[2] = x; }
 	}
 	const char *rbase = raw + (pp0 * K1F_PER_IN + e0 + 1) * B;	/* the slice in superperiod pp0; workgroup-uniform */
 	const long long pbytes = pstride * B;
@@ -803,16 +805,17 @@ void k1_fast(K1Params p)
 		k1_raw_issue<FMT, K1F_THREADS * B>(rr[d][1], vo[0], rb);
 		k1_raw_issue<FMT>(rr[d][2], vo[2], rb);
 	}
-	/* the lane's LO values, behind the first samples' loads (one round trip for both) */
+	K1F_STAMP(8);	/* prologue: addresses, first loads issued */
+	/* the lane's LO values, behind the first samples' loads (one round trip for both); the table carries its own
+	 * wrap-around (24 loads off one address) */
 	v2f w[24];
 	{
-		int ph = (p.no0 + e0 + 1 + off + 80) % 80;	/* 8000 = 100 LO periods: the same in every superperiod; e0 + 1 >= -23 */
-		const float2 *lo = p.lo + ((size_t)s * VDL2_CS + (active ? c : 0)) * 80;
+		const int ph = (p.no0 + e0 + 1 + off + 80) % 80;	/* 8000 = 100 LO periods: the same in every superperiod; e0 + 1 >= -23 */
+		const float2 *lo = p.lo_ext + ((size_t)s * VDL2_CS + (active ? c : 0)) * p.lo_stride + 8 + ph;
 #pragma unroll
 		for (int t = 0; t < 24; ++t) {
-			const float2 q = lo[ph];
+			const float2 q = lo[t];
 			w[t] = (v2f){q.x, q.y};
-			ph = (ph + 1 == 80) ? 0 : ph + 1;
 		}
 	}
 	const float fn = (float)nwin;
@@ -833,6 +836,17 @@ void k1_fast(K1Params p)
 				 * that DEPTH of them stay in flight.  Every iteration issues exactly 3 loads and 1 store per wavefront:
 				 * 4 D - 3 operations have been issued after the loads of iteration q in the steady state (fewer in the
 				 * first round, whose loads the wait in front of the loop has seen land). */
+#ifndef K1F_NOPRIO
+				/* the SIMD's arbiter serves its oldest wavefront first: left alone, the five wavefronts of a SIMD finish
+				 * one after the other (56 .. 111 us), and the last ones mix alone at a third of the SIMD's rate.  Rotating
+				 * priorities make them advance together. */
+				switch ((q + (int)blockIdx.x) & 3) {
+				case 0: __builtin_amdgcn_s_setprio(0); break;
+				case 1: __builtin_amdgcn_s_setprio(1); break;
+				case 2: __builtin_amdgcn_s_setprio(2); break;
+				default: __builtin_amdgcn_s_setprio(3); break;
+				}
+#endif
 #if defined(K1F_NOLOAD) || defined(K1F_NOSTORE)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
@@ -938,6 +952,10 @@ void k1_fast(K1Params p)
 		for (int i = 0; i < 7; ++i)
 			k1f_prof[blockIdx.x * 2 + wv][i] = pf[i];
 		k1f_prof[blockIdx.x * 2 + wv][7] = (unsigned)np;
+		k1f_prof[blockIdx.x * 2 + wv][8] = (unsigned)wall_clock64() - wall0;	/* 100 MHz ticks of the wavefront's life */
+		k1f_prof[blockIdx.x * 2 + wv][9] = wall0;
+		k1f_prof[blockIdx.x * 2 + wv][10] = pf[7];
+		k1f_prof[blockIdx.x * 2 + wv][11] = pf[8];
 	}
 #endif
 }
