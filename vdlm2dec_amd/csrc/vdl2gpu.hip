@@ -67,6 +67,7 @@ struct vdl2gpu {
 	std::vector<hipEvent_t> ring_copied;
 	std::vector<char> ring_inflight;
 	float2 *d_lo = nullptr;
+	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
 	float2 *d_dec[2] = { nullptr, nullptr };
 	StreamState *d_ss = nullptr;
@@ -442,6 +443,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipStreamDestroy(h->in_stream);
 	(void)hipFree(h->d_lo);
 	(void)hipFree(h->d_lo_ext);
+	(void)hipFree(h->d_k1_tickets);
 	(void)hipFree(h->d_dec[0]);
 	(void)hipFree(h->d_dec[1]);
 	(void)hipFree(h->d_ss);
@@ -534,6 +536,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMemsetAsync(h->d_dec[0], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_lo_ext, (size_t)S * VDL2_CS * (L + 48) * sizeof(float2)));
+	HIPCHK(h, hipMalloc(&h->d_k1_tickets, (size_t)S * 21 * 8 * sizeof(unsigned)));
 	HIPCHK(h, hipMalloc(&h->d_ss, (size_t)S * sizeof(StreamState)));
 	HIPCHK(h, hipMalloc(&h->d_cs, (size_t)S * VDL2_CS * sizeof(ChanState)));
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
@@ -1009,8 +1012,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				ngrp = std::max<long long>(8, std::min<long long>(ngrp, (k1.per_n + 1) / 2 / 8 * 8));	/* at least two superperiods each */
 				ngrp = std::max<long long>(8, ngrp);
 			}
-			k1.per_q = (int)(k1.per_n / ngrp);
-			k1.per_r = (int)(k1.per_n % ngrp);
+			k1.tickets = h->d_k1_tickets;
+			HIPCHK(h, hipMemsetAsync(h->d_k1_tickets, 0, (size_t)h->S * K1F_ROLES * 8 * sizeof(unsigned), ks));
 			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;

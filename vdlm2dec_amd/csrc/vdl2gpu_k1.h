@@ -663,6 +663,7 @@ __device__ __forceinline__ void k1_cmac3_v(v2f &acc, const v2f (&x)[4], const v2
 #ifndef K1F_DEPTH
 #define K1F_DEPTH 2		/* superperiods of raw samples in flight per wavefront (registers) */
 #endif
+#define K1F_CHUNK 8		/* superperiods per ticket (even: the two LDS copies and register sets alternate) */
 #define K1F_PER_IN 8000		/* a SUPERPERIOD: 4 periods of the schedule = 336 outputs = 21 lines of 16 */
 #define K1F_PER_OUT 336
 #define K1F_ROLES 21
@@ -737,6 +738,7 @@ void k1_fast(K1Params p)
 	 * a half-wave read on 8 different bank pairs; laid end to end, windows 4 apart -- 95 or 96 samples -- shared banks),
 	 * two copies used in turn (one barrier per iteration) */
 	__shared__ float2 xs[2][16 * 25 + 8];
+	__shared__ int s_next;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int s = blockIdx.y;
@@ -756,14 +758,20 @@ void k1_fast(K1Params p)
 	 * 48 of them, samples come from LDS four at a time), and a grid that is resident as a whole (the launch sizes it;
 	 * a workgroup's start-up -- window table, LO values, first samples: three memory round trips -- is paid once
 	 * per ~70 iterations instead of once per 23). */
-	const int nw = (int)(gridDim.x / K1F_ROLES);	/* groups: a multiple of 8, see the launch */
+	/* Work is handed out in TICKETS of K1F_CHUNK superperiods.  Workgroup b runs on XCD x = b % 8 and has role
+	 * g = (b / 8) % 21; the workgroups of one (role, XCD) form a family that shares a counter and takes the superperiods
+	 * per_lo + x + 8 i, i = 0, 1, .. in chunks: ticket t = i in [t C, t C + C).  The first ticket of a workgroup is its
+	 * rank in the family, the next one comes from the counter while the current one is being worked on -- a workgroup on
+	 * a SIMD that advances slowly (more wavefronts, a busier CU, another kernel's wavefronts beside it) simply takes
+	 * fewer tickets.  With a fixed share each the launch lasted as long as its slowest SIMD: 104 us for wavefronts that
+	 * lived 88 us on average. */
+	const int x = (int)(blockIdx.x & 7);
 	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
-	const int wgrp = (int)(blockIdx.x / (8 * K1F_ROLES)) * 8 + (int)(blockIdx.x & 7);
-	const long long pp0 = p.per_lo + wgrp;
-	const int np = p.per_q + (wgrp < p.per_r ? 1 : 0);	/* superperiods pp0 + q*nw, q < np */
-	if (np <= 0)
+	const int rank = (int)(blockIdx.x / (8 * K1F_ROLES)), nfam = (int)(gridDim.x / (8 * K1F_ROLES));
+	const int n_x = ((int)p.per_n - x + 7) >> 3;			/* superperiods of this XCD */
+	if (rank * K1F_CHUNK >= n_x)
 		return;
-	const long long pstride = (long long)K1F_PER_IN * nw;	/* samples between this workgroup's superperiods */
+	const unsigned *ctr = p.tickets + ((size_t)s * K1F_ROLES + g) * 8 + x;	/* zeroed by the launch; ticket = nfam + old value */
 	const int kk = lane >> 2, c = wv * 4 + (lane & 3);
 	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
@@ -795,15 +803,22 @@ void k1_fast(K1Params p)
 		else if (u == 1) { vo[1] = (unsigned)i * B; xd[1] = x; }
 		else { vo[2] = (unsigned)i * B; xd[2] = x; }
 	}
-	const char *rbase = raw + (pp0 * K1F_PER_IN + e0 + 1) * B;	/* the slice in superperiod pp0; workgroup-uniform */
-	const long long pbytes = pstride * B;
+	/* iteration index i of the family = (ticket, position) = (i / C, i % C): superperiod per_lo + x + 8 i */
+	const char *rbase = raw + ((p.per_lo + x) * K1F_PER_IN + e0 + 1) * B;	/* the slice in the family's first superperiod; workgroup-uniform */
+	constexpr long long pbytes = (long long)K1F_PER_IN * B * 8;
+	int idx0 = rank * K1F_CHUNK;					/* this iteration, the next one (-1: none) */
+	int idx1 = idx0 + 1 < n_x ? idx0 + 1 : -1;
 	raw_t rr[K1F_DEPTH][3];
-#pragma unroll
-	for (int d = 0; d < K1F_DEPTH; ++d) {
-		const char *rb = rbase + pbytes * (d < np ? d : np - 1);
-		k1_raw_issue<FMT>(rr[d][0], vo[0], rb);
-		k1_raw_issue<FMT, K1F_THREADS * B>(rr[d][1], vo[0], rb);
-		k1_raw_issue<FMT>(rr[d][2], vo[2], rb);
+	static_assert(K1F_DEPTH == 2 && K1F_CHUNK % 2 == 0 && K1F_CHUNK >= 6, "the loop below is written for two register sets");
+	{
+		const char *rb = rbase + pbytes * idx0;
+		k1_raw_issue<FMT>(rr[0][0], vo[0], rb);
+		k1_raw_issue<FMT, K1F_THREADS * B>(rr[0][1], vo[0], rb);
+		k1_raw_issue<FMT>(rr[0][2], vo[2], rb);
+		rb = rbase + pbytes * (idx1 >= 0 ? idx1 : idx0);
+		k1_raw_issue<FMT>(rr[1][0], vo[0], rb);
+		k1_raw_issue<FMT, K1F_THREADS * B>(rr[1][1], vo[0], rb);
+		k1_raw_issue<FMT>(rr[1][2], vo[2], rb);
 	}
 	K1F_STAMP(8);	/* prologue: addresses, first loads issued */
 	/* the lane's LO values, behind the first samples' loads (one round trip for both); the table carries its own
@@ -820,57 +835,83 @@ void k1_fast(K1Params p)
 	}
 	const float fn = (float)nwin;
 	const float rfn = 1.0f / fn;	/* RN(1/nf) for the exact FMA division below */
-	const float2 *dec = p.dec + (size_t)s * VDL2_CS * p.cap + p.ss[s].dec_fill + pp0 * K1F_PER_OUT + g * 16;	/* workgroup-uniform */
+	const float2 *dec = p.dec + (size_t)s * VDL2_CS * p.cap + p.ss[s].dec_fill + (p.per_lo + x) * K1F_PER_OUT + g * 16;	/* workgroup-uniform */
 	const unsigned dvo = (unsigned)(((size_t)(active ? c : 0) * p.cap + kk) * sizeof(float2));	/* planes are < 4 GB apart */
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* from here on the only memory operations are the counted ones below */
 #pragma unroll
 	for (int t = 0; t < 24; ++t)
 		asm volatile("" : "+v"(w[t]));	/* loaded in front of the loop, once */
 	K1F_STAMP(0);	/* prologue */
-	for (int q0 = 0; q0 < np; q0 += K1F_DEPTH) {
+	const unsigned xa = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xs[0][kk * 25];
+	unsigned tkr = 0;	/* lane 0 of wavefront 0: the counter's answer, landing while the chunk is worked on */
+	int nxt = 0x7fffffff;
+	int pos = 0;	/* position in the current chunk */
+#ifdef K1F_PROF
+	int nit = 0;
+#endif
+	while (idx0 >= 0) {
 #pragma unroll
 		for (int d = 0; d < K1F_DEPTH; ++d) {
-			const int q = q0 + d;
-			if (q < np) {
-				/* superperiod q: registers -> float -> LDS slice, then refill the registers with superperiod q+DEPTH so
-				 * that DEPTH of them stay in flight.  Every iteration issues exactly 3 loads and 1 store per wavefront:
-				 * 4 D - 3 operations have been issued after the loads of iteration q in the steady state (fewer in the
-				 * first round, whose loads the wait in front of the loop has seen land). */
+			if (idx0 >= 0) {
+#ifdef K1F_PROF
+				++nit;
+#endif
+				/* iteration idx0: registers -> float -> LDS slice, then refill the registers with the superperiod
+				 * DEPTH iterations ahead so that DEPTH of them stay in flight.  Every iteration issues exactly 3 loads
+				 * and 1 store per wavefront: 4 D - 3 operations have been issued after the loads of this iteration (one
+				 * more where a ticket request is among them, fewer in the very first ones -- the wait is then stricter
+				 * than it has to be, never too loose). */
 #ifndef K1F_NOPRIO
-				/* the SIMD's arbiter serves its oldest wavefront first: left alone, the five wavefronts of a SIMD finish
-				 * one after the other (56 .. 111 us), and the last ones mix alone at a third of the SIMD's rate.  Rotating
-				 * priorities make them advance together. */
-				switch ((q + (int)blockIdx.x) & 3) {
+				/* the SIMD's arbiter serves its oldest wavefront first: left alone, the five wavefronts of a SIMD advance
+				 * at very different rates.  Rotating priorities keep them together. */
+				switch ((pos + (int)blockIdx.x) & 3) {
 				case 0: __builtin_amdgcn_s_setprio(0); break;
 				case 1: __builtin_amdgcn_s_setprio(1); break;
 				case 2: __builtin_amdgcn_s_setprio(2); break;
 				default: __builtin_amdgcn_s_setprio(3); break;
 				}
 #endif
-#if defined(K1F_NOLOAD) || defined(K1F_NOSTORE)
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
 				asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * K1F_DEPTH - 3) : "memory");
-#endif
 				K1F_STAMP(1);	/* wait for the samples */
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
 					asm volatile("" : "+v"(rr[d][u]));	/* read only behind the wait */
-				float2 *xb = xs[q & 1];
+				float2 *xb = xs[d & 1];	/* = ii & 1: chunks and DEPTH are even */
 #pragma unroll
 				for (int u = 0; u < 3; ++u)
 					xb[xd[u]] = k1_raw_cvt<FMT>(rr[d][u]);
-				const int qn = (q + K1F_DEPTH < np) ? q + K1F_DEPTH : np - 1;
-#ifndef K1F_NOLOAD
+				if (pos == 0) {
+					/* ask for the next ticket: older than every load issued from here on, so the waits below see it land */
+					const unsigned long long m = __ballot(tid == 0);
+					asm volatile("s_mov_b64 s[2:3], exec\n\t"
+						     "s_mov_b64 exec, %3\n\t"
+						     "global_atomic_add %0, %1, %2, %4 sc0\n\t"
+						     "s_mov_b64 exec, s[2:3]"
+						     : "+v"(tkr) : "v"(0u), "v"(1u), "s"(m), "s"(ctr) : "memory", "s2", "s3");
+				}
+				if (pos == K1F_DEPTH) {
+					/* the wait above was for loads issued after the request: it has landed */
+					asm volatile("" : "+v"(tkr));
+					if (tid == 0)
+						s_next = ((int)tkr + nfam) * K1F_CHUNK;
+				}
+				if (pos == K1F_CHUNK - K1F_DEPTH)
+					nxt = __builtin_amdgcn_readfirstlane(s_next);	/* first index of the next ticket; written K1F_CHUNK - 2 D barriers ago */
+				/* the iteration DEPTH ahead: in this chunk, in the next one, or none (the loads then fetch this one again) */
+				int idx2 = pos < K1F_CHUNK - K1F_DEPTH ? idx0 + K1F_DEPTH : nxt + (pos - (K1F_CHUNK - K1F_DEPTH));
+				idx2 = idx2 < n_x ? idx2 : -1;
 				{
-					const char *rb = rbase + pbytes * qn;
+					const char *rb = rbase + pbytes * (idx2 >= 0 ? idx2 : idx0);
+#ifndef K1F_NOLOAD
 					k1_raw_issue<FMT>(rr[d][0], vo[0], rb);
 					k1_raw_issue<FMT, K1F_THREADS * B>(rr[d][1], vo[0], rb);
 					k1_raw_issue<FMT>(rr[d][2], vo[2], rb);
-				}
 #endif
+				}
 				K1F_STAMP(2);	/* convert, park, issue the next loads */
+#ifndef K1F_NOBARRIER
 				__syncthreads();	/* the slice is written */
+#endif
 				K1F_STAMP(3);	/* barrier */
 				v2f res = {0.0f, 0.0f};
 #ifdef K1F_NOMIX
@@ -893,29 +934,36 @@ void k1_fast(K1Params p)
 					} else {
 						/* six blocks of 4 samples; every block is mixed while the next one's samples are on their way
 						 * from LDS (reads return in order: at most 4 outstanding = the previous block is there) */
-						const unsigned xa = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xb[kk * 25];
-						v2f x0[4], x1[4];
-						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						k1_lds_issue4<0>(x0, xa);
-						k1_lds_issue4<32>(x1, xa);
-						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-						k1_cmac4_v(acc, x0, &w[0]);
-						k1_lds_issue4<64>(x0, xa);
-						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-						k1_cmac4_v(acc, x1, &w[4]);
-						k1_lds_issue4<96>(x1, xa);
-						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-						k1_cmac4_v(acc, x0, &w[8]);
-						k1_lds_issue4<128>(x0, xa);
-						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-						k1_cmac4_v(acc, x1, &w[12]);
-						k1_lds_issue4<160>(x1, xa);
-						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-						k1_cmac4_v(acc, x0, &w[16]);
-						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						k1_cmac3_v(acc, x1, &w[20]);
-						if (nwin == 24)
-							k1_cmac1_v(acc, x1[3], w[23]);
+						/* (which copy of the slice is part of the reads' immediate offsets: one address register for both) */
+						auto mix = [&](auto par) {
+							constexpr int XO = (int)sizeof(xs[0]) * decltype(par)::value;
+							v2f x0[4], x1[4];
+							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+							k1_lds_issue4<0 + XO>(x0, xa);
+							k1_lds_issue4<32 + XO>(x1, xa);
+							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							k1_cmac4_v(acc, x0, &w[0]);
+							k1_lds_issue4<64 + XO>(x0, xa);
+							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							k1_cmac4_v(acc, x1, &w[4]);
+							k1_lds_issue4<96 + XO>(x1, xa);
+							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							k1_cmac4_v(acc, x0, &w[8]);
+							k1_lds_issue4<128 + XO>(x0, xa);
+							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							k1_cmac4_v(acc, x1, &w[12]);
+							k1_lds_issue4<160 + XO>(x1, xa);
+							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							k1_cmac4_v(acc, x0, &w[16]);
+							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+							k1_cmac3_v(acc, x1, &w[20]);
+							if (nwin == 24)
+								k1_cmac1_v(acc, x1[3], w[23]);
+						};
+						if (d & 1)
+							mix(std::integral_constant<int, 1>{});
+						else
+							mix(std::integral_constant<int, 0>{});
 					}
 					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
 					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
@@ -936,12 +984,15 @@ void k1_fast(K1Params p)
 				 * count above holds) */
 				{
 #ifndef K1F_NOSTORE
-					k1_store_masked(dec + (long long)q * K1F_PER_OUT * nw, dvo, res, active);
+					k1_store_masked(dec + (long long)idx0 * (8 * K1F_PER_OUT), dvo, res, active);
 #endif
 				}
 				K1F_STAMP(5);	/* store issue */
 				/* no second barrier: the next iteration writes the other copy, and the one after that writes this one only
 				 * behind the next iteration's barrier, which every wave reaches after its reads here */
+				idx0 = idx1;
+				idx1 = idx2;
+				pos = pos + 1 == K1F_CHUNK ? 0 : pos + 1;
 			}
 		}
 	}
@@ -951,7 +1002,7 @@ void k1_fast(K1Params p)
 	if (lane == 0 && blockIdx.y == 0 && blockIdx.x * 2 + wv < K1F_PROF_SLOTS) {
 		for (int i = 0; i < 7; ++i)
 			k1f_prof[blockIdx.x * 2 + wv][i] = pf[i];
-		k1f_prof[blockIdx.x * 2 + wv][7] = (unsigned)np;
+		k1f_prof[blockIdx.x * 2 + wv][7] = (unsigned)nit;
 		k1f_prof[blockIdx.x * 2 + wv][8] = (unsigned)wall_clock64() - wall0;	/* 100 MHz ticks of the wavefront's life */
 		k1f_prof[blockIdx.x * 2 + wv][9] = wall0;
 		k1f_prof[blockIdx.x * 2 + wv][10] = pf[7];
