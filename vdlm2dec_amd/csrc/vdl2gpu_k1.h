@@ -737,7 +737,7 @@ void k1_fast(K1Params p)
 	/* LDS: every window has its own row of 25 float2 (24 samples + 1 of padding: rows of 50 dwords put the 8 windows of
 	 * a half-wave read on 8 different bank pairs; laid end to end, windows 4 apart -- 95 or 96 samples -- shared banks),
 	 * two copies used in turn (one barrier per iteration) */
-	__shared__ float2 xs[2][16 * 25 + 8];
+	__shared__ float2 xs[2][2][16 * 25 + 8];	/* [copy][half of the pair] */
 	__shared__ int s_next;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
@@ -769,7 +769,7 @@ void k1_fast(K1Params p)
 	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
 	const int rank = (int)(blockIdx.x / (8 * K1F_ROLES)), nfam = (int)(gridDim.x / (8 * K1F_ROLES));
 	const int n_x = ((int)p.per_n - x + 7) >> 3;			/* superperiods of this XCD */
-	if (rank * K1F_CHUNK >= n_x)
+	if (rank * K1F_CHUNK >= n_x)	/* its first ticket is empty */
 		return;
 	const unsigned *ctr = p.tickets + ((size_t)s * K1F_ROLES + g) * 8 + x;	/* zeroed by the launch; ticket = nfam + old value */
 	const int kk = lane >> 2, c = wv * 4 + (lane & 3);
@@ -803,19 +803,23 @@ void k1_fast(K1Params p)
 		else if (u == 1) { vo[1] = (unsigned)i * B; xd[1] = x; }
 		else { vo[2] = (unsigned)i * B; xd[2] = x; }
 	}
-	/* iteration index i of the family = (ticket, position) = (i / C, i % C): superperiod per_lo + x + 8 i */
+	/* index i of the family: superperiod per_lo + x + 8 i.  An ITERATION takes a pair (2 p, 2 p + 1): two slices in
+	 * flight (one register set each), one wait, one barrier and one turn of the bookkeeping for two superperiods of
+	 * mixing -- with one superperiod per iteration a wavefront spent as long outside the mixer as in it, and a SIMD
+	 * needs three of its five mixing. */
+	constexpr int CP = K1F_CHUNK / 2;	/* pairs per ticket */
+	static_assert(K1F_DEPTH == 2 && K1F_CHUNK % 2 == 0 && CP >= 4, "the loop below is written for pairs and a ticket known at the fourth pair");
 	const char *rbase = raw + ((p.per_lo + x) * K1F_PER_IN + e0 + 1) * B;	/* the slice in the family's first superperiod; workgroup-uniform */
 	constexpr long long pbytes = (long long)K1F_PER_IN * B * 8;
-	int idx0 = rank * K1F_CHUNK;					/* this iteration, the next one (-1: none) */
-	int idx1 = idx0 + 1 < n_x ? idx0 + 1 : -1;
-	raw_t rr[K1F_DEPTH][3];
-	static_assert(K1F_DEPTH == 2 && K1F_CHUNK % 2 == 0 && K1F_CHUNK >= 6, "the loop below is written for two register sets");
+	int p0 = rank * CP;	/* this iteration's pair */
+	raw_t rr[2][3];
 	{
-		const char *rb = rbase + pbytes * idx0;
+		const int ia = 2 * p0, ib = ia + 1 < n_x ? ia + 1 : ia;
+		const char *rb = rbase + pbytes * ia;
 		k1_raw_issue<FMT>(rr[0][0], vo[0], rb);
 		k1_raw_issue<FMT, K1F_THREADS * B>(rr[0][1], vo[0], rb);
 		k1_raw_issue<FMT>(rr[0][2], vo[2], rb);
-		rb = rbase + pbytes * (idx1 >= 0 ? idx1 : idx0);
+		rb = rbase + pbytes * ib;
 		k1_raw_issue<FMT>(rr[1][0], vo[0], rb);
 		k1_raw_issue<FMT, K1F_THREADS * B>(rr[1][1], vo[0], rb);
 		k1_raw_issue<FMT>(rr[1][2], vo[2], rb);
@@ -842,159 +846,169 @@ void k1_fast(K1Params p)
 	for (int t = 0; t < 24; ++t)
 		asm volatile("" : "+v"(w[t]));	/* loaded in front of the loop, once */
 	K1F_STAMP(0);	/* prologue */
-	const unsigned xa = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xs[0][kk * 25];
+	const unsigned xa = (unsigned)(size_t)(__attribute__((address_space(3))) const float2 *)&xs[0][0][kk * 25];
 	unsigned tkr = 0;	/* lane 0 of wavefront 0: the counter's answer, landing while the chunk is worked on */
 	int nxt = 0x7fffffff;
 	int pos = 0;	/* position in the current chunk */
+	int buf = 0;	/* which copy of the slices this iteration writes and reads */
 #ifdef K1F_PROF
 	int nit = 0;
 #endif
-	while (idx0 >= 0) {
-#pragma unroll
-		for (int d = 0; d < K1F_DEPTH; ++d) {
-			if (idx0 >= 0) {
+	while (p0 >= 0) {
 #ifdef K1F_PROF
-				++nit;
+		nit += 2;
 #endif
-				/* iteration idx0: registers -> float -> LDS slice, then refill the registers with the superperiod
-				 * DEPTH iterations ahead so that DEPTH of them stay in flight.  Every iteration issues exactly 3 loads
-				 * and 1 store per wavefront: 4 D - 3 operations have been issued after the loads of this iteration (one
-				 * more where a ticket request is among them, fewer in the very first ones -- the wait is then stricter
-				 * than it has to be, never too loose). */
+		/* pair p0: registers -> float -> LDS slices, then refill the registers with the next pair.  Every iteration
+		 * issues exactly 6 loads and then 2 stores per wavefront: only the 2 stores have been issued after the loads
+		 * this iteration waits for (a ticket request is issued BEFORE an iteration's loads, so they see it land). */
 #ifndef K1F_NOPRIO
-				/* the SIMD's arbiter serves its oldest wavefront first: left alone, the five wavefronts of a SIMD advance
-				 * at very different rates.  Rotating priorities keep them together. */
-				switch ((pos + (int)blockIdx.x) & 3) {
-				case 0: __builtin_amdgcn_s_setprio(0); break;
-				case 1: __builtin_amdgcn_s_setprio(1); break;
-				case 2: __builtin_amdgcn_s_setprio(2); break;
-				default: __builtin_amdgcn_s_setprio(3); break;
-				}
-#endif
-				asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * K1F_DEPTH - 3) : "memory");
-				K1F_STAMP(1);	/* wait for the samples */
-#pragma unroll
-				for (int u = 0; u < 3; ++u)
-					asm volatile("" : "+v"(rr[d][u]));	/* read only behind the wait */
-				float2 *xb = xs[d & 1];	/* = ii & 1: chunks and DEPTH are even */
-#pragma unroll
-				for (int u = 0; u < 3; ++u)
-					xb[xd[u]] = k1_raw_cvt<FMT>(rr[d][u]);
-				if (pos == 0) {
-					/* ask for the next ticket: older than every load issued from here on, so the waits below see it land */
-					const unsigned long long m = __ballot(tid == 0);
-					asm volatile("s_mov_b64 s[2:3], exec\n\t"
-						     "s_mov_b64 exec, %3\n\t"
-						     "global_atomic_add %0, %1, %2, %4 sc0\n\t"
-						     "s_mov_b64 exec, s[2:3]"
-						     : "+v"(tkr) : "v"(0u), "v"(1u), "s"(m), "s"(ctr) : "memory", "s2", "s3");
-				}
-				if (pos == K1F_DEPTH) {
-					/* the wait above was for loads issued after the request: it has landed */
-					asm volatile("" : "+v"(tkr));
-					if (tid == 0)
-						s_next = ((int)tkr + nfam) * K1F_CHUNK;
-				}
-				if (pos == K1F_CHUNK - K1F_DEPTH)
-					nxt = __builtin_amdgcn_readfirstlane(s_next);	/* first index of the next ticket; written K1F_CHUNK - 2 D barriers ago */
-				/* the iteration DEPTH ahead: in this chunk, in the next one, or none (the loads then fetch this one again) */
-				int idx2 = pos < K1F_CHUNK - K1F_DEPTH ? idx0 + K1F_DEPTH : nxt + (pos - (K1F_CHUNK - K1F_DEPTH));
-				idx2 = idx2 < n_x ? idx2 : -1;
-				{
-					const char *rb = rbase + pbytes * (idx2 >= 0 ? idx2 : idx0);
-#ifndef K1F_NOLOAD
-					k1_raw_issue<FMT>(rr[d][0], vo[0], rb);
-					k1_raw_issue<FMT, K1F_THREADS * B>(rr[d][1], vo[0], rb);
-					k1_raw_issue<FMT>(rr[d][2], vo[2], rb);
-#endif
-				}
-				K1F_STAMP(2);	/* convert, park, issue the next loads */
-#ifndef K1F_NOBARRIER
-				__syncthreads();	/* the slice is written */
-#endif
-				K1F_STAMP(3);	/* barrier */
-				v2f res = {0.0f, 0.0f};
-#ifdef K1F_NOMIX
-				if (p.nbch > 8) {
-#else
-				{
-#endif
-					const v2f *xp = reinterpret_cast<const v2f *>(&xb[kk * 25]);
-					v2f acc = {0.0f, 0.0f};
-					if (FMT == VDL2GPU_FMT_F32R) {
-#pragma unroll
-						for (int t = 0; t < 23; ++t) {
-							const float x = xp[t].x;
-							acc += (v2f){x, x} * w[t];
-						}
-						if (nwin == 24) {
-							const float x = xp[23].x;
-							acc += (v2f){x, x} * w[23];
-						}
-					} else {
-						/* six blocks of 4 samples; every block is mixed while the next one's samples are on their way
-						 * from LDS (reads return in order: at most 4 outstanding = the previous block is there) */
-						/* (which copy of the slice is part of the reads' immediate offsets: one address register for both) */
-						auto mix = [&](auto par) {
-							constexpr int XO = (int)sizeof(xs[0]) * decltype(par)::value;
-							v2f x0[4], x1[4];
-							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-							k1_lds_issue4<0 + XO>(x0, xa);
-							k1_lds_issue4<32 + XO>(x1, xa);
-							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-							k1_cmac4_v(acc, x0, &w[0]);
-							k1_lds_issue4<64 + XO>(x0, xa);
-							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-							k1_cmac4_v(acc, x1, &w[4]);
-							k1_lds_issue4<96 + XO>(x1, xa);
-							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-							k1_cmac4_v(acc, x0, &w[8]);
-							k1_lds_issue4<128 + XO>(x0, xa);
-							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-							k1_cmac4_v(acc, x1, &w[12]);
-							k1_lds_issue4<160 + XO>(x1, xa);
-							asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-							k1_cmac4_v(acc, x0, &w[16]);
-							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-							k1_cmac3_v(acc, x1, &w[20]);
-							if (nwin == 24)
-								k1_cmac1_v(acc, x1[3], w[23]);
-						};
-						if (d & 1)
-							mix(std::integral_constant<int, 1>{});
-						else
-							mix(std::integral_constant<int, 0>{});
-					}
-					/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
-					 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
-					 * checked for nf = 23, 24: tests/ctests/div_check.c); below that, and only
-					 * then, the plain IEEE division is used */
-					if (__all(fabsf(acc.x) >= 1e-30f && fabsf(acc.y) >= 1e-30f)) {
-						const float q0r = acc.x * rfn, q0i = acc.y * rfn;
-						res.x = fmaf(fmaf(-q0r, fn, acc.x), rfn, q0r);
-						res.y = fmaf(fmaf(-q0i, fn, acc.y), rfn, q0i);
-					} else {
-						res.x = acc.x / fn;
-						res.y = acc.y / fn;
-					}
-				}
-				K1F_STAMP(4);	/* mix + divide */
-				/* exactly one store instruction per iteration and wavefront: four whole lines (channels beyond nbch
-				 * masked off; a wavefront without any channel still issues it, with no lane enabled, so that the
-				 * count above holds) */
-				{
-#ifndef K1F_NOSTORE
-					k1_store_masked(dec + (long long)idx0 * (8 * K1F_PER_OUT), dvo, res, active);
-#endif
-				}
-				K1F_STAMP(5);	/* store issue */
-				/* no second barrier: the next iteration writes the other copy, and the one after that writes this one only
-				 * behind the next iteration's barrier, which every wave reaches after its reads here */
-				idx0 = idx1;
-				idx1 = idx2;
-				pos = pos + 1 == K1F_CHUNK ? 0 : pos + 1;
-			}
+		/* the SIMD's arbiter serves its oldest wavefront first: left alone, the five wavefronts of a SIMD advance
+		 * at very different rates.  Rotating priorities keep them together. */
+		switch ((pos + (int)blockIdx.x) & 3) {
+		case 0: __builtin_amdgcn_s_setprio(0); break;
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		default: __builtin_amdgcn_s_setprio(3); break;
 		}
+#endif
+#if defined(K1F_NOLOAD) || defined(K1F_NOSTORE)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+		asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
+		K1F_STAMP(1);	/* wait for the samples */
+#pragma unroll
+		for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+			for (int u = 0; u < 3; ++u)
+				asm volatile("" : "+v"(rr[ab][u]));	/* read only behind the wait */
+#pragma unroll
+		for (int ab = 0; ab < 2; ++ab) {
+			float2 *xb = xs[buf][ab];
+#pragma unroll
+			for (int u = 0; u < 3; ++u)
+				xb[xd[u]] = k1_raw_cvt<FMT>(rr[ab][u]);
+		}
+		if (pos == 0) {
+			/* ask for the next ticket: older than the loads issued below, so the next iteration's wait sees it land */
+			const unsigned long long m = __ballot(tid == 0);
+			asm volatile("s_mov_b64 s[2:3], exec\n\t"
+				     "s_mov_b64 exec, %3\n\t"
+				     "global_atomic_add %0, %1, %2, %4 sc0\n\t"
+				     "s_mov_b64 exec, s[2:3]"
+				     : "+v"(tkr) : "v"(0u), "v"(1u), "s"(m), "s"(ctr) : "memory", "s2", "s3");
+		}
+		if (pos == 1) {
+			asm volatile("" : "+v"(tkr));	/* it has landed: the wait above was for loads issued after the request */
+			if (tid == 0)
+				s_next = ((int)tkr + nfam) * CP;
+		}
+		if (pos == 2)
+			nxt = __builtin_amdgcn_readfirstlane(s_next);	/* first pair of the next ticket; written one barrier ago */
+		/* the next pair: in this chunk, the next ticket's first, or none (the loads then fetch this one again) */
+		int p1 = pos < CP - 1 ? p0 + 1 : nxt;
+		p1 = 2 * p1 < n_x ? p1 : -1;
+		{
+			const int ia = 2 * (p1 >= 0 ? p1 : p0), ib = ia + 1 < n_x ? ia + 1 : ia;
+#ifndef K1F_NOLOAD
+			const char *rb = rbase + pbytes * ia;
+			k1_raw_issue<FMT>(rr[0][0], vo[0], rb);
+			k1_raw_issue<FMT, K1F_THREADS * B>(rr[0][1], vo[0], rb);
+			k1_raw_issue<FMT>(rr[0][2], vo[2], rb);
+			rb = rbase + pbytes * ib;
+			k1_raw_issue<FMT>(rr[1][0], vo[0], rb);
+			k1_raw_issue<FMT, K1F_THREADS * B>(rr[1][1], vo[0], rb);
+			k1_raw_issue<FMT>(rr[1][2], vo[2], rb);
+#endif
+		}
+		K1F_STAMP(2);	/* convert, park, issue the next loads */
+#ifndef K1F_NOBARRIER
+		__syncthreads();	/* the slices are written */
+#endif
+		K1F_STAMP(3);	/* barrier */
+		const bool has_b = 2 * p0 + 1 < n_x;
+		const unsigned xc = xa + (unsigned)buf * (unsigned)sizeof(xs[0]);
+#pragma unroll
+		for (int ab = 0; ab < 2; ++ab) {
+			v2f res = {0.0f, 0.0f};
+#ifdef K1F_NOMIX
+			if (p.nbch > 8) {
+#else
+			if (ab == 0 || has_b) {
+#endif
+				v2f acc = {0.0f, 0.0f};
+				if (FMT == VDL2GPU_FMT_F32R) {
+					const v2f *xp = reinterpret_cast<const v2f *>(&xs[buf][ab][kk * 25]);
+#pragma unroll
+					for (int t = 0; t < 23; ++t) {
+						const float x = xp[t].x;
+						acc += (v2f){x, x} * w[t];
+					}
+					if (nwin == 24) {
+						const float x = xp[23].x;
+						acc += (v2f){x, x} * w[23];
+					}
+				} else {
+					/* six blocks of 4 samples; every block is mixed while the next one's samples are on their way
+					 * from LDS (reads return in order: at most 4 outstanding = the previous block is there); which
+					 * slice of the pair is part of the reads' immediate offsets */
+					auto mix = [&](auto par) {
+						constexpr int XO = (int)sizeof(xs[0][0]) * decltype(par)::value;
+						v2f x0[4], x1[4];
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						k1_lds_issue4<0 + XO>(x0, xc);
+						k1_lds_issue4<32 + XO>(x1, xc);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x0, &w[0]);
+						k1_lds_issue4<64 + XO>(x0, xc);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x1, &w[4]);
+						k1_lds_issue4<96 + XO>(x1, xc);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x0, &w[8]);
+						k1_lds_issue4<128 + XO>(x0, xc);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x1, &w[12]);
+						k1_lds_issue4<160 + XO>(x1, xc);
+						asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						k1_cmac4_v(acc, x0, &w[16]);
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						k1_cmac3_v(acc, x1, &w[20]);
+						if (nwin == 24)
+							k1_cmac1_v(acc, x1[3], w[23]);
+					};
+					if (ab)
+						mix(std::integral_constant<int, 1>{});
+					else
+						mix(std::integral_constant<int, 0>{});
+				}
+				/* D /= nf (d8psk.c:377).  q0 = x*RN(1/nf); q = fma(fma(-q0, nf, x), RN(1/nf), q0)
+				 * is the correctly rounded quotient for every |x| >= 1e-30 (exhaustively
+				 * checked for nf = 23, 24: tests/ctests/div_check.c); below that, and only
+				 * then, the plain IEEE division is used */
+				if (__all(fabsf(acc.x) >= 1e-30f && fabsf(acc.y) >= 1e-30f)) {
+					const float q0r = acc.x * rfn, q0i = acc.y * rfn;
+					res.x = fmaf(fmaf(-q0r, fn, acc.x), rfn, q0r);
+					res.y = fmaf(fmaf(-q0i, fn, acc.y), rfn, q0i);
+				} else {
+					res.x = acc.x / fn;
+					res.y = acc.y / fn;
+				}
+			}
+			K1F_STAMP(4);	/* mix + divide */
+			/* exactly one store instruction per superperiod and wavefront: four whole lines (channels beyond nbch masked
+			 * off; a wavefront without any channel, or the missing second half of the family's last pair, still issues
+			 * it, with no lane enabled, so that the count above holds) */
+#ifndef K1F_NOSTORE
+			k1_store_masked(dec + (long long)(2 * p0 + ab) * (8 * K1F_PER_OUT), dvo, res, active && (ab == 0 || has_b));
+#endif
+			K1F_STAMP(5);	/* store issue */
+		}
+		/* no second barrier: the next iteration writes the other copy of the slices, and the one after that writes this
+		 * one only behind the next iteration's barrier, which every wave reaches after its reads here */
+		p0 = p1;
+		pos = pos + 1 == CP ? 0 : pos + 1;
+		buf ^= 1;
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef K1F_PROF
