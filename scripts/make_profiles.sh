@@ -5,7 +5,8 @@
 #   r02_bench_pmc_hbm.json      FETCH_SIZE / WRITE_SIZE per kernel launch (separate --pmc passes)
 #   r02_bench_pmc_sq.json       SQ counters per kernel launch (three --pmc passes of <= 8 counters)
 #   r02_valu_rate.txt           scripts/micro/valu_rate.bin: what packed / plain FP32 and the mixer's instruction mix issue at
-#   r02_k1_ablation.txt         k1_fast rebuilt without mixer / loads / stores / XCD mapping (scripts/r02_probe5.sh)
+#   r02_k1_ablation.txt         k1_fast rebuilt without mixer / barrier / priority rotation (scripts/r02_probe6.sh) and with phase stamps (r02_probe7.sh)
+#   r02_clock_rate.txt          scripts/micro/clock_rate.bin: shader clock and packed-FP32 issue interval against wavefronts per SIMD
 #   r02_ber_curve.json          scripts/ber_curve.py: frame success vs Es/N0, GPU == oracle at every point
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -21,7 +22,7 @@ S="--no-parity --steps 4 --warmup 2"
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pr_w -- $B $S > /tmp/pr_w.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pr_s1 -- $B $S > /tmp/pr_s1.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/pr_s2 -- $B $S > /tmp/pr_s2.log 2>&1 )
-( cd /tmp && rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES --output-format csv -d /tmp/pr_s3 -- $B $S > /tmp/pr_s3.log 2>&1 )
+( cd /tmp && rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pr_s3 -- $B $S > /tmp/pr_s3.log 2>&1 )
 python - "$OUT" <<'PY'
 import sys, glob, csv, collections, json
 out = sys.argv[1]
@@ -49,7 +50,8 @@ json.dump({"per_launch": sq, "_note": "SQ_* in quad-cycles / instructions summed
 PY
 $B 2>/dev/null | tail -1 > $OUT/r02_bench_line.json
 timeout 300 scripts/micro/valu_rate.bin > $OUT/r02_valu_rate.txt 2>&1
-timeout 600 scripts/r02_probe5.sh > $OUT/r02_k1_ablation.txt 2>&1
+timeout 120 scripts/micro/clock_rate.bin > $OUT/r02_clock_rate.txt 2>&1
+( printf "%s\n" "-DK1F_BASE" "-DK1F_NOMIX" "-DK1F_NOPRIO" | timeout 600 scripts/r02_probe6.sh; printf "%s\n" "-DK1F_BASE" | timeout 300 scripts/r02_probe7.sh ) > $OUT/r02_k1_ablation.txt 2>&1
 timeout 900 python scripts/ber_curve.py --out $OUT/r02_ber_curve.json > $OUT/r02_ber_curve.txt 2>&1
 python - "$OUT" <<'PY'
 import sys, json, csv

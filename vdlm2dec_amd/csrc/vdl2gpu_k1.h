@@ -658,7 +658,11 @@ __device__ __forceinline__ void k1_cmac3_v(v2f &acc, const v2f (&x)[4], const v2
 }
 
 #define K1F_THREADS 128		/* two wavefronts: channels 0-3 and 4-7 of the same 16 windows */
-#define K1F_WAVES_OF(FMT_) ((FMT_) == VDL2GPU_FMT_CF32 ? 4 : 5)	/* wavefronts per SIMD the kernel is built for: 96 registers (cf32 holds its
+#ifdef K1F_PROF
+#define K1F_WAVES_OF(FMT_) 4	/* the stamps need registers of their own */
+#else
+#define K1F_WAVES_OF(FMT_) ((FMT_) == VDL2GPU_FMT_CF32 ? 4 : 5)
+#endif	/* wavefronts per SIMD the kernel is built for: 96 registers (cf32 holds its
 								 * raw samples in twice as many: 128, 4 wavefronts) */
 #ifndef K1F_DEPTH
 #define K1F_DEPTH 2		/* superperiods of raw samples in flight per wavefront (registers) */
