@@ -1001,16 +1001,23 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
 			(void)hipEventRecord(pt.e[8], ks);
-			/* the grid is resident as a whole (or in `rounds` equal waves of workgroups): n_cu * 2 * K1F_WAVES_OF(fmt) workgroups of
-			 * two wavefronts fit; groups of 21 roles, a multiple of 8 groups (one XCD each, see k1_fast), every group
-			 * takes every ngrp-th superperiod */
+			/* The grid is resident as a whole: n_cu * 2 * K1F_WAVES_OF(fmt) workgroups of two wavefronts fit.  Per stream
+			 * 21 roles x 8 XCDs families of `nfam` workgroups each, which take the family's tickets in turn (see k1_fast);
+			 * a family needs no more workgroups than it has tickets.  With several streams the families are many and
+			 * small: rather two workgroups each and a twentieth of them waiting for a slot than one each and half the
+			 * SIMDs' wavefront slots empty. */
 			long long ngrp;
 			{
 				const long long slots = (long long)h->n_cu * 2 * K1F_WAVES_OF(h->cfg.fmt);
-				const int rounds = getenv("VDL2GPU_K1F_ROUNDS") ? std::max(1, atoi(getenv("VDL2GPU_K1F_ROUNDS"))) : 1;
-				ngrp = slots * rounds / ((long long)K1F_ROLES * h->S) / 8 * 8;
-				ngrp = std::max<long long>(8, std::min<long long>(ngrp, (k1.per_n + 1) / 2 / 8 * 8));	/* at least two superperiods each */
-				ngrp = std::max<long long>(8, ngrp);
+				const long long per_fam = (long long)K1F_ROLES * 8 * h->S;
+				long long nfam = slots / per_fam;
+				if (nfam < 4 && (nfam + 1) * per_fam * 100 <= slots * 108)
+					++nfam;
+				if (getenv("VDL2GPU_K1F_NFAM"))
+					nfam = atoi(getenv("VDL2GPU_K1F_NFAM"));
+				const long long tickets = ((k1.per_n + 7) / 8 + K1F_CHUNK - 1) / K1F_CHUNK;	/* of the family with the most */
+				nfam = std::max<long long>(1, std::min(nfam, tickets));
+				ngrp = nfam * 8;
 			}
 			k1.tickets = h->d_k1_tickets;
 			HIPCHK(h, hipMemsetAsync(h->d_k1_tickets, 0, (size_t)h->S * K1F_ROLES * 8 * sizeof(unsigned), ks));
