@@ -714,6 +714,8 @@ void k2a_region(K2Params p)
 	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
 		return;
 	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
+	if (blockIdx.x >= nreg)	/* nothing for this workgroup (64 channels x 128 workgroups, 40 regions each): not even the tables */
+		return;
 	const long long dec_base = p.ss[s].dec_base;
 	const int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
 	const int skip_r = p.cs[sc].r, skip_par = (int)(p.cs[sc].pos & 1);
