@@ -17,7 +17,7 @@ for f in glob.glob(f"/tmp/pmc_{i}/**/*counter_collection.csv", recursive=True):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 for k in sorted(agg):
-    if k.startswith(("k2a", "k1_", "void k1_", "k2b", "k2c", "k2d")):
+    if k.startswith(("k2", "k1_", "void k1_", "k3", "k4", "k_")):
         print(k, {c: round(v / max(1, cnt[(k, c)])) for c, v in agg[k].items()})
 PY
 done

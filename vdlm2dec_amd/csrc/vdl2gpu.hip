@@ -98,6 +98,7 @@ struct vdl2gpu {
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
+	int k2d_grid = 128;	/* payload workgroups per channel */
 	int force_serial = 0;
 	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
 	int n_cu = 256;
@@ -585,6 +586,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	if (getenv("VDL2GPU_STAGE_EVERY"))
 		h->stage_every = std::max(1, atoi(getenv("VDL2GPU_STAGE_EVERY")));
+	if (getenv("VDL2GPU_K2D_GRID"))
+		h->k2d_grid = std::max(1, atoi(getenv("VDL2GPU_K2D_GRID")));
 	if (getenv("VDL2GPU_PRIM_DROP"))
 		h->prim_drop = atoi(getenv("VDL2GPU_PRIM_DROP"));
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
@@ -1193,7 +1196,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (spec) {
 			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
 			HIPCHK(h, hipStreamWaitEvent(h->pay_stream, h->k2c_done, 0));
-			hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
 			HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
 		}
 		if (staged)
@@ -1223,7 +1226,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (h->ring_spec[ring])
 			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
 		else
-			hipLaunchKernelGGL(k2d_payload, dim3(128, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->frames_on) {
 			/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:

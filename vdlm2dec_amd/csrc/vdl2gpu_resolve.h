@@ -116,6 +116,7 @@ void k2b_clusters(K2Params p)
 	}
 	__syncthreads();
 	const unsigned total = s_pref[nsc64];
+	int ord = 0;	/* (development counters: the wavefront's n-th cluster) */
 	for (unsigned tk = blockIdx.x; tk < total; tk += gridDim.x) {
 		int scl = 0;
 		while (scl + 1 < nsc64 && s_pref[scl + 1] <= tk)
@@ -181,6 +182,12 @@ void k2b_clusters(K2Params p)
 			atomicAdd(p.dbg + 6, (unsigned long long)(rc == MR_STEADY));
 			atomicAdd(p.dbg + 7, (unsigned long long)out.nrej);
 		}
+		if (tid == 0 && p.dbg) {	/* is a wavefront's first cluster slower than its later ones (code fetched cold)? */
+			const int o = ord < 3 ? ord : 3;
+			atomicAdd(p.dbg + 8 + o, (unsigned long long)(t2 - t0));
+			atomicAdd(p.dbg + 12 + o, 1ull);
+		}
+		++ord;
 		int status;
 		if (rc == MR_STEADY)
 			status = CL_STEADY;
