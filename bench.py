@@ -29,7 +29,8 @@ Extra objects on the JSON line:
                 bursts of one steady-state tile are what every tile of the timed region must contain, record for record
                 (channel, instant, nbrow, nlbyte, carrier estimate, all 2040 data bytes).  A mismatch nulls `value` and
                 the process exits 1.
-  cpu_baseline  the oracle (CPU restatement, pinned bit-equal to the reference) on this host's cores on a bounded sample.
+  cpu_baseline  the real reference (oracle/_ref: its own sources, its own compile flags) on this host's cores on a bounded
+                sample; beside it ("port") the oracle, the CPU restatement pinned bit-equal to it.
 """
 from __future__ import annotations
 
@@ -118,6 +119,63 @@ def cpu_baseline(raw: np.ndarray, fmt: str, fos, rate: int, budget_s: float = 12
             "sample": f"{n} samples ({reps} x the 4.2 MS tile of the same recording), {len(fos)} channels, {nthreads} threads "
                       f"(1 thread/channel), {dt:.1f} s wall, {nb} bursts; single-thread single-channel "
                       f"{1.0 / one / 1e6:.1f} MS/s; host CPU: {model} x{ncores}"}
+
+
+def cpu_baseline_reference(raw: np.ndarray, fmt: str, fos, rate: int, budget_s: float = 10.0):
+    """The REAL reference on host cores: oracle/_ref/ref_rtl[_ofast] is vdlm2dec's own d8psk.c/viterbi.c/vdlm2.c/crc.c/
+    rs.c compiled where they lie (oracle/Makefile; the _ofast build with the reference's own -Ofast -march=native)
+    behind a harness that does what rtl.c's in_callback and main.c do: one producer mixing and decimating blocks of
+    RTLINBUFSZ for every channel, one rcv_thread per channel, two barriers per block.  Prebuilt in the container
+    (the GPU box has no /root/reference); returns None where the binary is missing or does not run on this host."""
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    if fmt == "f32":
+        names = ["ref_air_ofast", "ref_air"]
+    elif fmt in ("cu8", "cs16", "cf32"):
+        names = ["ref_rtl_ofast", "ref_rtl"]
+    else:
+        return None
+    per = {"cu8": 2, "cs16": 2, "cf32": 2, "f32": 1}[fmt]
+    n_tile = raw.size // per
+    reps = max(1, min(32, (512 << 20) // max(1, raw.nbytes)))       # at most 512 MB of input
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    res = None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as td:
+        path = os.path.join(td, "iq.bin")
+        with open(path, "wb") as f:
+            for _ in range(reps):
+                f.write(raw.tobytes())
+        n = n_tile * reps
+        fo = ",".join(str(int(x)) for x in fos)
+        fr = ",".join(str(int(FC + x)) for x in fos)
+        for name in names:
+            exe = os.path.join(here, "oracle", "_ref", name)
+            if not os.path.exists(exe):
+                continue
+            cmd = [exe, path, fmt, str(rate), fo, fr, os.path.join(td, "out.txt")]
+            try:
+                t0 = time.perf_counter()
+                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                one = time.perf_counter() - t0
+            except (subprocess.SubprocessError, OSError):
+                continue                                          # e.g. -march=native of another machine
+            runs, total = 1, one
+            while total < budget_s and runs < 8:
+                t0 = time.perf_counter()
+                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                total += time.perf_counter() - t0
+                runs += 1
+            nb = sum(1 for ln in open(os.path.join(td, "out.txt")) if ln.startswith("B"))
+            res = {"value": n * runs / total / 1e6, "unit": "MS/s", "cores": len(fos) + 1, "kind": "reference",
+                   "sample": f"{runs} runs of oracle/_ref/{name} (vdlm2dec's own sources"
+                             f"{', its own -Ofast -march=native' if name.endswith('_ofast') else ', -O2'}; producer + one rcv_thread per "
+                             f"channel as in rtl.c/main.c) over {n} samples ({reps} x the 4.2 MS tile) from a file in "
+                             f"{'memory' if tmpdir else 'tmp'}, {len(fos)} channels, {total:.1f} s wall, {nb} bursts in the last run (all channels in "
+                             f"one process is this harness's timing mode: the count varies by a few per cent from run to run; "
+                             f"parity is pinned one channel per process, tests/test_oracle_vs_ref.py)"}
+            break
+    return res
 
 
 def oracle_stream(tile: np.ndarray, fmt: str, rate: int, fos, ntiles: int):
@@ -463,7 +521,13 @@ def main():
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS") or os.environ.get("VDL2GPU_K1_PROF"):
             out["dbg"] = rx.debug_counters(64)
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tiles_np[0], args.fmt, fos, rate)
+            port = cpu_baseline(tiles_np[0], args.fmt, fos, rate)
+            ref = cpu_baseline_reference(tiles_np[0], args.fmt, fos, rate)
+            if ref is not None:
+                ref["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}   # the oracle, for comparison
+                out["cpu_baseline"] = ref
+            else:
+                out["cpu_baseline"] = port
         print(json.dumps(out))
         if not parity_ok:
             print("bench.py: PARITY FAILED -- value withheld", file=sys.stderr)

@@ -6,7 +6,7 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python bench.py --steps 2 --warmup 1 --no-cpu --no-parity > /tmp/pmc_$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python bench.py --steps 2 --warmup 1 --no-cpu --no-parity $BENCH_ARGS > /tmp/pmc_$i.log 2>&1
   python - "$i" <<'PY'
 import sys, glob, csv, collections
 i = sys.argv[1]
