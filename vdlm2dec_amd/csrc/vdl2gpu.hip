@@ -68,6 +68,7 @@ struct vdl2gpu {
 	std::vector<char> ring_inflight;
 	float2 *d_lo = nullptr;
 	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
+	unsigned k1_tbase[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* what they hold, per XCD (the same for every role and stream) */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
 	float2 *d_dec[2] = { nullptr, nullptr };
 	StreamState *d_ss = nullptr;
@@ -538,6 +539,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_lo_ext, (size_t)S * VDL2_CS * (L + 48) * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_k1_tickets, (size_t)S * 21 * 8 * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_k1_tickets, 0, (size_t)S * 21 * 8 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_ss, (size_t)S * sizeof(StreamState)));
 	HIPCHK(h, hipMalloc(&h->d_cs, (size_t)S * VDL2_CS * sizeof(ChanState)));
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
@@ -1022,8 +1024,15 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				nfam = std::max<long long>(1, std::min(nfam, tickets));
 				ngrp = nfam * 8;
 			}
+			/* the counters are never reset: a launch makes exactly one request per ticket of a family (k1_fast), so the
+			 * host knows where each one stands */
 			k1.tickets = h->d_k1_tickets;
-			HIPCHK(h, hipMemsetAsync(h->d_k1_tickets, 0, (size_t)h->S * K1F_ROLES * 8 * sizeof(unsigned), ks));
+			for (int x = 0; x < 8; ++x) {
+				k1.tbase[x] = h->k1_tbase[x];
+				const long long n_x = (k1.per_n - x + 7) >> 3;
+				if (n_x > 0)
+					h->k1_tbase[x] += (unsigned)((n_x + K1F_CHUNK - 1) / K1F_CHUNK);
+			}
 			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;

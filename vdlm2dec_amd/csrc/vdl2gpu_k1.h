@@ -775,7 +775,8 @@ void k1_fast(K1Params p)
 	const int n_x = ((int)p.per_n - x + 7) >> 3;			/* superperiods of this XCD */
 	if (rank * K1F_CHUNK >= n_x)	/* its first ticket is empty */
 		return;
-	const unsigned *ctr = p.tickets + ((size_t)s * K1F_ROLES + g) * 8 + x;	/* zeroed by the launch; ticket = nfam + old value */
+	const unsigned *ctr = p.tickets + ((size_t)s * K1F_ROLES + g) * 8 + x;	/* ticket = nfam + (old value - tbase[x]) */
+	const unsigned tbase = p.tbase[x];
 	const int kk = lane >> 2, c = wv * 4 + (lane & 3);
 	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
@@ -905,7 +906,7 @@ void k1_fast(K1Params p)
 		if (pos == 1) {
 			asm volatile("" : "+v"(tkr));	/* it has landed: the wait above was for loads issued after the request */
 			if (tid == 0)
-				s_next = ((int)tkr + nfam) * CP;
+				s_next = ((int)(tkr - tbase) + nfam) * CP;
 		}
 		if (pos == 2)
 			nxt = __builtin_amdgcn_readfirstlane(s_next);	/* first pair of the next ticket; written one barrier ago */

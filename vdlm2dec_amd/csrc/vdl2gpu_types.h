@@ -86,7 +86,8 @@ struct K1Params {
 	long long N, J;
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
 	long long per_lo, per_n;	/* k1_fast: superperiods [per_lo, per_lo+per_n) */
-	unsigned *tickets;	/* k1_fast: [S][21 roles][8 XCDs] work counters, zero at launch */
+	unsigned *tickets;	/* k1_fast: [S][21 roles][8 XCDs] work counters; never reset: */
+	unsigned tbase[8];	/* ... what the counters of XCD x hold when this launch starts (every launch adds the number of its tickets) */
 	const float2 *lo;	/* [S][8][L] */
 	const float2 *lo_ext;	/* k1_fast: [S][8][lo_stride], entry 8 + i = lo[i mod L] for -8 <= i < L + 40 */
 	int lo_stride;
