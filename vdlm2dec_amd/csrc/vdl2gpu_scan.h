@@ -732,7 +732,9 @@ void k2a_region(K2Params p)
 
 /* one workgroup = K2A_VRUN tiles of 2*K2A_TS samples; every piece of a verify segment inside a tile
  * is scanned in the segment's class */
+#ifndef K2A_VRUN
 #define K2A_VRUN 4
+#endif
 #define K2A_VITEMS 64
 __global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k2a_verify(K2Params p)
