@@ -139,7 +139,19 @@ def cpu_baseline_reference(raw: np.ndarray, fmt: str, fos, rate: int, budget_s: 
     per = {"cu8": 2, "cs16": 2, "cf32": 2, "f32": 1}[fmt]
     n_tile = raw.size // per
     reps = max(1, min(32, (512 << 20) // max(1, raw.nbytes)))       # at most 512 MB of input
-    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    for tmpdir in (["/dev/shm"] if os.path.isdir("/dev/shm") else []) + [None]:
+        try:
+            return _reference_run(raw, fmt, fos, rate, budget_s, names, n_tile, reps, tmpdir, here)
+        except OSError:
+            continue        # e.g. a 64 MB /dev/shm: try the ordinary temporary directory, then give up
+        except Exception:   # a baseline leg must never take the bench down (a timed-out run, an unreadable output)
+            return None
+    return None
+
+
+def _reference_run(raw, fmt, fos, rate, budget_s, names, n_tile, reps, tmpdir, here):
+    import subprocess
+    import tempfile
     res = None
     with tempfile.TemporaryDirectory(dir=tmpdir) as td:
         path = os.path.join(td, "iq.bin")
