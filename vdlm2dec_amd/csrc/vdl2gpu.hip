@@ -1197,10 +1197,11 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		h->k2_mid_rec = true;
 		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
-		/* With no repair round scheduled the resolver's selection is final unless the verify pass fails
-		 * (then K2f redoes the channel and the host drops what K2d made of it, see harvest_ring): decode
-		 * the payloads beside the verify pass instead of behind it. */
-		const bool spec = h->repair_rounds == 0 && !h->full_scan && !serial && h->S * VDL2_CS <= 512;
+		/* The resolver's selection is final unless the verify pass fails -- then a repair round re-resolves the
+		 * channel, or K2f redoes it serially, and the host drops what K2d made of it (see harvest_ring; K2d decodes
+		 * a repaired selection in a second pass behind the rounds): decode the payloads beside the verify pass
+		 * instead of behind it. */
+		const bool spec = !h->full_scan && !serial && h->S * VDL2_CS <= 512;
 		h->ring_spec[ring] = spec;
 		if (spec) {
 			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
@@ -1218,6 +1219,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			 * re-resolved and re-verified with that hit in their table; every other channel's
 			 * workgroups exit at once.  What still fails is redone serially by K2f. */
 			K2Params k2r = k2;
+			if (spec && h->repair_rounds > 0)	/* a repair round rewrites the selection K2d is reading */
+				HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));
 			for (int rr = 1; rr <= h->repair_rounds; ++rr) {
 				k2r.round = rr;
 				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2r);
@@ -1232,9 +1235,14 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
-		if (h->ring_spec[ring])
+		if (h->ring_spec[ring]) {
 			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
-		else
+			if (h->repair_rounds > 0 && !h->full_scan && !serial) {
+				K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
+				k2p.pay_final = 1;
+				hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2p);
+			}
+		} else
 			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->frames_on) {

@@ -294,6 +294,10 @@ void k2c_resolve(K2Params p)
 			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
 			p.ctl[CTL_NSEL0 + sc] = 0;
 			p.ctl[CTL_NSEG0 + sc] = 0;
+			/* if K2d ran ahead on the first pass's selection, what it made of this channel is void (the host and K4
+			 * drop the records tagged 0 of masked channels); K2d decodes the repaired selection in its second pass */
+			if (p.fmask && sc < 512)
+				atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
 		}
 		__syncthreads();
 	}
@@ -715,6 +719,10 @@ void k2d_payload(K2Params p)
 	__shared__ unsigned s_slot;
 	__shared__ float sph[VDL2_MAXSYM];
 	const int sc = blockIdx.y;
+	/* second pass (pay_final): only the channels a repair round re-resolved behind the first pass's back; their records
+	 * are final (tag 1).  A channel K2f redid serially has nothing selected. */
+	if (p.pay_final && !(sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u)))
+		return;
 	unsigned n = p.ctl[CTL_NSEL0 + sc];
 	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
 	const unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
@@ -733,7 +741,7 @@ void k2d_payload(K2Params p)
 			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
-			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, 0, d.sc);
+			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc);
 		}
 		__syncthreads();
 	}

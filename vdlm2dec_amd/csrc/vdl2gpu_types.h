@@ -140,7 +140,8 @@ struct K2Params {
 	vdl2gpu_burst_t *recs;	/* output ring of this push */
 	unsigned *outc;		/* [0] = records written, [1] = records dropped (ring full) */
 	unsigned *outc_total_redo;	/* running count of serial redos (host adapts the number of repair rounds) */
-	unsigned *fmask;	/* [16] bit per (stream, channel slot) that K2f redid serially in this push */
+	unsigned *fmask;	/* [16] bit per (stream, channel slot) that a repair round re-resolved or K2f redid serially in this push */
+	int pay_final;		/* K2d: second pass, behind the repair rounds (only masked channels, records tagged final) */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
 	int prim_drop;		/* test handicap: every prim_drop-th candidate gets no precomputed cluster (the resolver builds it) */
