@@ -131,3 +131,28 @@ def test_frames_of_channels_redone_serially(built, oracle):
     assert st["serial_redos"] > 0
     assert sorted(frames) == want and len(want) >= 10
     assert sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in bursts) == sorted(b.key() for b in ob)
+
+
+def test_frames_of_channels_repaired_behind_the_payload_decode(built, oracle, monkeypatch):
+    """The same handicap with repair rounds scheduled from the first push: the payload decode has run ahead on the first
+    pass's selection when a round re-resolves a channel; those records (and the frames K4 would make of them) are void,
+    the repaired selection is decoded behind the rounds -- bursts and frames must be the oracle's, none twice."""
+    from vdlm2dec_amd import lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", "3")
+    monkeypatch.setenv("VDL2GPU_DEBUG_COUNTERS", "1")
+    spec = synth.random_scenario(2_000_000, S.FO8[:3], 1 << 21, seed=96, bursts_per_s=10.0, info_max=100)
+    raw = synth.synth_stream(spec, "cs16")
+    ob = oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC)
+    want = sorted((0, b.chn, f) for b in ob for f in oracle.frames_of_block(b.nbrow, b.nlbyte, b.data))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20, frames=True,
+                  flags=lib.F_TEST_NOREGION) as rx:
+        bursts, frames = [], []
+        for s0 in range(0, spec.nsamples, 600_000):
+            rx.push(raw[2 * s0:2 * (s0 + 600_000)])
+            frames += rx.poll_frames()
+            bursts += rx.poll()
+        repaired = rx.debug_counters(32, reset=False)[24]      # channel-pushes that went through a repair round
+    assert repaired > 0
+    assert sorted(frames) == want and len(want) >= 10
+    assert sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in bursts) == sorted(b.key() for b in ob)
