@@ -62,7 +62,7 @@ CONFIGS = {
             rate=10_000_000, streams=1, tiles=64, fos=FO8_10MS),
     4: dict(workload="configs[3]: 512 replayed channels sharded across 8xMI355X via RCCL/xGMI (offline bulk-decode): "
                      "8 streams x 8 channels per GPU",
-            rate=2_000_000, streams=8, tiles=4, fos=None),
+            rate=2_000_000, streams=8, tiles=16, fos=None),
 }
 
 

@@ -328,20 +328,24 @@ def test_verify_pass_catches_incomplete_tables(built, oracle):
     assert _gpu_keys(got) == want and len(want) >= 15
 
 
-def test_repair_rounds_rescan_around_verify_hits(built, oracle, monkeypatch):
+@pytest.mark.parametrize("rounds", [1, 3])
+def test_repair_rounds_rescan_around_verify_hits(built, oracle, monkeypatch, rounds):
     """Same handicap, but with repair rounds on from the first push: every event the verify pass finds
-    becomes a seed, its neighbourhood is scanned in all classes and the chain resolved again -- the
-    result must be the oracle's whether a channel ends up repaired or redone serially."""
+    becomes a seed, its neighbourhood is scanned in all classes and the chain resolved again; the last
+    scheduled round (the only one with rounds = 1) scans the channels that still fail completely, which
+    leaves nothing to verify -- no channel may be left to the serial redo, and the result is the oracle's."""
     from vdlm2dec_amd import lib
     from vdlm2dec_amd.demod import Receiver, plan_channels
-    monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", "3")
+    monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", str(rounds))
     spec = synth.random_scenario(2_000_000, S.FO8[:3], 1 << 21, seed=95, bursts_per_s=10.0, info_max=100)
     raw = synth.synth_stream(spec, "cs16")
     want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
     with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20,
                   flags=lib.F_TEST_NOREGION) as rx:
         got = rx.run(raw, block=600_000)
+        st = rx.stats()
     assert _gpu_keys(got) == want and len(want) >= 15
+    assert st["serial_redos"] == 0
 
 
 @pytest.mark.timeout(300)

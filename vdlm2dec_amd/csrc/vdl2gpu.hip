@@ -1223,10 +1223,21 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));
 			for (int rr = 1; rr <= h->repair_rounds; ++rr) {
 				k2r.round = rr;
+				/* The LAST scheduled round does not repair, it starts over: the channels that still fail are scanned
+				 * completely -- every class at every instant, like VDL2GPU_F_FULLSCAN but for them alone (≈ 0.1 ms for
+				 * a channel of a 67 MS push) --, which leaves nothing to verify and nothing to cascade; before it,
+				 * rounds that only scan around what the verify pass found (cheaper when they suffice). */
+				k2r.full_round = (rr == h->repair_rounds) ? 1 : 0;
 				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2r);
+				if (k2r.full_round) {
+					const unsigned want = tiles;
+					unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
+					per = per > want ? want : per;
+					hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+				} else
 				hipLaunchKernelGGL(k2a_region, dim3(32, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
-				hipLaunchKernelGGL(k2b_clusters, dim3(256, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2b_clusters, dim3(k2r.full_round ? (unsigned)(h->n_cu * 4 * K2B_WAVES) : 256u, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
 			}

@@ -319,7 +319,7 @@ void k2c_resolve(K2Params p)
 	const int r_probe = cs->r;
 	const int par_probe = (int)(cs->pos & 1);	/* the probe scanned class (r_probe, par_probe) everywhere */
 	const int t_end = (int)(cx.avail_end - cx.dec_base);
-	const bool lazy = !p.full_scan;
+	const bool lazy = !p.full_scan && !p.full_round;	/* (a full round's tables hold every class: nothing is left to verify) */
 	mach_init_taps(sh);
 	mach_load(sh, cs);
 	MachOut out;

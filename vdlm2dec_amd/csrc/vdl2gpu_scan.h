@@ -484,11 +484,13 @@ void k2a_probe(K2Params p)
 	const long long avail_end = dec_base + ss->dec_fill + p.J;
 	if (p.force_serial)
 		return;
+	if (p.round > 0 && (!p.full_round || p.fail[sc] >= VDL2_VERIFIED))
+		return;		/* in a repair round the probe only runs as the complete scan of a failing channel */
 	if (threadIdx.x < 16)
 		sh.prof[threadIdx.x] = 0;
 	k2a_tables(sh);
 	/* each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its channel */
-	if (p.full_scan) {
+	if (p.full_scan || p.full_round) {
 		K2aPre<1> pre;
 		pre.loaded = false;
 		const long long step = (long long)gridDim.x * K2A_TS;
@@ -652,6 +654,17 @@ void k2r_regions(K2Params p)
 		return;
 	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
 		return;		/* repair round: only channels whose verify pass found something */
+	if (p.full_round) {
+		/* the channel's tables are made again from nothing, by a scan of every class at every instant */
+		if (tid == 0) {
+			p.ctl[CTL_CAND0 + sc] = 0;
+			p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 0;
+			p.ctl[CTL_NCLUST0 + sc] = 0;
+			p.ctl[CTL_NREG0 + sc] = 0;
+			p.ctl[CTL_NSEED0 + sc] = 0;
+		}
+		return;
+	}
 	int ncand = (int)p.ctl[CTL_NSEED0 + sc];
 	ncand = ncand > VDL2_CAND_CAP ? VDL2_CAND_CAP : ncand;
 	const int *seeds = p.seeds + (size_t)sc * VDL2_CAND_CAP;
@@ -745,7 +758,7 @@ void k2a_verify(K2Params p)
 	const int tid = threadIdx.x;
 	const int c = blockIdx.y, s = blockIdx.z;
 	const int sc = s * VDL2_CS + c;
-	if (p.force_serial || p.full_scan)
+	if (p.force_serial || p.full_scan || p.full_round)
 		return;
 	if (p.round > 0 && !p.redo[sc])
 		return;
