@@ -117,7 +117,8 @@ struct vdl2gpu {
 	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
 	bool k2_mid_rec = false;
-	int repair_rounds = 0;		/* adapted 0..4 from how often the serial fallback was needed */
+	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
+	int rounds_floor = 0;		/* many channels: one (complete) round is always scheduled, see create */
 	unsigned redos_seen = 0, repairs_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -592,6 +593,11 @@ static int create_impl(vdl2gpu_t *h)
 		h->k2d_grid = std::max(1, atoi(getenv("VDL2GPU_K2D_GRID")));
 	if (getenv("VDL2GPU_PRIM_DROP"))
 		h->prim_drop = atoi(getenv("VDL2GPU_PRIM_DROP"));
+	/* A push in which a channel's verify pass fails with no round scheduled costs a serial redo of that channel's whole
+	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
+	 * round is always scheduled. */
+	h->rounds_floor = (h->S * h->C >= 16) ? 1 : 0;
+	h->repair_rounds = h->rounds_floor;
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
 		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
@@ -1350,7 +1356,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			h->repair_rounds = std::min(4, h->repair_rounds + 1);
 		} else if (repairs != h->repairs_seen) {
 			h->last_redo_push = h->ring_push[ring];	/* the rounds are earning their keep */
-		} else if (h->repair_rounds > 0 && h->ring_push[ring] > h->last_redo_push + 256) {
+		} else if (h->repair_rounds > h->rounds_floor && h->ring_push[ring] > h->last_redo_push + 256) {
 			h->repair_rounds--;
 			h->last_redo_push = h->ring_push[ring];
 		}
