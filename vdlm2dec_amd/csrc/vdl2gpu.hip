@@ -1245,7 +1245,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2b_clusters, dim3(k2r.full_round ? (unsigned)(h->n_cu * 4 * K2B_WAVES) : 256u, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
-				hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+				if (!k2r.full_round)	/* (complete tables leave nothing to verify) */
+					hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
 			}
 			HIPCHK(h, hipGetLastError());
 		}
