@@ -365,6 +365,27 @@ def test_resolver_builds_the_clusters_it_is_not_given(built, oracle, monkeypatch
     assert _gpu_keys(got) == want and len(want) >= 20
 
 
+def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracle):
+    """More than 4096 trigger candidates of one channel in one push (500 short bursts in 10 s of air time): the
+    parallel tables are unusable for that push and the channel is handled by the serial machine -- slower, and
+    still the oracle's bursts; the next, ordinary push goes through the tables again."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    n = 20_000_000
+    spec = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=110.0, info_max=4)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    assert len(want) >= 450
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=n) as rx:
+        got = rx.run(raw, block=n)
+        st = rx.stats()
+        assert _gpu_keys(got) == want
+        assert st["serial_samples"] > 400_000 and st["overflowed"] == 0     # most of the push's 840 000 decimated samples
+        s0 = st["serial_samples"]
+        rx.push(raw[:4_000_000])        # 2 M samples: far below the tables' capacity
+        rx.poll()
+        assert rx.stats()["serial_samples"] - s0 < 100_000
+
+
 def test_pipelined_polling_delivers_everything_once(built, oracle):
     """vdl2gpu_poll_ready (non-blocking) + a final vdl2gpu_poll: two pushes in flight, every burst
     handed out exactly once, in stream-time order per poll."""
