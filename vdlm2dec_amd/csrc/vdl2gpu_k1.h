@@ -308,6 +308,11 @@ template <int FMT> __global__ __launch_bounds__(K1P_THREADS, 6)
 void k1_pp(K1PParams p)
 {
 	constexpr int B = K1Fmt<FMT>::BYTES, SPB = K1Fmt<FMT>::SPB;
+#ifdef K1P_DBG
+	const int dbg = p.dbg;	/* development switches (VDL2GPU_K1_DBG): 1 no mixing, 2 no loads after the first chunk, 4 no stores, .. */
+#else
+	constexpr int dbg = 0;	/* (as run-time tests they were seven branches in every block of 8 samples) */
+#endif
 	constexpr int NPIECE = K1P_CH / SPB;			/* 16-byte pieces per period and chunk */
 	constexpr int NPT = (64 * NPIECE + K1P_THREADS - 1) / K1P_THREADS;	/* pieces per thread */
 	__shared__ float2 xs[8 + 64 * K1P_XROW + 8];	/* 8 entries of pad on either side: blocks of 8 are read whole */
@@ -356,7 +361,7 @@ void k1_pp(K1PParams p)
 	for (int j = 0; j < NPT; ++j)
 		rr[j] = *reinterpret_cast<const uint4 *>(lptr[j] + (long long)m0 * K1P_CH * B);
 	for (int m = m0; m <= m1; ++m) {
-		if (!(p.dbg & 8))
+		if (!(dbg & 8))
 			__syncthreads();	/* the previous chunk has been read by every wave */
 #pragma unroll
 		for (int j = 0; j < NPT; ++j)
@@ -367,14 +372,14 @@ void k1_pp(K1PParams p)
 				for (int u = 0; u < SPB; ++u)
 					xs[lcol[j] + u] = cv[u];
 			}
-		if (m < m1 && !(p.dbg & 2)) {
+		if (m < m1 && !(dbg & 2)) {
 #pragma unroll
 			for (int j = 0; j < NPT; ++j)
 				rr[j] = *reinterpret_cast<const uint4 *>(lptr[j] + (long long)(m + 1) * K1P_CH * B);
 		}
-		if (!(p.dbg & 8))
+		if (!(dbg & 8))
 			__syncthreads();
-		if (!active || (p.dbg & 1))
+		if (!active || (dbg & 1))
 			continue;
 		const int cb = m * K1P_CH - p.d;	/* period-relative index of the chunk's first sample */
 		const int hi = (i_stop < cb + K1P_CH) ? i_stop : cb + K1P_CH;
@@ -391,14 +396,14 @@ void k1_pp(K1PParams p)
 			for (; n >= 8; n -= 8) {
 				v16f w;
 				v2f xr[8];
-				if (p.dbg & 16) {
+				if (dbg & 16) {
 					w = (v16f)(1.0f);
 #pragma unroll
 					for (int u = 0; u < 8; ++u)
 						xr[u] = acc;
-				} else if (p.dbg & 512)
+				} else if (dbg & 512)
 					k1_load_block_nos(w, xr, lp, xa);
-				else if (p.dbg & 1024)
+				else if (dbg & 1024)
 					k1_load_block_nol(w, xr, lp, xa);
 				else
 					k1_load_block(w, xr, lp, xa);
@@ -406,19 +411,19 @@ void k1_pp(K1PParams p)
 #pragma unroll
 					for (int u = 0; u < 8; ++u)
 						k1_rmac_s(acc, xr[u].x, (v2f){w[2 * u], w[2 * u + 1]});
-				} else if (!(p.dbg & 64))
+				} else if (!(dbg & 64))
 					k1_cmac8_s(acc, xr, w);
 				lp += 8;
 				xa += 64;
 			}
-			if (n && !(p.dbg & 128)) {
+			if (n && !(dbg & 128)) {
 				/* the tail: read the 8 entries that END with it (what lies before is the row's or the table's
 				 * front pad or earlier samples) and enter the unrolled sequence n steps before its end */
 				v16f w;
 				v2f xr[8];
-				if (p.dbg & 512)
+				if (dbg & 512)
 					k1_load_block_nos(w, xr, lp - (8 - n), xa - (unsigned)(8 - n) * 8u);
-				else if (p.dbg & 1024)
+				else if (dbg & 1024)
 					k1_load_block_nol(w, xr, lp - (8 - n), xa - (unsigned)(8 - n) * 8u);
 				else
 					k1_load_block(w, xr, lp - (8 - n), xa - (unsigned)(8 - n) * 8u);
@@ -435,7 +440,7 @@ void k1_pp(K1PParams p)
 				}
 #undef K1_TAIL
 			}
-			if (i > wend && (p.dbg & 256)) {
+			if (i > wend && (dbg & 256)) {
 				acc = (v2f){0.0f, 0.0f};
 				++k;
 				if (k < k1) {
@@ -468,7 +473,7 @@ void k1_pp(K1PParams p)
 #pragma unroll
 					for (int it = 0; it < 4; ++it) {
 						const int pp = it * 16 + (lane >> 2), q = lane & 3;
-						if (pp < nper && 2 * q < slot && !(p.dbg & 4)) {
+						if (pp < nper && 2 * q < slot && !(dbg & 4)) {
 							const float2 v0 = os[c][(2 * q) * K1P_OROW + pp];
 							float2 *dst = decp + (long long)pp * K1P_PER_OUT + kflush + 2 * q;
 							if (2 * q + 1 < slot) {
