@@ -66,6 +66,11 @@ CONFIGS = {
 }
 
 
+def synth_default():
+    from vdlm2dec_amd import synth
+    return synth.DEFAULT_FO_8CH
+
+
 def make_tile(seed: int, fmt: str, rate: int, fos):
     from vdlm2dec_amd import synth
     spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0, info_max=240)   # the same traffic per channel-second at every rate

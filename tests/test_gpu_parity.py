@@ -202,6 +202,25 @@ def test_channeliser_push_sizes_around_its_tickets(built, oracle, fmt, nch):
         assert len(g) == len(d) and np.array_equal(d.view(np.uint32), g.view(np.uint32)), (fmt, nch, c)
 
 
+@pytest.mark.parametrize("fmt", ["cs16", "cu8"])
+def test_long_pushes_are_cut_into_parts(built, oracle, monkeypatch, fmt):
+    """A push longer than ~36 s of air time is cut into equal parts inside the library (the tables hold what a busy
+    channel triggers in about that long); here the limit is lowered to 262144 samples: bursts and the 84 kS/s planes
+    are those of the oracle, and of the same recording pushed whole."""
+    spec = S.regimes(seed=311)
+    assert spec.nsamples > 3 * 262144       # four parts
+    raw = synth.synth_stream(spec, fmt)
+    want = sorted(b.key() for b in oracle.run_oracle(raw, fmt, spec.rate, spec.fo, S.FC))
+    with _rx(spec.rate, spec.fo, fmt, max_push=spec.nsamples, keep_dec=True) as rx:
+        whole = _gpu_keys(rx.run(raw))
+    monkeypatch.setenv("VDL2GPU_SPLIT_SAMPLES", "262144")
+    with _rx(spec.rate, spec.fo, fmt, max_push=spec.nsamples, keep_dec=True) as rx:
+        rx.push(raw)
+        got = rx.poll()
+        assert rx.stats()["samples_in"] == spec.nsamples
+    assert _gpu_keys(got) == want == whole and len(want) >= 10
+
+
 def test_empty_and_invalid_pushes(built):
     from vdlm2dec_amd import lib
     with _rx(2_000_000, [-50000], "cu8", max_push=4096) as rx:

@@ -119,6 +119,7 @@ struct vdl2gpu {
 	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
 	int rounds_floor = 0;		/* many channels: one (complete) round is always scheduled, see create */
+	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked */
 	unsigned redos_seen = 0, repairs_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -596,6 +597,9 @@ static int create_impl(vdl2gpu_t *h)
 	/* A push in which a channel's verify pass fails with no round scheduled costs a serial redo of that channel's whole
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
 	 * round is always scheduled. */
+	h->split_samples = (size_t)(36.0 * (double)h->cfg.sdrinrate) / 32768 * 32768;
+	if (getenv("VDL2GPU_SPLIT_SAMPLES"))
+		h->split_samples = (size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES"));
 	h->rounds_floor = (h->S * h->C >= 16) ? 1 : 0;
 	h->repair_rounds = h->rounds_floor;
 	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
@@ -776,7 +780,22 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 		h->err = "an earlier HIP error left the handle unusable: " + h->err;
 		return VDL2GPU_EHIP;
 	}
-	const int rc = push_impl(h, iq, nsamples, stream_stride_bytes, memkind, wait_copy);
+	/* A push carries at most ~36 s of air time through the tables: their 4096 trigger candidates per channel are what a
+	 * busy channel produces in about that long, and a channel that overflows them is handled by the serial machine for
+	 * the whole push (40 ms for a 54 s push of 8 channels).  Longer pushes are cut into equal parts (multiples of the
+	 * reference's 32768-sample block, which VDL2GPU_F_RTL_QUIRK needs anyway); any cut gives the same bursts. */
+	int rc = VDL2GPU_OK;
+	const size_t lim = h ? h->split_samples : 0;
+	if (!h || !iq || lim == 0 || nsamples <= lim)
+		rc = push_impl(h, iq, nsamples, stream_stride_bytes, memkind, wait_copy);
+	else {
+		if (nsamples > h->cfg.max_push)
+			return VDL2GPU_EINVAL;
+		const size_t parts = (nsamples + lim - 1) / lim;
+		const size_t part = ((nsamples + parts - 1) / parts + 32767) / 32768 * 32768;
+		for (size_t off = 0; off < nsamples && rc == VDL2GPU_OK; off += part)
+			rc = push_impl(h, (const char *)iq + off * h->sample_bytes, std::min(part, nsamples - off), stream_stride_bytes, memkind, wait_copy);
+	}
 	if (rc == VDL2GPU_EHIP)
 		h->failed = true;	/* part of the push may be enqueued: nothing after it can be trusted */
 	return rc;

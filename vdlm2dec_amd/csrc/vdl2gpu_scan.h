@@ -35,7 +35,7 @@
 #ifndef K2A_WL
 #define K2A_WL 192		/* screened-in evaluations per tile and sub-phase; more than that and the tile is done in pieces */
 #endif
-#define VDL2_REG_CAP 1024	/* probe-hit regions per channel per push */
+#define VDL2_REG_CAP 4096	/* probe-hit regions per channel per push (noise alone seeds ~100 per million 84 kS/s samples) */
 #ifndef VDL2_REG_PAD
 #define VDL2_REG_PAD 40
 #endif
@@ -708,10 +708,10 @@ void k2r_regions(K2Params p)
 		__syncthreads();
 		if (tid == 0) {
 			const int n = s_nreg;
+			/* more regions than the list holds: the surplus is dropped -- regions are a cost decision, what a
+			 * missing one would have found the verify pass finds (and a repair round scans the channel completely) */
 			p.ctl[CTL_NREG0 + sc] = (unsigned)(n > VDL2_REG_CAP ? VDL2_REG_CAP : n);
 			p.ctl[CTL_NSEED0 + sc] = 0;	/* the seed list now collects what K2a-verify finds */
-			if (n > VDL2_REG_CAP)
-				p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 1u;	/* tables unusable -> serial */
 		}
 	}
 }
