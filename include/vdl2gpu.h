@@ -84,7 +84,8 @@ typedef struct {
 				 * what a busy channel produces in roughly 40 s; a channel that exceeds them in a push is handled by
 				 * the serial machine for that push (exact, ~100x slower; stats.serial_samples shows it).  A push
 				 * longer than 36 s of air time (72 MS at 2 MS/s) is therefore cut into equal parts inside the
-				 * library -- the bursts are the same for any cut. */
+				 * library -- the bursts are the same for any cut -- and the parts are halved whenever a channel's
+				 * tables overflow all the same (doubled again after 1024 pushes without one). */
 	int32_t device;		/* HIP device ordinal */
 	uint32_t max_bursts;	/* burst-record ring capacity (0 = default 65536) */
 	uint32_t flags;		/* VDL2GPU_F_* */

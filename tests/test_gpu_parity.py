@@ -405,6 +405,26 @@ def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracl
         assert rx.stats()["serial_samples"] - s0 < 100_000
 
 
+def test_overflowing_pushes_are_cut_shorter_from_then_on(built, oracle):
+    """The same dense recording pushed whole again and again: after the first overflows the library halves the parts
+    it cuts pushes into until the tables hold a part's candidates -- the last pushes do not touch the serial machine,
+    and every burst is still the oracle's."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    n, reps = 20_000_000, 7
+    spec = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=110.0, info_max=4)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(np.tile(raw, reps), "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=n) as rx:
+        got, serial = [], []
+        for _ in range(reps):
+            rx.push(raw)
+            got += rx.poll()
+            serial.append(rx.stats()["serial_samples"])
+    assert _gpu_keys(got) == want
+    assert serial[0] > 400_000                              # the first push went through the serial machine
+    assert serial[-1] - serial[-2] < 100_000                # the last one through the tables
+
+
 def test_pipelined_polling_delivers_everything_once(built, oracle):
     """vdl2gpu_poll_ready (non-blocking) + a final vdl2gpu_poll: two pushes in flight, every burst
     handed out exactly once, in stream-time order per poll."""

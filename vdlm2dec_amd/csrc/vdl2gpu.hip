@@ -119,7 +119,10 @@ struct vdl2gpu {
 	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
 	int rounds_floor = 0;		/* many channels: one (complete) round is always scheduled, see create */
-	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked */
+	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked; halved
+					 * whenever a channel's candidate tables overflow */
+	size_t split_default = 0;
+	unsigned long long last_ovf_push = 0;
 	unsigned redos_seen = 0, repairs_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -598,6 +601,7 @@ static int create_impl(vdl2gpu_t *h)
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
 	 * round is always scheduled. */
 	h->split_samples = (size_t)(36.0 * (double)h->cfg.sdrinrate) / 32768 * 32768;
+	h->split_default = h->split_samples;
 	if (getenv("VDL2GPU_SPLIT_SAMPLES"))
 		h->split_samples = (size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES"));
 	h->rounds_floor = (h->S * h->C >= 16) ? 1 : 0;
@@ -1317,6 +1321,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k3.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
 		k3.host_cnt = h->d_pin_cnt + 24 * ring;
 		k3.ring = ring;
+		k3.ctl = h->d_ctl;
+		k3.nstreams = h->S;
 		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
@@ -1365,6 +1371,18 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	const unsigned c0 = h->h_pin_cnt[24 * ring], c1 = h->h_pin_cnt[24 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
+	{
+		/* a channel whose candidates overflowed the tables went through the serial machine (milliseconds): cut the
+		 * pushes into shorter parts from now on; back up slowly when it has been quiet for long */
+		const unsigned novf = h->h_pin_cnt[24 * ring + 7];
+		if (novf && !getenv("VDL2GPU_SPLIT_SAMPLES")) {
+			h->split_samples = std::max<size_t>(8 * 32768, h->split_samples / 2 / 32768 * 32768);
+			h->last_ovf_push = h->ring_push[ring];
+		} else if (h->split_samples < h->split_default && h->ring_push[ring] > h->last_ovf_push + 1024) {
+			h->split_samples = std::min(h->split_default, h->split_samples * 2);
+			h->last_ovf_push = h->ring_push[ring];
+		}
+	}
 	{
 		/* repair rounds only cost launches while nothing fails, so: none until the first verify
 		 * failure shows up (as a serial redo), then as many as it takes to get rid of the serial

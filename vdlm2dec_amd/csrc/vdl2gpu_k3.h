@@ -69,6 +69,13 @@ __global__ void k3_rebase(K3Params p)
 			p.host_cnt[4 + i] = p.fcnt ? p.fcnt[i] : 0u;
 		for (int i = 0; i < 16; ++i)
 			p.host_cnt[8 + i] = p.fmask[i];
+		/* channels that went through the serial machine because their candidates did not fit the tables: the host
+		 * shortens the parts it cuts pushes into */
+		unsigned novf = 0;
+		for (int sc = 0; sc < p.nstreams * VDL2_CS; ++sc)
+			if (sc % VDL2_CS < p.nbch && (p.ctl[CTL_CAND0 + sc] > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc]))
+				++novf;
+		p.host_cnt[7] = novf;
 	}
 	StreamState *ss = p.ss + s;
 	long long mn = 0x7fffffffffffffffLL;

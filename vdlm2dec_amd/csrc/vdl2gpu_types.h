@@ -185,8 +185,11 @@ struct K3Params {
 	const unsigned *outc;	/* device counters: [2*ring] records, [2*ring+1] dropped, [4] serial redos so far */
 	const unsigned *fmask;	/* K2f's redo mask of this push (16 words) */
 	const unsigned *fcnt;	/* block path in the pipeline (VDL2GPU_F_FRAMES): frames, dropped, bytes; else nullptr */
-	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4..6]: frame counters) */
+	unsigned *host_cnt;	/* the same, in pinned host memory, for this push's ring ([4..6]: frame counters, [7]: channels whose
+				 * candidate tables overflowed in this push) */
 	int ring;
+	const unsigned *ctl;	/* the push's control words */
+	int nstreams;
 };
 
 struct KInitParams {		/* per-push reset of the demodulator's control words */
