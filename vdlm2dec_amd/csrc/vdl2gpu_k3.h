@@ -58,6 +58,15 @@ __global__ void k_push_init(KInitParams p)
 __global__ void k3_rebase(K3Params p)
 {
 	const int s = blockIdx.x;
+	/* channels that went through the serial machine because their candidates did not fit the tables (the host then
+	 * shortens the parts it cuts pushes into): one lane per channel slot, not one load after the other */
+	unsigned novf = 0;
+	if (s == 0)
+		for (int sc = (int)threadIdx.x; sc < (p.nstreams * VDL2_CS + 63) / 64 * 64; sc += 64) {
+			const bool over = sc < p.nstreams * VDL2_CS && sc % VDL2_CS < p.nbch &&
+					  (p.ctl[CTL_CAND0 + sc] > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc]);
+			novf += (unsigned)__popcll(__ballot(over));
+		}
 	if (threadIdx.x != 0)
 		return;
 	if (s == 0) {
@@ -69,12 +78,6 @@ __global__ void k3_rebase(K3Params p)
 			p.host_cnt[4 + i] = p.fcnt ? p.fcnt[i] : 0u;
 		for (int i = 0; i < 16; ++i)
 			p.host_cnt[8 + i] = p.fmask[i];
-		/* channels that went through the serial machine because their candidates did not fit the tables: the host
-		 * shortens the parts it cuts pushes into */
-		unsigned novf = 0;
-		for (int sc = 0; sc < p.nstreams * VDL2_CS; ++sc)
-			if (sc % VDL2_CS < p.nbch && (p.ctl[CTL_CAND0 + sc] > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc]))
-				++novf;
 		p.host_cnt[7] = novf;
 	}
 	StreamState *ss = p.ss + s;
