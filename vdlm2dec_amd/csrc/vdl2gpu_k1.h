@@ -745,7 +745,7 @@ void k1_fast(K1Params p)
 #endif
 	/* LDS: every window has its own row of 25 float2 (24 samples + 1 of padding: rows of 50 dwords put the 8 windows of
 	 * a half-wave read on 8 different bank pairs; laid end to end, windows 4 apart -- 95 or 96 samples -- shared banks),
-	 * two copies used in turn (one barrier per iteration) */
+	 * a pair of slices per iteration, two copies of the pair used in turn (one barrier per iteration) */
 	__shared__ float2 xs[2][2][16 * 25 + 8];	/* [copy][half of the pair] */
 	__shared__ int s_next;
 	const int tid = threadIdx.x;
@@ -757,23 +757,21 @@ void k1_fast(K1Params p)
 	 * wavefront's store is four whole, aligned lines.  (Runs of 64 bytes -- 8 windows per wavefront -- reached HBM as
 	 * partial lines once the read stream pushed them out of the L2 before their other halves arrived: the same
 	 * traffic moved in 128 us instead of 86, scripts/micro/store_shape.hip.)
-	 * Workgroup group w handles superperiods per_lo + w, + w + NW, + w + 2 NW, ..: at every iteration the grid reads
-	 * one contiguous band of NW superperiods and writes one contiguous band of each plane.  Workgroup b runs on XCD
-	 * b % 8: b = (group_hi * 21 + role) * 8 + group_lo keeps a group's roles -- neighbouring lines -- on one L2.
 	 *
 	 * The kernel is built around what a SIMD needs to stay busy: one wavefront issues a packed operation every 9 cycles
-	 * at best, four of them together one every 3.5 (scripts/micro/clock_rate.hip) -- three to four wavefronts per SIMD
-	 * must be mixing at any time.  Hence 96 registers (5 wavefronts per SIMD: the 24 LO values of the lane's window take
-	 * 48 of them, samples come from LDS four at a time), and a grid that is resident as a whole (the launch sizes it;
-	 * a workgroup's start-up -- window table, LO values, first samples: three memory round trips -- is paid once
-	 * per ~70 iterations instead of once per 23). */
+	 * at best, four of them together one every 3.5, eight one every 1.5 - 2 (scripts/micro/clock_rate.hip, valu_rate.hip)
+	 * -- three to four wavefronts per SIMD must be mixing at any time.  Hence 96 registers (5 wavefronts per SIMD: the
+	 * 24 LO values of the lane's window take 48 of them, samples come from LDS four at a time), and a grid that is
+	 * resident as a whole (the launch sizes it): a workgroup's start-up -- cold code, LO values, first samples -- is
+	 * paid once per ~70 superperiods. */
 	/* Work is handed out in TICKETS of K1F_CHUNK superperiods.  Workgroup b runs on XCD x = b % 8 and has role
 	 * g = (b / 8) % 21; the workgroups of one (role, XCD) form a family that shares a counter and takes the superperiods
 	 * per_lo + x + 8 i, i = 0, 1, .. in chunks: ticket t = i in [t C, t C + C).  The first ticket of a workgroup is its
 	 * rank in the family, the next one comes from the counter while the current one is being worked on -- a workgroup on
 	 * a SIMD that advances slowly (more wavefronts, a busier CU, another kernel's wavefronts beside it) simply takes
 	 * fewer tickets.  With a fixed share each the launch lasted as long as its slowest SIMD: 104 us for wavefronts that
-	 * lived 88 us on average. */
+	 * lived 88 us on average.  A family's superperiods are neighbours of the other roles' on the same XCD: at any time the
+	 * grid reads one contiguous band of the input and writes one contiguous band of each plane, each L2 its own eighth. */
 	const int x = (int)(blockIdx.x & 7);
 	const int g = (int)((blockIdx.x >> 3) % K1F_ROLES);
 	const int rank = (int)(blockIdx.x / (8 * K1F_ROLES)), nfam = (int)(gridDim.x / (8 * K1F_ROLES));
