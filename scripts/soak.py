@@ -26,7 +26,22 @@ while time.time() < t_end:
     want = sorted(b.key() for b in ob)
     block = int(rng.choice([ns, ns // 2 + 17, 1_234_567, 400_000, 2_000_000, 65536]))
     frames_too = bool(seed & 1)  # every other scenario also runs the block path in the pipeline
-    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16), frames=frames_too) as rx:
+    # the knobs the library adapts by itself, exercised from the start: repair rounds (the last one is the complete
+    # rescan), short parts for long pushes, clusters withheld from K2b, the region scan dropped (verify must catch up)
+    for k in ("VDL2GPU_REPAIR_ROUNDS", "VDL2GPU_SPLIT_SAMPLES", "VDL2GPU_PRIM_DROP"):
+        os.environ.pop(k, None)
+    mode = int(rng.integers(0, 6))
+    if mode == 1:
+        os.environ["VDL2GPU_REPAIR_ROUNDS"] = str(int(rng.integers(1, 4)))
+    elif mode == 2:
+        os.environ["VDL2GPU_SPLIT_SAMPLES"] = str(int(rng.choice([262144, 524288, 1 << 20])))
+    elif mode == 3:
+        os.environ["VDL2GPU_PRIM_DROP"] = str(int(rng.integers(2, 6)))
+    flags = 0
+    if mode in (1, 4):
+        from vdlm2dec_amd import lib as _lib
+        flags = _lib.F_TEST_NOREGION
+    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16), frames=frames_too, flags=flags) as rx:
         got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in rx.run(raw, block=block))
         gotf = sorted(rx.poll_frames()) if frames_too else []
         st = rx.stats()
@@ -35,7 +50,7 @@ while time.time() < t_end:
         wantf = sorted((0, b.chn, f) for b in ob for f in O.frames_of_block(b.nbrow, b.nlbyte, b.data))
         ok = ok and gotf == wantf
     n_ok += ok; n_bad += (not ok)
-    print("seed %d rate %d ch %d %s ns %d dens %.0f block %d: %d bursts %s redos %d" % (seed, rate, nch, fmt, ns, dens, block, len(want), "OK" if ok else "MISMATCH", st["serial_redos"]), flush=True)
+    print("seed %d rate %d ch %d %s ns %d dens %.0f block %d mode %d: %d bursts %s redos %d" % (seed, rate, nch, fmt, ns, dens, block, mode, len(want), "OK" if ok else "MISMATCH", st["serial_redos"]), flush=True)
     seed += 1
 print("soak: %d ok, %d bad" % (n_ok, n_bad))
 sys.exit(1 if n_bad else 0)
