@@ -455,10 +455,13 @@ def main():
         okt = torch.tensor([1 if ok_local else 0], device=dev, dtype=torch.int32)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok_all = bool(okt.item())
-        allrecs, counts, _ = shard.run_sharded(nstreams_total, lambda idx: shard.pack_records(timed, stream_offset=idx.start))
+        g = shard.run_sharded(nstreams_total, lambda idx: shard.pack_records(timed, stream_offset=idx.start))
+        allrecs, counts, _ = g
         total_bursts = int(sum(counts))
+        # counts + per-rank digests reach every rank (40 bytes each); the records only rank 0, point to point in chunks
         gathered = {"records_on_rank0": int(len(allrecs)), "per_rank": counts,
-                    "digest": shard.digest(allrecs).hex()[:16] if rank == 0 else None}
+                    "digest": shard.digest(allrecs).hex()[:16] if rank == 0 else None,
+                    "digest_of_rank_digests": g.combined.hex()[:16]}
     else:
         ok_all = ok_local
         total_bursts = int(len(timed))

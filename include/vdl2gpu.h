@@ -93,13 +93,18 @@ typedef struct {
 
 #define VDL2GPU_F_KEEP_DEC 1u	/* accepted for compatibility: the last push's decimated stream is always kept (vdl2gpu_debug_dec) */
 #define VDL2GPU_F_FULLSCAN 4u	/* scan all four FIR sub-phases everywhere instead of probe + regions + verify */
-#define VDL2GPU_F_TEST_NOREGION 8u	/* test hook: drop the region scan; the verify pass must then redo channels serially */
+#define VDL2GPU_F_TEST_NOREGION 8u	/* test hook: drop the region scan; the verify pass must then redo channels serially.  Only
+					 * libvdl2gpu_test.so (the same sources with -DVDL2GPU_TESTHOOKS) honours it, together with the
+					 * VDL2GPU_PRIM_DROP / VDL2GPU_SPLIT_SAMPLES environment handicaps; libvdl2gpu.so rejects the
+					 * flag with VDL2GPU_EINVAL and never reads those variables */
 #define VDL2GPU_F_FRAMES 16u	/* run the block path (RS, HDLC, FCS) on every push's bursts as well: vdl2gpu_poll_frames() */
 #define VDL2GPU_F_SERIAL 2u	/* diagnostics: skip the parallel sync tables, one serial machine per channel */
 #define VDL2GPU_F_RTL_QUIRK 32u	/* cu8 only: reproduce in_callback() as written (rtl.c:285-292): in every hand-off block of
 				 * 32768 samples, sample k is stored at index k+1, index 0 stays 0 and the last sample is
 				 * lost -- what the reference decodes on a real RTL stick.  Every push must
 				 * then be a whole number of 32768-sample blocks (RTLINBUFSZ/2, vdlm2.h:35). */
+
+#define VDL2GPU_F_DEBUG_HEADS 64u	/* diagnostics: keep the header soft bits of every sync trigger of the last push (vdl2gpu_debug_heads) */
 
 /* One decoded burst = the msgblk_t fields the DSP fills (vdlm2.h:39-47). */
 typedef struct {
@@ -181,7 +186,10 @@ int vdl2gpu_sync(vdl2gpu_t *h);
  * (end_sample, stream, chn).  Returns the count (>=0) or a negative error.
  * The host keeps what has been fetched from the GPU and not yet handed out in two bounded queues (bursts;
  * with VDL2GPU_F_FRAMES also frames): a consumer that drains only one of them loses the OLDEST entries of the
- * other once it holds more than 4 x max_bursts (counted in vdl2gpu_stats_t.overflowed / frames dropped). */
+ * other once it holds more than 4 x max_bursts unread ones (counted in vdl2gpu_stats_t.overflowed / frames
+ * dropped).  Memory: the storage behind a queue is compacted as soon as its handed-out prefix is the larger part,
+ * so it holds at most 2 x the unread records plus one push's worth -- <= 9 x max_bursts records of 2104 bytes
+ * (1.2 GB with the default max_bursts = 65536 and a consumer that never polls; a few MB with one that does). */
 int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Same, but never waits: hands out only the bursts of pushes the GPU has already finished.  Lets
  * a caller keep the next push running while it consumes the previous one (two pushes can be in
@@ -274,6 +282,11 @@ int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n);
 int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, int max_segs);
 /* Development cycle counters of the demodulator kernels (meaning is internal). */
 int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int n, int reset);
+/* With VDL2GPU_F_DEBUG_HEADS: the descrambled header soft bits (what viterbi_add() is given, d8psk.c:81-83) of every
+ * sync trigger ANY kernel of the last push handled -- the clusters of all timing classes, on the real chain or not,
+ * and the serial stretches --, 34 x uint32 per entry: nstar (lo, hi), stream * 8 + channel slot, clk0, then the float
+ * bits of p2err, perr, err, pfr and soft[25], one word of padding.  Unordered.  Returns the count (<= max_entries). */
+int vdl2gpu_debug_heads(vdl2gpu_t *h, uint32_t *out, int max_entries);
 /* Device build of the fixed-sequence atan2f, elementwise (host arrays). */
 int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x, float *out, size_t n);
 

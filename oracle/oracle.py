@@ -29,7 +29,7 @@ class VoBlock(C.Structure):
 class VoTrigger(C.Structure):
     _fields_ = [("dec_index", C.c_int64), ("p2err", C.c_float), ("perr", C.c_float), ("err", C.c_float),
                 ("pfr", C.c_float), ("of", C.c_float), ("clk", C.c_int32), ("accepted", C.c_int32),
-                ("len_bits", C.c_int32)]
+                ("len_bits", C.c_int32), ("nhead", C.c_int32), ("head", C.c_float * 25)]
 
 
 def build(force: bool = False) -> str:
@@ -140,7 +140,13 @@ class OracleChannel:
         n = self.L.vo_num_triggers(self.h)
         p = self.L.vo_triggers(self.h)
         return [dict(dec_index=p[i].dec_index, p2err=p[i].p2err, perr=p[i].perr, err=p[i].err, pfr=p[i].pfr,
-                     of=p[i].of, clk=p[i].clk, accepted=p[i].accepted, len_bits=p[i].len_bits) for i in range(n)]
+                     of=p[i].of, clk=p[i].clk, accepted=p[i].accepted, len_bits=p[i].len_bits,
+                     head=np.array(p[i].head[:p[i].nhead], np.float32)) for i in range(n)]
+
+    def heads(self) -> np.ndarray:
+        """every soft bit given to the header Viterbi (viterbi_add, d8psk.c:83), in call order"""
+        t = self.triggers()
+        return np.concatenate([x["head"] for x in t]) if t else np.zeros(0, np.float32)
 
     def dec(self) -> np.ndarray:
         n = self.L.vo_num_dec(self.h)

@@ -281,6 +281,10 @@ static void take_bit(vo_chan *c, float sv)
 	case ST_HEAD:
 		if (c->nbits < 3)
 			v = 0;
+		{
+			vo_trigger *th = &c->trigs[c->ntrigs - 1];	/* tap: tests/golden/*.json hold the real reference's digest of these */
+			th->head[th->nhead++] = v;
+		}
 		header_viterbi_step(c, v, (int)c->nbits);
 		if (++c->nbits < 25)
 			return;

@@ -42,6 +42,8 @@ typedef struct {
 	int32_t clk;		/* (int)roundf(of) */
 	int32_t accepted;	/* 1 = header accepted, 0 = rejected (d8psk.c:97-107) */
 	int32_t len_bits;
+	int32_t nhead;		/* header soft bits taken so far (25 unless the stream ended inside the header) */
+	float head[25];		/* what viterbi_add() is given, in call order: descrambled, bits 0..2 forced to 0 (d8psk.c:81-83) */
 } vo_trigger;
 
 typedef struct vo_chan vo_chan;

@@ -41,7 +41,7 @@ while time.time() < t_end:
     if mode in (1, 4):
         from vdlm2dec_amd import lib as _lib
         flags = _lib.F_TEST_NOREGION
-    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16), frames=frames_too, flags=flags) as rx:
+    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16), frames=frames_too, flags=flags, testhooks=True) as rx:
         got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in rx.run(raw, block=block))
         gotf = sorted(rx.poll_frames()) if frames_too else []
         st = rx.stats()

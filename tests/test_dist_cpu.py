@@ -39,18 +39,28 @@ def _decode(O, specs, raws, idxs):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, chunk):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
     specs, raws = _streams()
     # the decoder is injected: here the oracle, on the GPU box a Receiver (bench.py) -- sharding + gather are shared
-    allrecs, counts, mine = shard.run_sharded(NSTREAMS, lambda idx: shard.pack_bursts(_decode(O, specs, raws, idx)), dst=0)
+    own = {}
+
+    def decode(idx):
+        own["recs"] = shard.pack_bursts(_decode(O, specs, raws, idx))
+        return own["recs"]
+
+    g = shard.run_sharded(NSTREAMS, decode, dst=0, chunk_records=chunk)
+    allrecs, counts, mine = g
     assert list(mine) == list(shard.shard_streams(NSTREAMS, rank, world))
+    if rank != 0:
+        # a rank that is not the destination gets no records back and allocates nothing beyond its own for the exchange
+        assert len(allrecs) == 0 and g.peak_extra_bytes == 0
+    assert g.digests[rank] == shard.digest(own["recs"]) and counts[rank] == len(own["recs"])
     dist.barrier()
-    if rank == 0:
-        q.put((counts, shard.digest(allrecs), len(allrecs)))
+    q.put((rank, counts, g.combined, [d.hex() for d in g.digests], shard.digest(allrecs) if rank == 0 else None, len(allrecs)))
     dist.destroy_process_group()
 
 
@@ -79,22 +89,32 @@ def test_shard_partition_is_exact():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_gather_equals_single_process(oracle):
+@pytest.mark.parametrize("world,chunk", [(2, 4096), (3, 5), (2, 1)])
+def test_gloo_gather_equals_single_process(oracle, world, chunk):
+    """world-size 2 and 3 over gloo: counts and digests reach EVERY rank (40 bytes each), the records only rank 0,
+    point to point and in chunks (chunk = 5 and 1 records: several sends per rank); the gathered set, its digest and
+    the digest of digests equal the single-process decode."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, chunk)) for r in range(world)]
     for p in procs:
         p.start()
-    counts, dig, n = q.get(timeout=120)
+    res = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     specs, raws = _streams()
     ref = _decode(oracle, specs, raws, range(NSTREAMS))
     recs = shard.pack_bursts(ref)
-    assert n == len(ref) and sum(counts) == n and n >= 6
-    assert counts == [sum(1 for b in ref if b.stream in shard.shard_streams(NSTREAMS, r, 2)) for r in range(2)]
-    assert dig == shard.digest(recs)
+    want_counts = [sum(1 for b in ref if b.stream in shard.shard_streams(NSTREAMS, r, world)) for r in range(world)]
+    want_combined = shard.combined_digest(recs, NSTREAMS, world)
+    for rank, counts, combined, digests, dig0, n in res:
+        assert counts == want_counts and combined == want_combined      # every rank, not only the destination
+        assert digests == res[0][3]
+        if rank == 0:
+            assert n == len(ref) and n >= 6 and dig0 == shard.digest(recs)
+        else:
+            assert n == 0 and dig0 is None

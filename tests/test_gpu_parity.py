@@ -173,7 +173,8 @@ def test_channeliser_push_sizes_around_its_tickets(built, oracle, fmt, nch):
     if fmt == "f32" and nch > 4:
         pytest.skip("real input: mirror-image offsets interfere; covered with 1 and 3 channels")
     fos = S.FO8_AIR_5MS[:nch] if fmt == "f32" else S.FO8[:nch]
-    sizes = [24000, 25001, 8000 * 5 + 3, 8000 * 11 + 123, 8000 * 18, 8000 * 19 + 7999, 8000 * 66 + 5, 8000 * 130 + 77, 8000 * 9]
+    # (the first three start on a window boundary and are whole superperiods: k1_fast takes them alone, no general launch)
+    sizes = [24000, 8000 * 4, 8000 * 17, 25001, 8000 * 5 + 3, 8000 * 11 + 123, 8000 * 18, 8000 * 19 + 7999, 8000 * 66 + 5, 8000 * 130 + 77, 8000 * 9]
     n = sum(sizes)
     rng = np.random.default_rng(4242 + nch)
     if fmt == "cs16":
@@ -213,8 +214,8 @@ def test_long_pushes_are_cut_into_parts(built, oracle, monkeypatch, fmt):
     want = sorted(b.key() for b in oracle.run_oracle(raw, fmt, spec.rate, spec.fo, S.FC))
     with _rx(spec.rate, spec.fo, fmt, max_push=spec.nsamples, keep_dec=True) as rx:
         whole = _gpu_keys(rx.run(raw))
-    monkeypatch.setenv("VDL2GPU_SPLIT_SAMPLES", "262144")
-    with _rx(spec.rate, spec.fo, fmt, max_push=spec.nsamples, keep_dec=True) as rx:
+    monkeypatch.setenv("VDL2GPU_SPLIT_SAMPLES", "262144")     # a handicap of libvdl2gpu_test.so; the product library ignores it
+    with _rx(spec.rate, spec.fo, fmt, max_push=spec.nsamples, keep_dec=True, testhooks=True) as rx:
         rx.push(raw)
         got = rx.poll()
         assert rx.stats()["samples_in"] == spec.nsamples
@@ -247,6 +248,27 @@ def test_multi_stream_batch_equals_single_streams(built, oracle):
         want = sorted(b.key() for b in oracle.run_oracle(raws[s][:n], "cs16", sp.rate, sp.fo, S.FC))
         mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
         assert mine == want and len(want) >= 8
+
+
+@pytest.mark.parametrize("nch,nstr", [(4, 2), (3, 3), (1, 5)])
+def test_multi_stream_with_fewer_than_eight_channels(built, oracle, nch, nstr):
+    """Several streams of fewer than 8 channels each, on the parallel path (pushes longer than the serial machine's
+    4096 frames): the payload kernel addresses (stream, channel) slots as stream * 8 + channel like every other kernel
+    (round 2's grid spanned nbch * nstreams slots and never decoded the channels of streams >= 1)."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    specs = [synth.random_scenario(2_000_000, S.FO8[:nch], 600_000, seed=500 + 10 * nch + i, bursts_per_s=40.0, info_max=60) for i in range(nstr)]
+    raws = [synth.synth_stream(sp, "cs16") for sp in specs]
+    raw = np.stack(raws)
+    with Receiver(2_000_000, [plan_channels(S.FC, sp.fo) for sp in specs], fmt="cs16", max_push=300_000) as rx:
+        got = rx.run(raw, block=300_000)      # 12 600 frames per push
+        assert rx.stats()["serial_samples"] < 100_000
+    total = 0
+    for s, sp in enumerate(specs):
+        want = sorted(b.key() for b in oracle.run_oracle(raws[s], "cs16", sp.rate, sp.fo, S.FC))
+        mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
+        assert mine == want, s
+        total += len(want)
+    assert total >= 6 * nstr
 
 
 def test_device_resident_input(built, oracle):
@@ -379,7 +401,7 @@ def test_resolver_builds_the_clusters_it_is_not_given(built, oracle, monkeypatch
     spec = synth.random_scenario(2_000_000, S.FO8[:4], 1 << 21, seed=97 + drop, bursts_per_s=12.0, info_max=90)
     raw = synth.synth_stream(spec, "cs16")
     want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
-    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20) as rx:
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20, testhooks=True) as rx:
         got = rx.run(raw, block=700_000)
     assert _gpu_keys(got) == want and len(want) >= 20
 

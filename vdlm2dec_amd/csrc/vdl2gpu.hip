@@ -126,6 +126,9 @@ struct vdl2gpu {
 	unsigned redos_seen = 0, repairs_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
+	HeadTap *d_headtap = nullptr;	/* VDL2GPU_F_DEBUG_HEADS: every trigger of the last push (any kernel) */
+	unsigned *d_headtap_n = nullptr;
+	unsigned headtap_cap = 0;
 	uint64_t total_in = 0;		/* samples per stream pushed so far */
 	uint64_t pushes = 0;
 	uint64_t overflowed = 0;
@@ -152,6 +155,22 @@ struct vdl2gpu {
 	unsigned pin_recs = 0;
 	bool failed = false;	/* a HIP call failed while work was being enqueued: device and host state no longer agree */
 	std::string err;
+	/* Environment knobs, read ONCE in create_impl (INTEGRATION.md lists them): push_impl never calls getenv.
+	 * The test handicaps (VDL2GPU_PRIM_DROP, VDL2GPU_SPLIT_SAMPLES, VDL2GPU_F_TEST_NOREGION) exist only in the
+	 * library built with -DVDL2GPU_TESTHOOKS (libvdl2gpu_test.so, which the tests load). */
+	struct {
+		bool k1_early = false;		/* VDL2GPU_K1_EARLY: start the channeliser beside the previous push's scan */
+		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
+		bool k1_pp = false;		/* VDL2GPU_K1_PP: k1_pp at 2 MS/s as well */
+		bool debug_counters = false;	/* VDL2GPU_DEBUG_COUNTERS: cycle counters of the demodulator kernels */
+		bool split_fixed = false;	/* (test hook) the part length was given: do not adapt it */
+		int k1f_nfam = 0;		/* VDL2GPU_K1F_NFAM */
+		int k1_dbg = 0;			/* VDL2GPU_K1_DBG */
+		int k1_nsub = 0;		/* VDL2GPU_K1_NSUB */
+	} knob;
+	/* stage sums of the pushes that carried stage events, unscaled, and how many those were */
+	double st_scan = 0, st_cluster = 0, st_resolve = 0, st_demod = 0, st_other = 0;
+	uint64_t st_pushes = 0;
 };
 
 /* ------------------------------------------------------------ pure host helpers */
@@ -503,6 +522,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_prim);
 	(void)hipFree(h->d_seeds);
 	(void)hipFree(h->d_dbg);
+	(void)hipFree(h->d_headtap);
+	(void)hipFree(h->d_headtap_n);
 	if (h->h_pin)
 		(void)hipHostFree(h->h_pin);
 	if (h->h_pin_cnt)
@@ -590,24 +611,34 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_sidx, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	HIPCHK(h, hipMalloc(&h->d_seeds, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
+	/* every environment knob is read here, once */
+	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
-	if (getenv("VDL2GPU_STAGE_EVERY"))
-		h->stage_every = std::max(1, atoi(getenv("VDL2GPU_STAGE_EVERY")));
-	if (getenv("VDL2GPU_K2D_GRID"))
-		h->k2d_grid = std::max(1, atoi(getenv("VDL2GPU_K2D_GRID")));
-	if (getenv("VDL2GPU_PRIM_DROP"))
-		h->prim_drop = atoi(getenv("VDL2GPU_PRIM_DROP"));
+	h->stage_every = std::max(1, env_int("VDL2GPU_STAGE_EVERY", h->stage_every));
+	h->k2d_grid = std::max(1, env_int("VDL2GPU_K2D_GRID", h->k2d_grid));
+	h->knob.k1_early = getenv("VDL2GPU_K1_EARLY") != nullptr;
+	h->knob.no_k1_fast = getenv("VDL2GPU_NO_K1_FAST") != nullptr;
+	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
+	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
+	h->knob.k1f_nfam = env_int("VDL2GPU_K1F_NFAM", 0);
+	h->knob.k1_dbg = env_int("VDL2GPU_K1_DBG", 0);
+	h->knob.k1_nsub = env_int("VDL2GPU_K1_NSUB", 0);
+#ifdef VDL2GPU_TESTHOOKS
+	h->prim_drop = env_int("VDL2GPU_PRIM_DROP", 0);
+#endif
 	/* A push in which a channel's verify pass fails with no round scheduled costs a serial redo of that channel's whole
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
 	 * round is always scheduled. */
 	h->split_samples = (size_t)(36.0 * (double)h->cfg.sdrinrate) / 32768 * 32768;
 	h->split_default = h->split_samples;
-	if (getenv("VDL2GPU_SPLIT_SAMPLES"))
+#ifdef VDL2GPU_TESTHOOKS
+	if (getenv("VDL2GPU_SPLIT_SAMPLES")) {
 		h->split_samples = (size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES"));
+		h->knob.split_fixed = true;
+	}
+#endif
 	h->rounds_floor = (h->S * h->C >= 16) ? 1 : 0;
-	h->repair_rounds = h->rounds_floor;
-	if (getenv("VDL2GPU_REPAIR_ROUNDS"))
-		h->repair_rounds = atoi(getenv("VDL2GPU_REPAIR_ROUNDS"));
+	h->repair_rounds = env_int("VDL2GPU_REPAIR_ROUNDS", h->rounds_floor);
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->quirk = (cfg.flags & VDL2GPU_F_RTL_QUIRK) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
@@ -628,6 +659,12 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pin_cnt, h->h_pin_cnt, 0));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
 	HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, 64 * sizeof(unsigned long long), h->stream));
+	if (cfg.flags & VDL2GPU_F_DEBUG_HEADS) {
+		h->headtap_cap = 1u << 18;
+		HIPCHK(h, hipMalloc(&h->d_headtap, (size_t)h->headtap_cap * sizeof(HeadTap)));
+		HIPCHK(h, hipMalloc(&h->d_headtap_n, sizeof(unsigned)));
+		HIPCHK(h, hipMemsetAsync(h->d_headtap_n, 0, sizeof(unsigned), h->stream));
+	}
 
 	std::vector<float2> lo((size_t)S * VDL2_CS * L, make_float2(0.f, 0.f));
 	std::vector<ChanCfg> cc((size_t)S * VDL2_CS, ChanCfg{ 0, 0, 0, 0 });
@@ -690,6 +727,10 @@ extern "C" int vdl2gpu_create(const vdl2gpu_config_t *cfg, vdl2gpu_t **out)
 		return VDL2GPU_EINVAL;
 	if ((cfg->flags & VDL2GPU_F_RTL_QUIRK) && cfg->fmt != VDL2GPU_FMT_CU8)
 		return VDL2GPU_EINVAL;	/* the quirk is in_callback()'s, and that only ever sees cu8 */
+#ifndef VDL2GPU_TESTHOOKS
+	if (cfg->flags & VDL2GPU_F_TEST_NOREGION)
+		return VDL2GPU_EINVAL;	/* test handicaps are compiled into libvdl2gpu_test.so only */
+#endif
 	const unsigned sdrclk = cfg->sdrclk ? cfg->sdrclk : cfg->sdrinrate / 4000;
 	if (sdrclk <= 21 || sdrclk > 1000000)
 		return VDL2GPU_EINVAL;
@@ -747,13 +788,13 @@ static int harvest_timing(vdl2gpu_t *h)
 			d[0] = a + b + c;
 		}
 		h->tm.channelise_ms += d[0];
-		if (pt.staged) {	/* one push in stage_every carries the chain's events: it stands for all of them */
-			const double k = (double)h->stage_every;
-			h->tm.scan_ms += k * (d[1] + d[4]);
-			h->tm.cluster_ms += k * d[2];
-			h->tm.resolve_ms += k * (d[3] + d[5]);
-			h->tm.demod_ms += k * (d[1] + d[2] + d[3] + d[4] + d[5]);
-			h->tm.other_ms += k * d[6];
+		if (pt.staged) {	/* only some pushes carry the chain's events: their mean stands for all (see vdl2gpu_get_timing) */
+			h->st_scan += d[1] + d[4];
+			h->st_cluster += d[2];
+			h->st_resolve += d[3] + d[5];
+			h->st_demod += d[1] + d[2] + d[3] + d[4] + d[5];
+			h->st_other += d[6];
+			h->st_pushes++;
 		}
 		if (pt.fast) {
 			float f = 0;
@@ -980,7 +1021,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	/* start beside the previous push's candidate sort, not beside its scan: the first period's small kernel
 	 * runs there, so that the big one starts the moment the resolver does (waiting with both until then
 	 * saves an event record, 3 us, and loses 15) */
-	if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))
+	if (h->k2_mid_rec && !h->knob.k1_early)
 		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid_a, 0));
 	HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
@@ -1006,7 +1047,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		 * window) and the tail on the general one */
 		const long long periods = J / K1P_PER_OUT;
 		const int per_in = 4 * h->sdrclk;
-		bool fast = (per_in % h->L == 0 && periods >= 4 && !h->quirk && !getenv("VDL2GPU_NO_K1_FAST"));
+		bool fast = (per_in % h->L == 0 && periods >= 4 && !h->quirk && !h->knob.no_k1_fast &&
+			     std::min(K1P_CH, h->maxwin) <= h->L);	/* k1_pp steps its LO index by a piece (<= a chunk, <= a window) and wraps it once */
 		K1PParams kp{};
 		if (fast) {
 			auto wend_abs = [&](long long j) { return ((j + 1) * (long long)h->sdrclk - k1.c0 + 20) / 21 - 1; };
@@ -1020,19 +1062,25 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			kp.d = (int)((a0 % 16) / h->sample_bytes);
 		}
 		const long long nsp = periods / 4;	/* superperiods of 4 periods = 336 outputs = 21 lines of the planes */
-		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && nsp >= 3 && !getenv("VDL2GPU_K1_PP") &&
+		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && nsp >= 3 && !h->knob.k1_pp &&
 				    (size_t)h->cap * VDL2_CS * sizeof(float2) < (1ull << 32);	/* k1_fast addresses a stream's planes with 32-bit offsets */
 		if (fast2m) {
 			/* 2 MS/s: the LO values of a window fit a lane's registers (lane = window x channel).  Whole superperiods in
-			 * the middle; the first one (carried partial window) and the tail on the general kernel */
-			generic(0, K1F_PER_OUT - 1);
+			 * the middle; the first one (carried partial window) and the tail on the general kernel -- unless the push
+			 * starts on a window boundary of the schedule (c0 == 0: nothing carried in) and is a whole number of
+			 * superperiods (nothing carried out): then the fast kernel takes all of it and the two general launches
+			 * (36 us each for 0.02 % of the samples: launch and latency, not work) are not made at all. */
+			const bool whole = k1.c0 == 0 && nsamples % K1F_PER_IN == 0 && J == nsp * K1F_PER_OUT;
+			if (!whole)
+				generic(0, K1F_PER_OUT - 1);
 			(void)hipEventRecord(pt.e[11], ks);	/* the wait for the resolver that follows is not channeliser time */
 			pt.fast = true;
-			k1.per_lo = 1;
-			k1.per_n = nsp - 2;
+			k1.per_lo = whole ? 0 : 1;
+			k1.per_n = whole ? nsp : nsp - 2;
+			k1.edge_state = whole ? 1 : 0;
 			k1.lo_ext = h->d_lo_ext;
 			k1.lo_stride = h->L + 48;
-			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
+			if (h->k2_mid_rec && !h->knob.k1_early)	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
 			(void)hipEventRecord(pt.e[8], ks);
 			/* The grid is resident as a whole: n_cu * 2 * K1F_WAVES_OF(fmt) workgroups of two wavefronts fit.  Per stream
@@ -1047,8 +1095,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				long long nfam = slots / per_fam;
 				if (nfam < 4 && (nfam + 1) * per_fam * 100 <= slots * 108)
 					++nfam;
-				if (getenv("VDL2GPU_K1F_NFAM"))
-					nfam = atoi(getenv("VDL2GPU_K1F_NFAM"));
+				if (h->knob.k1f_nfam > 0)
+					nfam = h->knob.k1f_nfam;
 				const long long tickets = ((k1.per_n + 7) / 8 + K1F_CHUNK - 1) / K1F_CHUNK;	/* of the family with the most */
 				nfam = std::max<long long>(1, std::min(nfam, tickets));
 				ngrp = nfam * 8;
@@ -1071,7 +1119,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			}
 			(void)hipEventRecord(pt.e[9], ks);
 			pt.fast_parts = 1;
-			generic((nsp - 1) * K1F_PER_OUT, J);
+			if (!whole)
+				generic((nsp - 1) * K1F_PER_OUT, J);
 		} else if (fast) {
 			generic(0, K1P_PER_OUT - 1);
 			(void)hipEventRecord(pt.e[11], ks);
@@ -1099,7 +1148,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			auto proven = [](int nf) { return nf == 23 || nf == 24 || nf == 59 || nf == 60 || nf == 71 || nf == 72 || nf == 119 || nf == 120; };
 			kp.fast_div = proven(nfmin) && proven(nfmax) && nfmax - nfmin <= 1;
 			kp.nf_lo = nfmin;
-			kp.dbg = getenv("VDL2GPU_K1_DBG") ? atoi(getenv("VDL2GPU_K1_DBG")) : 0;
+			kp.dbg = h->knob.k1_dbg;
 			kp.rcp_lo = 1.0f / (float)nfmin;
 			kp.rcp_hi = 1.0f / (float)(nfmin + 1);
 			/* tasks = (blocks of 64 periods) x (runs of wpt windows): enough of them that the last round of
@@ -1118,11 +1167,11 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 					best = nsub;
 				}
 			}
-			if (getenv("VDL2GPU_K1_NSUB"))
-				best = atoi(getenv("VDL2GPU_K1_NSUB"));
+			if (h->knob.k1_nsub > 0)
+				best = h->knob.k1_nsub;
 			kp.nsub = best;
 			kp.wpt = K1P_PER_OUT / best;
-			if (h->k2_mid_rec && !getenv("VDL2GPU_K1_EARLY"))	/* beside the previous push's resolver */
+			if (h->k2_mid_rec && !h->knob.k1_early)	/* beside the previous push's resolver */
 				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
 			(void)hipEventRecord(pt.e[8], ks);
 			const dim3 grid((unsigned)(blocks * kp.nsub), (unsigned)h->S);
@@ -1182,12 +1231,22 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.rec_cap = h->rec_cap;
 		/* A short push (a live SDR block is 1376 frames per channel) is cheaper on the serial machine alone
 		 * than through the scan's ten launches: the parallel path only pays from a few thousand frames on. */
-		const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !(h->cfg.flags & VDL2GPU_F_TEST_NOREGION));
+#ifdef VDL2GPU_TESTHOOKS
+		const bool noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) != 0;
+#else
+		const bool noregion = false;
+#endif
+		const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !noregion);
 		k2.force_serial = serial ? 1 : 0;
 		k2.prim_drop = h->prim_drop;
-		k2.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
+		k2.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
+		k2.headtap = h->d_headtap;
+		k2.headtap_n = h->d_headtap_n;
+		k2.headtap_cap = h->headtap_cap;
+		if (h->d_headtap)
+			HIPCHK(h, hipMemsetAsync(h->d_headtap_n, 0, sizeof(unsigned), h->stream));
 		k2.full_scan = h->full_scan;
-		k2.test_noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) ? 1 : 0;
+		k2.test_noregion = noregion ? 1 : 0;
 		k2.regs = h->d_regs;
 		k2.segs = h->d_segs;
 		k2.fail = h->d_fail;
@@ -1235,7 +1294,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (spec) {
 			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
 			HIPCHK(h, hipStreamWaitEvent(h->pay_stream, h->k2c_done, 0));
-			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
 			HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
 		}
 		if (staged)
@@ -1281,10 +1340,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			if (h->repair_rounds > 0 && !h->full_scan && !serial) {
 				K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
 				k2p.pay_final = 1;
-				hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2p);
+				hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2p);
 			}
 		} else
-			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(h->C * h->S)), dim3(K2D_NT), 0, h->stream, k2);
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2);
 		HIPCHK(h, hipGetLastError());
 		if (h->frames_on) {
 			/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
@@ -1300,7 +1359,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			k4.compact = 1;
 			k4.tabs = h->d_k4tab;
 			k4.fmask = h->ring_spec[ring] ? h->d_fmask : nullptr;
-			k4.dbg = getenv("VDL2GPU_DEBUG_COUNTERS") ? h->d_dbg : nullptr;
+			k4.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
 			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 16), dim3(K4_NT), 0, h->stream, k4);
 			HIPCHK(h, hipGetLastError());
 		}
@@ -1375,7 +1434,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		/* a channel whose candidates overflowed the tables went through the serial machine (milliseconds): cut the
 		 * pushes into shorter parts from now on; back up slowly when it has been quiet for long */
 		const unsigned novf = h->h_pin_cnt[24 * ring + 7];
-		if (novf && !getenv("VDL2GPU_SPLIT_SAMPLES")) {
+		if (novf && !h->knob.split_fixed) {
 			h->split_samples = std::max<size_t>(8 * 32768, h->split_samples / 2 / 32768 * 32768);
 			h->last_ovf_push = h->ring_push[ring];
 		} else if (h->split_samples < h->split_default && h->ring_push[ring] > h->last_ovf_push + 1024) {
@@ -1412,7 +1471,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			h->ready.clear();
 			h->ready_idx.clear();
 			h->ready_pos = 0;
-		} else if (h->ready_pos > 2 * qmax) {	/* a long-lived backlog: drop the handed-out prefix of the storage */
+		} else if (h->ready_pos > 1024 && h->ready_pos > h->ready_idx.size() / 2) {	/* the handed-out prefix is the larger part of the storage: drop it
+											 * (so the storage never exceeds 2 x the unread records + one push: <= (8 + 1) x max_bursts records) */
 			std::vector<vdl2gpu_burst_t> keep;
 			keep.reserve(h->ready_idx.size() - h->ready_pos);
 			for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
@@ -1491,7 +1551,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 				h->fready.clear();
 				h->fready_idx.clear();
 				h->fready_pos = 0;
-			} else if (h->fready_pos > 8 * (size_t)h->rec_cap) {	/* compact: entries are self-delimiting */
+			} else if (h->fready_pos > 1024 && h->fready_pos > h->fready_idx.size() / 2) {	/* compact: entries are self-delimiting */
 				std::vector<uint8_t> keep;
 				std::vector<size_t> kidx;
 				const size_t hdr0 = offsetof(vdl2gpu_frame_t, data);
@@ -1764,8 +1824,21 @@ extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset
 	if (rc)
 		return rc;
 	*out = h->tm;
-	if (reset)
+	{
+		/* stage sums: mean of the pushes that carried stage events x all pushes (the staged ones are every
+		 * stage_every-th: scaling their sum by stage_every was biased whenever pushes % stage_every != 0) */
+		const double k = h->st_pushes ? (double)h->tm.pushes / (double)h->st_pushes : 0.0;
+		out->scan_ms = k * h->st_scan;
+		out->cluster_ms = k * h->st_cluster;
+		out->resolve_ms = k * h->st_resolve;
+		out->demod_ms = k * h->st_demod;
+		out->other_ms = k * h->st_other;
+	}
+	if (reset) {
 		h->tm = vdl2gpu_timing_t{};
+		h->st_scan = h->st_cluster = h->st_resolve = h->st_demod = h->st_other = 0;
+		h->st_pushes = 0;
+	}
 	return VDL2GPU_OK;
 }
 
@@ -1884,5 +1957,44 @@ extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, in
 	n = std::min<unsigned>(n, (unsigned)std::min(max_segs, VDL2_SEG_CAP));
 	if (n)
 		HIPCHK(h, hipMemcpy(out, h->d_segs + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+/* VDL2GPU_F_DEBUG_HEADS: the header soft bits of every sync trigger any kernel of the LAST push handled -- the
+ * clusters of all eight timing classes, the resolver's serial stretches, a serial redo --, 34 x 32-bit words each:
+ * {nstar lo, nstar hi, stream * 8 + channel slot, clk0, p2err, perr, err, pfr (float bits), soft[25] (float bits), pad}.
+ * Returns the number of entries written to `out` (<= max_entries), in no particular order. */
+extern "C" int vdl2gpu_debug_heads(vdl2gpu_t *h, uint32_t *out, int max_entries)
+{
+	if (!h || !out || max_entries < 0)
+		return VDL2GPU_EINVAL;
+	if (!h->d_headtap) {
+		h->err = "vdl2gpu_debug_heads needs VDL2GPU_F_DEBUG_HEADS";
+		return VDL2GPU_EINVAL;
+	}
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	unsigned n = 0;
+	HIPCHK(h, hipMemcpy(&n, h->d_headtap_n, sizeof n, hipMemcpyDeviceToHost));
+	n = std::min(n, h->headtap_cap);
+	n = std::min<unsigned>(n, (unsigned)max_entries);
+	std::vector<HeadTap> tmp(n);
+	if (n)
+		HIPCHK(h, hipMemcpy(tmp.data(), h->d_headtap, (size_t)n * sizeof(HeadTap), hipMemcpyDeviceToHost));
+	for (unsigned i = 0; i < n; ++i) {
+		uint32_t *o = out + 34 * (size_t)i;
+		const HeadTap &e = tmp[i];
+		o[0] = (uint32_t)((unsigned long long)e.nstar & 0xffffffffu);
+		o[1] = (uint32_t)((unsigned long long)e.nstar >> 32);
+		o[2] = (uint32_t)e.sc;
+		o[3] = (uint32_t)e.clk0;
+		memcpy(o + 4, &e.p2err, 4);
+		memcpy(o + 5, &e.perr, 4);
+		memcpy(o + 6, &e.err, 4);
+		memcpy(o + 7, &e.pfr, 4);
+		memcpy(o + 8, e.soft, 100);
+		o[33] = 0;
+	}
 	return (int)n;
 }

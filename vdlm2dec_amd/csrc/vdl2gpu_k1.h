@@ -778,6 +778,14 @@ void k1_fast(K1Params p)
 	const int n_x = ((int)p.per_n - x + 7) >> 3;			/* superperiods of this XCD */
 	if (rank * K1F_CHUNK >= n_x)	/* its first ticket is empty */
 		return;
+	if (p.edge_state && blockIdx.x == 0 && tid < VDL2_CS) {	/* (rank 0 of XCD 0: never empty) what k1_channelise leaves at a push's two ends */
+		StreamState *ss = p.ss + s;
+		if (tid == 0) {
+			ss->last_fill = ss->dec_fill;
+			ss->last_J = p.J;
+		}
+		ss->acc[p.parity ^ 1][tid] = make_float2(0.0f, 0.0f);	/* the push ends on a window boundary: nothing carried */
+	}
 	const unsigned *ctr = p.tickets + ((size_t)s * K1F_ROLES + g) * 8 + x;	/* ticket = nfam + (old value - tbase[x]) */
 	const unsigned tbase = p.tbase[x];
 	const int kk = lane >> 2, c = wv * 4 + (lane & 3);

@@ -167,6 +167,9 @@ struct MachCtx {
 	long long desc_static;	/* >= 0: descriptor slots are desc_static + burst index (K2b: no atomics) */
 	int sc;
 	unsigned long long *dbg;
+	HeadTap *headtap;	/* diagnostics, see K2Params */
+	unsigned *headtap_n;
+	unsigned headtap_cap;
 	long long t_lo, t_hi;	/* stream-time range currently held in the LDS tile (cluster mode) */
 	const float *grey;	/* 3 x 257 soft-bit tables in LDS, or nullptr -> constant memory */
 	unsigned *rec_count, *rec_ovf;
@@ -181,7 +184,7 @@ struct MachState {
 };
 
 struct MachOut {
-	int nslots, slots[VDL2_CL_MAXB];
+	int nslots, badslot;	/* descriptors made; one of them found the pool full (an array of the slots became a scratch object: only its sign was ever read) */
 	int ntrig, nrej, nburst, ndefer;
 	long long neval;
 };
@@ -340,102 +343,150 @@ struct MachTrig {
 	bool defer;		/* header or burst not completely inside the data held */
 };
 
-template <int NT, bool XL> __device__ MachTrig mach_trigger(MachSharedT<NT> &sh, MachCtx &cx, long long nstar,
-							     float p2err, float perr, float err, float pfr)
+/* ring_r >= 0 (K2b): the caller is rebuilding the 68-phase ring in front of the trigger in sub-phase ring_r and has
+ * filled sh.pbuf[0..63]; the last four phases (instants nstar-6 .. nstar) are computed here, in the same filter pass as
+ * the header symbols (a pass of its own for four lanes costs a wavefront as much as one for sixty-four). */
+template <int NT, bool XL> __device__ __forceinline__ MachTrig mach_trigger(MachSharedT<NT> &sh, MachCtx &cx, long long nstar,
+							     float p2err, float perr, float err, float pfr, int ring_r = -1)
 {
 	const int tid = threadIdx.x;
-	if (tid == 0) {
-		/* parabolic interpolation of the error minimum, d8psk.c:303-305 */
-		const float of = 4.0f * (p2err - 4.0f * perr + 3.0f * err) / (p2err - 2.0f * perr + err);
-		int clk0 = (int)roundf(of);
-		if (clk0 < 0)
-			clk0 = 0;	/* unreachable for finite inputs: of is in [4,12] */
-		if (clk0 > 68)
-			clk0 = 68;
-		int j0, rb0;
-		burst_timing(clk0, &j0, &rb0);
-		sh.ctl[0] = clk0;
-		sh.ctl[1] = j0;
-		sh.ctl[2] = rb0;
-		sh.fctl[0] = pfr;	/* df = pfr, d8psk.c:301 */
-	}
-	__syncthreads();
-	const int clk0 = sh.ctl[0], j0 = sh.ctl[1], rb = sh.ctl[2];
-	const float df = sh.fctl[0];
+	/* parabolic interpolation of the error minimum, d8psk.c:303-305 -- the same four numbers in every lane, so every
+	 * lane computes it (through LDS it was a store, a barrier and four loads) */
+	const float of = 4.0f * (p2err - 4.0f * perr + 3.0f * err) / (p2err - 2.0f * perr + err);
+	int clk0 = (int)roundf(of);
+	if (clk0 < 0)
+		clk0 = 0;	/* unreachable for finite inputs: of is in [4,12] */
+	if (clk0 > 68)
+		clk0 = 68;
+	int j0, rb;
+	burst_timing(clk0, &j0, &rb);
+	const float df = pfr;	/* df = pfr, d8psk.c:301 */
 	const long long nsym0 = nstar + j0;	/* stream time of burst symbol 0 */
 	bool defer = (nsym0 + 64 >= cx.avail_end);	/* 9 header symbols must be present */
 	int accepted = 0, nbrow = 0, nlbyte = 0, nsym = 0;
 	if (!defer) {
-		mach_need<NT, XL>(sh, cx, nstar - 16, nsym0 + 65);
-		if (tid < 9)
-			sh.psym[tid] = mach_fir<NT, XL>(sh, cx, nsym0 + 8 * tid, rb);
-		if (tid == 9)
-			sh.fctl[1] = mach_fir<NT, XL>(sh, cx, nstar, clk0);	/* P1 */
-		__syncthreads();
-		if (tid < 25) {
-			const int k = tid / 3;
-			const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
-			const int idx = k2_grey_index(sh.psym[k], pprev, df);
-			float v = mach_soft_bit(cx, idx, tid % 3, (int)((VDL2_PN_HEAD >> tid) & 1u));
-			if (tid < 3)
-				v = 0.0f;	/* reserved bits forced, d8psk.c:81-82 */
-			sh.hsoft[tid] = v;
+		mach_need<NT, XL>(sh, cx, nstar - (ring_r >= 0 ? 24 : 16), nsym0 + 65);
+		/* ONE filter pass: header symbols 0..8 (sub-phase rb), P1 = the trigger instant filtered with clk0 as first
+		 * tap (d8psk.c:306), and K2b's four ring phases (as separate passes each costs the wavefront a whole FIR + atan2f) */
+		if (tid < (ring_r >= 0 ? 14 : 10)) {
+			const long long n = tid < 9 ? nsym0 + 8 * tid : (tid == 9 ? nstar : nstar - 2LL * (13 - tid));
+			const int tap = tid < 9 ? rb : (tid == 9 ? clk0 : ring_r);
+			const float ph = mach_fir<NT, XL>(sh, cx, n, tap);
+			if (tid < 9)
+				sh.psym[tid] = ph;
+			else if (tid == 9)
+				sh.fctl[1] = ph;	/* P1 */
+			else
+				sh.pbuf[VDL2_NPH - 14 + tid] = ph;	/* ring entries 64..67 */
 		}
 		__syncthreads();
-		if (tid < 64) {
-			/* (25,20) code, 32 syndrome states = 32 lanes (viterbi.c:46-78).
-			 * Target state t has two candidates: bit 0 from state t, bit 1
-			 * from state t^H[n]; the reference visits sources in ascending
-			 * order and replaces a survivor only by a strictly larger metric. */
-			const int t = tid & 31;
-			double pb = (t == 0) ? 1.0 : 0.0;
-			for (int n = 0; n < 25; ++n) {
-				const double v = (double)sh.hsoft[n];
-				const int src1 = t ^ c_hcol[n];
-				const double pb1 = __shfl(pb, src1, 32);
-				const double m0 = pb * (1.0 - v);
-				const double m1 = pb1 * v;
-				const bool has0 = (pb != 0.0), has1 = (pb1 != 0.0);
-				double nv = 0.0;
-				int nb = 0, ns = 0;
-				if (t < src1) {
-					if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
-					if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
-				} else {
-					if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
-					if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
+		if (tid < 64) {	/* the first wavefront */
+			float v = 0.0f;
+			if (tid < 25) {
+				const int k = tid / 3;
+				const float pprev = k ? sh.psym[k - 1] : sh.fctl[1];
+				const int idx = k2_grey_index(sh.psym[k], pprev, df);
+				v = mach_soft_bit(cx, idx, tid % 3, (int)((VDL2_PN_HEAD >> tid) & 1u));
+				if (tid < 3)
+					v = 0.0f;	/* reserved bits forced, d8psk.c:81-82 */
+				sh.hsoft[tid] = v;
+			}
+			if (cx.headtap) {	/* diagnostics: uniform, off in production */
+				unsigned k = 0;
+				if (tid == 0)
+					k = atomicAdd(cx.headtap_n, 1u);
+				k = (unsigned)__shfl((int)k, 0, 64);
+				if (k < cx.headtap_cap) {
+					HeadTap *e = cx.headtap + k;
+					if (tid < 25)
+						e->soft[tid] = v;
+					if (tid == 0) {
+						e->nstar = nstar;
+						e->sc = cx.sc;
+						e->clk0 = clk0;
+						e->p2err = p2err;
+						e->perr = perr;
+						e->err = err;
+						e->pfr = pfr;
+					}
 				}
-				if (tid < 32) {
-					sh.vbk[n + 1][t] = (uint8_t)ns;
-					sh.vbv[n + 1][t] = (uint8_t)nb;
-				}
-				pb = nv;
+			}
+			/* The (25,20) decode (viterbi.c:46-96) is a max-product search over the codewords: metric = product of
+			 * v (bit 1) or 1 - v (bit 0) per position, in doubles.  If the hard decisions b_n = (v_n > 0.5) form a
+			 * codeword (syndrome 0: the path ends in state 0) and every v_n is at least 1e-3 away from 0.5, that word
+			 * is the decoder's output and the trellis need not be run: its metric takes the larger factor at every
+			 * position, any other path the smaller one somewhere, which is >= 0.4 % less -- eleven orders of magnitude
+			 * above what 25 roundings of a double product can move; products are monotone under rounding, so its
+			 * prefix wins every compare-select on the way (strictly: the reference's `>` never sees a tie), and no
+			 * metric underflows (v in [2e-6, 1-2e-6], d8psk.h).  Forced bits (v = 0) decide 0 in both.
+			 * Else: the reference's trellis, below. */
+			const bool one = tid < 25 && v > 0.5f;
+			const bool unsure = tid >= 3 && tid < 25 && fabsf(v - 0.5f) < 1e-3f;
+			const unsigned long long hb = __ballot(one);
+			const int hc = one ? c_hcol[tid < 25 ? tid : 0] : 0;
+			unsigned syn = 0;
+#pragma unroll
+			for (int k = 0; k < 5; ++k)
+				syn |= (unsigned)(__popcll(__ballot((hc >> k) & 1)) & 1) << k;
+			const bool quick = (syn == 0) && (__ballot(unsure) == 0ull);
+			if (tid == 0) {
+				sh.ctl[7] = quick ? 1 : 0;
+				sh.ctl[8] = (int)((hb >> 3) & 0x1ffffu);	/* len: header bit 3 + i is bit i of the length (d8psk.c:90-93 undo exactly that order) */
 			}
 		}
 		__syncthreads();
-		if (tid == 0) {
-			unsigned word = 0, mask = 1;
-			int sv = 0;
-			for (int n = 25; n > 0; --n) {
-				if (sh.vbv[n][sv])
-					word |= mask;
-				sv = sh.vbk[n][sv];
-				mask <<= 1;
+		if (!sh.ctl[7]) {	/* uniform */
+			if (tid < 64) {
+				/* (25,20) code, 32 syndrome states = 32 lanes (viterbi.c:46-78).
+				 * Target state t has two candidates: bit 0 from state t, bit 1
+				 * from state t^H[n]; the reference visits sources in ascending
+				 * order and replaces a survivor only by a strictly larger metric. */
+				const int t = tid & 31;
+				double pb = (t == 0) ? 1.0 : 0.0;
+				for (int n = 0; n < 25; ++n) {
+					const double v = (double)sh.hsoft[n];
+					const int src1 = t ^ c_hcol[n];
+					const double pb1 = __shfl(pb, src1, 32);
+					const double m0 = pb * (1.0 - v);
+					const double m1 = pb1 * v;
+					const bool has0 = (pb != 0.0), has1 = (pb1 != 0.0);
+					double nv = 0.0;
+					int nb = 0, ns = 0;
+					if (t < src1) {
+						if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
+						if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
+					} else {
+						if (has1 && m1 > nv) { nv = m1; nb = 1; ns = src1; }
+						if (has0 && m0 > nv) { nv = m0; nb = 0; ns = t; }
+					}
+					if (tid < 32) {
+						sh.vbk[n + 1][t] = (uint8_t)ns;
+						sh.vbv[n + 1][t] = (uint8_t)nb;
+					}
+					pb = nv;
+				}
 			}
-			word >>= 5;	/* drop the 5 parity bits, d8psk.c:90 */
-			unsigned len = 0;
-			for (int i = 0; i < 17; ++i)
-				len |= ((word >> i) & 1u) << (16 - i);	/* reversebits(.,17) */
-			const int nbr = (int)(len / 1992u) + 1;
-			const int nlb = (int)((len % 1992u + 7u) / 8u);
-			sh.ctl[3] = (len >= 96u && nbr <= 8) ? 1 : 0;
-			sh.ctl[4] = nbr;
-			sh.ctl[5] = nlb;
+			__syncthreads();
+			if (tid == 0) {
+				unsigned word = 0, mask = 1;
+				int sv = 0;
+				for (int n = 25; n > 0; --n) {
+					if (sh.vbv[n][sv])
+						word |= mask;
+					sv = sh.vbk[n][sv];
+					mask <<= 1;
+				}
+				word >>= 5;	/* drop the 5 parity bits, d8psk.c:90 */
+				sh.ctl[8] = (int)(__brev(word & 0x1ffffu) >> 15);	/* reversebits(.,17) */
+			}
+			__syncthreads();
 		}
-		__syncthreads();
-		accepted = sh.ctl[3];
-		nbrow = sh.ctl[4];
-		nlbyte = sh.ctl[5];
+		{
+			const unsigned len = (unsigned)sh.ctl[8];
+			nbrow = (int)(len / 1992u) + 1;
+			nlbyte = (int)((len % 1992u + 7u) / 8u);
+			accepted = (len >= 96u && nbrow <= 8) ? 1 : 0;
+		}
 		if (accepted) {
 			nsym = burst_geom(nbrow, nlbyte).nsym;
 			if (nsym0 + 8LL * (nsym - 1) >= cx.avail_end)
@@ -509,10 +560,8 @@ template <int NT, bool XL> __device__ __forceinline__ long long mach_commit_trig
 		const unsigned slot = (unsigned)sh.ctl[6];
 		if (!XL && !cx.desc && slot != 0xffffffffu)
 			burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg);
-#pragma unroll
-		for (int i = 0; i < VDL2_CL_MAXB; ++i)
-			if (out.nslots == i)
-				out.slots[i] = (int)slot;
+		if (slot == 0xffffffffu)
+			out.badslot = 1;
 		out.nslots++;
 		out.nburst++;
 	}
@@ -521,7 +570,7 @@ template <int NT, bool XL> __device__ __forceinline__ long long mach_commit_trig
 
 /* stop_steady: return MR_STEADY as soon as the detector is history-free and at least
  * `min_trig` triggers were handled.  first_nev: size of the first search window (a hint). */
-template <int NT, bool XL> __device__ int machine_run(MachSharedT<NT> &sh, MachCtx &cx, MachState &st, bool stop_steady,
+template <int NT, bool XL> __device__ __forceinline__ int machine_run(MachSharedT<NT> &sh, MachCtx &cx, MachState &st, bool stop_steady,
 					     int min_trig, int max_bursts, int first_nev, MachOut &out)
 {
 	const int tid = threadIdx.x;
@@ -620,6 +669,9 @@ __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, 
 	cx.pn = p.pn;
 	cx.sc = s * VDL2_CS + c;
 	cx.dbg = to_stage ? p.dbg : nullptr;
+	cx.headtap = p.headtap;
+	cx.headtap_n = p.headtap_n;
+	cx.headtap_cap = p.headtap_cap;
 	cx.t_lo = cx.t_hi = 0;
 	cx.grey = nullptr;
 	cx.sel = cx.nsel = nullptr;

@@ -57,8 +57,10 @@ void k2s_sort(K2Params p)
 				break;
 			}
 		}
+#ifdef VDL2GPU_TESTHOOKS
 		if (p.prim_drop > 0 && j % p.prim_drop == p.prim_drop - 1)
 			primary = false;
+#endif
 		int2 *head = p.clhead + (size_t)sc * VDL2_CAND_CAP + idx;
 		if (!primary)
 			*head = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
@@ -80,7 +82,7 @@ void k2s_sort(K2Params p)
  * again) and record where and how the idle search resumes.
  */
 #ifndef K2B_WAVES
-#define K2B_WAVES 4
+#define K2B_WAVES 3	/* 163 registers: with 4 (128) the compiler spilled 12-20 of them to scratch; the kernel's time does not depend on 3 / 4 / 6 wavefronts per SIMD */
 #endif
 __global__ __launch_bounds__(K2B_NT) __attribute__((amdgpu_waves_per_eu(K2B_WAVES, 8)))
 void k2b_clusters(K2Params p)
@@ -137,9 +139,7 @@ void k2b_clusters(K2Params p)
 		MachOut out;
 		out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
 		out.neval = 0;
-#pragma unroll
-		for (int i = 0; i < VDL2_CL_MAXB; ++i)
-			out.slots[i] = 0;
+		out.badslot = 0;
 		/* The candidate record holds what the detector saw when it fired -- the three fit errors and
 		 * the slope (the scan computed them with the detector's own arithmetic) --, so the trigger is
 		 * handled from those; what has to be rebuilt is the phase ring the detector returns to after
@@ -147,8 +147,8 @@ void k2b_clusters(K2Params p)
 		const long long t0 = wall_clock64();
 		const long long nstar = st.pos;
 		mach_need<K2B_NT, true>(sh, cx, nstar - 152, nstar + 1);
-		for (int i = tid; i < VDL2_NPH; i += K2B_NT)
-			sh.pbuf[i] = mach_fir<K2B_NT, true>(sh, cx, nstar - 2LL * (VDL2_NPH - 1 - i), st.r);
+		static_assert(K2B_NT == 64 && VDL2_NPH == 68, "ring rebuild: 64 phases here, the last 4 in mach_trigger's filter pass");
+		sh.pbuf[tid] = mach_fir<K2B_NT, true>(sh, cx, nstar - 2LL * (VDL2_NPH - 1 - tid), st.r);
 		if (tid == 0) {
 			sh.errs[0] = 500.0f;	/* errors re-armed (d8psk.c:308) */
 			sh.errs[1] = 500.0f;
@@ -158,7 +158,7 @@ void k2b_clusters(K2Params p)
 		const long long t1 = wall_clock64();
 		int rc;
 		{
-			const MachTrig tg = mach_trigger<K2B_NT, true>(sh, cx, nstar, cd.p2err, cd.perr, cd.err, cd.pfr);
+			const MachTrig tg = mach_trigger<K2B_NT, true>(sh, cx, nstar, cd.p2err, cd.perr, cd.err, cd.pfr, st.r);
 			if (tg.defer) {
 				out.ndefer++;
 				rc = MR_DEFER;
@@ -195,12 +195,7 @@ void k2b_clusters(K2Params p)
 			status = CL_DEFER_FIRST;
 		else
 			status = CL_NONSTEADY;
-		bool bad = false;
-#pragma unroll
-		for (int i = 0; i < VDL2_CL_MAXB; ++i)
-			if (i < out.nslots && out.slots[i] < 0)
-				bad = true;	/* descriptor pool full */
-		if (bad)
+		if (out.badslot)	/* descriptor pool full */
 			status = CL_INVALID;
 		if (status == CL_NONSTEADY)
 			mach_store(sh, st, &cl->saved);
@@ -324,6 +319,7 @@ void k2c_resolve(K2Params p)
 	mach_load(sh, cs);
 	MachOut out;
 	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.badslot = 0;
 	out.neval = 0;
 	unsigned long long n_slow = 0;
 	int ncand = (int)p.ctl[CTL_CAND0 + sc];
@@ -445,12 +441,19 @@ void k2c_resolve(K2Params p)
 	const long long tk2 = wall_clock64();
 	bool steady_end = false;
 	int nvis = 0;	/* slots of svis[] in use (thread 0's copy counts) */
+	bool replay = false;	/* a cluster K2b did not make (CL_INVALID) is replayed here, from its candidate's instant */
 	for (;;) {
-		if (!tables_ok || st.fresh < VDL2_STEADY) {
-			/* history-dependent stretch (or no tables): serial machine */
+		if (!tables_ok || st.fresh < VDL2_STEADY || replay) {
+			/* history-dependent stretch (or no tables): serial machine.  (ONE call site: inlined into the kernel,
+			 * its context stays in registers; with two the compiler made it a function and passed MachCtx /
+			 * MachState / MachOut through 264 bytes of scratch per lane.)  A replay runs until the detector is
+			 * history-free again behind at least one more trigger than the push has counted so far (a plain 1
+			 * returned at once, without progress, when an earlier trigger had been counted). */
 			const long long p0 = st.pos;
-			const int rc = machine_run<K2_NT, false>(sh, cx, st, tables_ok, 0, 1 << 30, 0, out);
-			n_slow += (unsigned long long)(st.pos - p0);
+			const int rc = machine_run<K2_NT, false>(sh, cx, st, tables_ok, replay ? out.ntrig + 1 : 0, 1 << 30, replay ? 1 : 0, out);
+			if (!replay)
+				n_slow += (unsigned long long)(st.pos - p0);
+			replay = false;
 			if (rc != MR_STEADY)
 				break;
 			continue;
@@ -531,14 +534,10 @@ void k2c_resolve(K2Params p)
 			break;
 		}
 		if (status == CL_INVALID) {
-			/* staging pool was full: replay this stretch here, until the detector is history-free again
-			 * behind at least this one trigger (out counts the whole push's: one more than it holds now;
-			 * a plain 1 returned at once, without progress, when an earlier trigger had been counted) */
+			/* no cluster for this candidate (not a primary, or the staging pool was full): replay the stretch at the top of the loop */
 			st.pos = ncand_t;
 			mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
-			const int rc = machine_run<K2_NT, false>(sh, cx, st, true, out.ntrig + 1, 1 << 30, 1, out);
-			if (rc != MR_STEADY)
-				break;
+			replay = true;
 			continue;
 		}
 		/* CL_NONSTEADY: its bursts count, then continue from the explicit state it stopped in */
@@ -686,6 +685,7 @@ void k2f_commit(K2Params p)
 	mach_load(sh, cs);
 	MachOut out;
 	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.badslot = 0;
 	out.neval = 0;
 	machine_run<K2_NT, false>(sh, cx, st, false, 0, 1 << 30, 0, out);
 	__syncthreads();
@@ -718,7 +718,9 @@ void k2d_payload(K2Params p)
 {
 	__shared__ unsigned s_slot;
 	__shared__ float sph[VDL2_MAXSYM];
-	const int sc = blockIdx.y;
+	const int sc = blockIdx.y;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of a stream */
+	if ((sc % VDL2_CS) >= p.nbch)
+		return;
 	/* second pass (pay_final): only the channels a repair round re-resolved behind the first pass's back; their records
 	 * are final (tag 1).  A channel K2f redid serially has nothing selected. */
 	if (p.pay_final && !(sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u)))

@@ -76,6 +76,15 @@ struct Seg {			/* the chain idled in class (r, parity of lo) over stream-relativ
 	int lo, hi, r, pad;
 };
 
+struct HeadTap {		/* diagnostics (VDL2GPU_F_DEBUG_HEADS): what one sync trigger gave the header decoder */
+	long long nstar;	/* stream time of the trigger */
+	int sc;			/* stream * 8 + channel slot */
+	int clk0;		/* (int)roundf(of), d8psk.c:305 */
+	float p2err, perr, err, pfr;	/* the detector's view at the trigger (d8psk.c:292-305) */
+	float soft[25];		/* descrambled header soft bits as viterbi_add() gets them (d8psk.c:81-83) */
+};
+static_assert(sizeof(HeadTap) == 132 || sizeof(HeadTap) == 136, "HeadTap layout");
+
 struct K1Params {
 	const void *raw;
 	size_t stream_stride;
@@ -86,6 +95,8 @@ struct K1Params {
 	long long N, J;
 	long long jbeg, jend;	/* generic kernel: outputs [jbeg, jend] (jend may be J = the carried tail) */
 	long long per_lo, per_n;	/* k1_fast: superperiods [per_lo, per_lo+per_n) */
+	int edge_state;		/* k1_fast covers the whole push (it starts and ends on a window boundary of the schedule: no carried
+				 * partial window): the launch also leaves the stream state the general kernel would (last_fill, last_J, empty carry) */
 	unsigned *tickets;	/* k1_fast: [S][21 roles][8 XCDs] work counters; never reset: */
 	unsigned tbase[8];	/* ... what the counters of XCD x hold when this launch starts (every launch adds the number of its tickets) */
 	const float2 *lo;	/* [S][8][L] */
@@ -160,6 +171,9 @@ struct K2Params {
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
 	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
 	unsigned long long *dbg;	/* diagnostics: cycle counters */
+	HeadTap *headtap;	/* diagnostics: every trigger any kernel of the push handled (nullptr: off) */
+	unsigned *headtap_n;
+	unsigned headtap_cap;
 };
 #define CTL_OUT 0
 #define CTL_OUT_OVF 1

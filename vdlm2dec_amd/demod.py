@@ -58,8 +58,9 @@ class Receiver:
     def __init__(self, sdrinrate: int, channels: Sequence[ThreadParam] | Sequence[Sequence[ThreadParam]],
                  fmt: str = "cu8", max_push: int = 1 << 22, device: int = 0, sdrclk: int = 0,
                  max_bursts: int = 0, keep_dec: bool = False, serial: bool = False, full_scan: bool = False,
-                 frames: bool = False, rtl_quirk: bool = False, flags: int = 0):
-        self.L = _lib.load()
+                 frames: bool = False, rtl_quirk: bool = False, flags: int = 0, testhooks: bool = False):
+        # testhooks: load libvdl2gpu_test.so, the build that honours F_TEST_NOREGION / VDL2GPU_PRIM_DROP / VDL2GPU_SPLIT_SAMPLES
+        self.L = _lib.load(testhooks=testhooks or bool(flags & _lib.F_TEST_NOREGION))
         if channels and isinstance(channels[0], ThreadParam):
             channels = [list(channels)]
         self.nstreams = len(channels)
@@ -245,6 +246,15 @@ class Receiver:
     def debug_cands(self, stream: int, ch: int, max_cands: int = 4096) -> np.ndarray:
         buf = np.zeros((max_cands, 6), np.int32)
         n = self._check(self.L.vdl2gpu_debug_cands(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
+        return buf[:n].copy()
+
+    def debug_heads(self, max_entries: int = 1 << 16) -> np.ndarray:
+        """Header soft bits of every trigger of the last push (needs flags=lib.F_DEBUG_HEADS): structured array
+        (nstar, sc, clk0, p2err, perr, err, pfr, soft[25])."""
+        dt = np.dtype([("nstar", "<i8"), ("sc", "<i4"), ("clk0", "<i4"), ("p2err", "<f4"), ("perr", "<f4"),
+                       ("err", "<f4"), ("pfr", "<f4"), ("soft", "<f4", (25,)), ("pad", "<u4")])
+        buf = np.zeros(max_entries, dt)
+        n = self._check(self.L.vdl2gpu_debug_heads(self.h, buf.ctypes.data_as(C.c_void_p), max_entries))
         return buf[:n].copy()
 
     def debug_counters(self, n: int = 16, reset: bool = True):

@@ -11,6 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvdl2gpu.so")
+LIB_TEST_PATH = os.path.join(_HERE, "libvdl2gpu_test.so")   # the same sources with -DVDL2GPU_TESTHOOKS (tests only)
 
 FMT = {"cu8": 0, "cs16": 1, "cf32": 2, "f32": 3}
 SAMPLE_BYTES = {"cu8": 2, "cs16": 4, "cf32": 8, "f32": 4}
@@ -21,6 +22,7 @@ F_FULLSCAN = 4
 F_TEST_NOREGION = 8
 F_FRAMES = 16
 F_RTL_QUIRK = 32
+F_DEBUG_HEADS = 64
 
 # every symbol include/vdl2gpu.h declares
 EXPORTS = (
@@ -29,7 +31,7 @@ EXPORTS = (
     "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "vdl2gpu_decode_blocks", "vdl2gpu_poll_frames", "vdl2gpu_poll_frames_ready", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
     "vdl2gpu_choose_fc_rtl", "vdl2gpu_choose_fc_air",
-    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs",
+    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs", "vdl2gpu_debug_heads",
 )
 
 
@@ -75,17 +77,18 @@ class Vdl2GpuError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libvdl2gpu.so; raises if the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(testhooks: bool = False):
+    """Load libvdl2gpu.so (or, for the tests' handicaps, libvdl2gpu_test.so); raises if the HIP
+    extension has not been built."""
+    if testhooks in _libs:
+        return _libs[testhooks]
+    path = LIB_TEST_PATH if testhooks else LIB_PATH
+    if not os.path.exists(path):
         raise Vdl2GpuError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     if not os.environ.get("VDL2GPU_NO_TORCH"):
         # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HSA runtimes in
@@ -95,7 +98,7 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.vdl2gpu_abi_version.restype = C.c_int
     L.vdl2gpu_create.restype = C.c_int
     L.vdl2gpu_create.argtypes = [C.POINTER(ConfigT), C.POINTER(C.c_void_p)]
@@ -158,7 +161,9 @@ def load():
     L.vdl2gpu_debug_segs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_cands.restype = C.c_int
     L.vdl2gpu_debug_cands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.vdl2gpu_debug_heads.restype = C.c_int
+    L.vdl2gpu_debug_heads.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_counters.restype = C.c_int
     L.vdl2gpu_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    _lib = L
+    _libs[testhooks] = L
     return L
