@@ -36,6 +36,30 @@
 extern int nbch;		/* main.c:59 */
 
 static channel_t g_ch[MAXNBCHANNELS];
+
+/* d8psk.c:295 stamps a burst with gettimeofday() when its sync word triggers, i.e. while the hand-off block that holds
+ * the trigger is being processed; out.c prints that stamp with every message.  Here bursts come back one or more blocks
+ * later, so the wall time of every push is kept (first input sample, timeval) and a burst gets the stamp of the push
+ * its trigger sample (vdl2gpu_burst_t.trig_sample) arrived in.  The longest burst spans 33 blocks at 2 MS/s. */
+#define NSTAMP 256
+static struct { unsigned long long first; struct timeval tv; } g_stamp[NSTAMP];
+static unsigned long long g_npush, g_nsamples;
+
+static void stamp_push(unsigned long long nsamples)
+{
+	gettimeofday(&g_stamp[g_npush % NSTAMP].tv, NULL);
+	g_stamp[g_npush % NSTAMP].first = g_nsamples;
+	g_npush++;
+	g_nsamples += nsamples;
+}
+
+static struct timeval stamp_of(long long sample)
+{
+	unsigned long long k = g_npush, oldest = g_npush > NSTAMP ? g_npush - NSTAMP : 0;
+	while (k > oldest + 1 && g_stamp[(k - 1) % NSTAMP].first > (unsigned long long)(sample < 0 ? 0 : sample))
+		k--;
+	return g_stamp[(k - 1) % NSTAMP].tv;	/* (a trigger older than the ring gets the oldest stamp kept) */
+}
 static volatile int g_ready;	/* channels initialised so far (channel 0 must be first, vdlm2.c:172) */
 
 int initD8psk(channel_t *ch)
@@ -58,7 +82,7 @@ static void deliver(vdl2gpu_t *h)
 		for (i = 0; i < nf; i++) {
 			memset(&blk, 0, sizeof blk);
 			vdl2gpu_burst_to_msgblk(&b[f[i].block], &blk, sizeof blk);
-			gettimeofday(&blk.tv, NULL);
+			blk.tv = stamp_of(b[f[i].block].trig_sample);	/* d8psk.c:295 */
 			out(&blk, f[i].data, f[i].len);
 		}
 		if (nf < 0)
@@ -79,7 +103,7 @@ static void deliver(vdl2gpu_t *h)
 			channel_t *ch = &g_ch[b[i].chn];
 			vdl2gpu_burst_to_msgblk(&b[i], ch->blk, sizeof(msgblk_t));
 			ch->df = b[i].df;			/* channel_t.df as d8psk.c:301 leaves it */
-			gettimeofday(&ch->blk->tv, NULL);	/* d8psk.c:295 stamps at sync; here at delivery */
+			ch->blk->tv = stamp_of(b[i].trig_sample);	/* d8psk.c:295: the time the block holding the sync trigger was handed over */
 			decodeVdlm2(ch);			/* takes ch->blk, installs a fresh zeroed one */
 		}
 		if (n < 64)
@@ -144,7 +168,9 @@ void *rcv_thread(void *arg)
 		pthread_barrier_wait(&Bar2);
 		if (h) {
 			/* returns once Cbuff has been copied out; demodulation continues asynchronously */
-			int rc = vdl2gpu_push(h, Cbuff, RTLINBUFSZ / 2, 0, VDL2GPU_MEM_HOST);
+			int rc;
+			stamp_push(RTLINBUFSZ / 2);
+			rc = vdl2gpu_push(h, Cbuff, RTLINBUFSZ / 2, 0, VDL2GPU_MEM_HOST);
 			if (rc)
 				fprintf(stderr, "vdl2gpu_push: %s (%s)\n", vdl2gpu_strerror(rc), vdl2gpu_last_error(h));
 		}

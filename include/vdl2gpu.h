@@ -208,6 +208,15 @@ const char *vdl2gpu_strerror(int code);
  * are compile-time constants of this library, so a host with another ABI must copy the fields itself)
  * from a burst record.  `msgblk` must point at sizeof(msgblk_t) zeroed bytes (calloc, as vdlm2.c:201);
  * msgblk_size is checked against 16624. */
+#define VDL2GPU_MSGBLK_OFF_CHN 8
+#define VDL2GPU_MSGBLK_OFF_FR 12
+#define VDL2GPU_MSGBLK_OFF_TV 16
+#define VDL2GPU_MSGBLK_OFF_PPM 32
+#define VDL2GPU_MSGBLK_OFF_NBROW 36
+#define VDL2GPU_MSGBLK_OFF_NLBYTE 40
+#define VDL2GPU_MSGBLK_OFF_DATA 44
+#define VDL2GPU_MSGBLK_SIZE 16624	/* oracle/ref_layout_check.c holds these against offsetof(msgblk_t, ..) of the reference's own vdlm2.h
+					 * with _Static_assert: `make -C oracle ref` fails if they ever disagree */
 int vdl2gpu_burst_to_msgblk(const vdl2gpu_burst_t *b, void *msgblk, size_t msgblk_size);
 
 /* ---- block path: what the reference's blk_thread does with a msgblk_t ----

@@ -217,8 +217,9 @@ def run_ref(path: str, fmt: str, rate: int, fo: int, fr: int, out_path: str, qui
         for line in f:
             p = line.split()
             if p[0] == "B":
+                tv = p[5][1:].split(".")     # "t<sec>.<usec>": the harness's gettimeofday is the sample clock
                 blocks.append(dict(nbrow=int(p[1]), nlbyte=int(p[2]), ppm=float(p[3]), df_bits=int(p[4], 16),
-                                   data=bytes.fromhex(p[5])))
+                                   tv=int(tv[0]) * 1_000_000 + int(tv[1]), data=bytes.fromhex(p[-1])))
             elif p[0] == "F":
                 frames.append(dict(nbrow=int(p[1]), nlbyte=int(p[2]), frame=bytes.fromhex(p[4])))
     taps = None

@@ -119,8 +119,10 @@ void __wrap_decodeVdlm2(channel_t * ch)
 	int r, i;
 	msgblk_t *b = ch->blk;
 	pthread_mutex_lock(&outmtx);
-	fprintf(outfd, "B %d %d %.9g %08x ", b->nbrow, b->nlbyte, b->ppm,
-		*(uint32_t *) & ch->df);
+	/* tv: what d8psk.c:295 stamped at the sync trigger -- gettimeofday() is the sample clock here (below), so the
+	 * stamp says which hand-off block the trigger was seen in, deterministically */
+	fprintf(outfd, "B %d %d %.9g %08x t%ld.%06ld ", b->nbrow, b->nlbyte, b->ppm,
+		*(uint32_t *) & ch->df, (long)b->tv.tv_sec, (long)b->tv.tv_usec);
 	if (nbch > 1)
 		fprintf(outfd, "c%d ", b->chn);
 	for (r = 0; r < 8; r++)

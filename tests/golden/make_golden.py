@@ -64,7 +64,7 @@ def main():
                 hd = taps[taps["t"] == 3]["a"].astype("<f4").tobytes()
                 meta["channels"].append(dict(
                     chn=c, fo=fo,
-                    blocks=[dict(nbrow=b["nbrow"], nlbyte=b["nlbyte"], df_bits=b["df_bits"],
+                    blocks=[dict(nbrow=b["nbrow"], nlbyte=b["nlbyte"], df_bits=b["df_bits"], tv=b["tv"],
                                  ppm_bits=int(np.float32(b["ppm"]).view(np.uint32)), data=b["data"].hex())
                             for b in blocks],
                     frames=[f["frame"].hex() for f in frames],

@@ -94,3 +94,46 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("oracle's", "") or f in ("vdl2_math.h",), \
                     f"{f} mentions the oracle"
+
+
+def test_test_handicaps_exist_only_in_the_test_build(built):
+    """libvdl2gpu.so (the product) rejects VDL2GPU_F_TEST_NOREGION and has no code for the VDL2GPU_PRIM_DROP /
+    VDL2GPU_SPLIT_SAMPLES handicaps; libvdl2gpu_test.so (-DVDL2GPU_TESTHOOKS) is what the tests load for them.
+    The flag is checked before any device is touched, so this runs without a GPU."""
+    from vdlm2dec_amd import lib
+    prod, test = lib.load(), lib.load(testhooks=True)
+    for name in lib.EXPORTS:
+        assert hasattr(test, name), name
+    chan = (lib.ChanT * 1)(lib.ChanT(0, 136_975_000, -50_000))
+    cfg = lib.ConfigT(struct_size=C.sizeof(lib.ConfigT), sdrinrate=2_000_000, fmt=0, nbch=1, nstreams=1, chan=chan,
+                      max_push=32768, flags=lib.F_TEST_NOREGION)
+    h = C.c_void_p()
+    assert prod.vdl2gpu_create(C.byref(cfg), C.byref(h)) == -1          # VDL2GPU_EINVAL, whatever the machine
+    rc = test.vdl2gpu_create(C.byref(cfg), C.byref(h))
+    assert rc in (0, -5)                                                    # accepted: a handle, or ENODEV without a GPU
+    if rc == 0:
+        test.vdl2gpu_destroy(h)
+    blob = open(lib.LIB_PATH, "rb").read()
+    assert b"VDL2GPU_PRIM_DROP" not in blob and b"VDL2GPU_SPLIT_SAMPLES" not in blob
+    assert b"VDL2GPU_PRIM_DROP" in open(lib.LIB_TEST_PATH, "rb").read()
+    src = open(os.path.join(ROOT, "vdlm2dec_amd", "csrc", "vdl2gpu.hip")).read()
+    push = src[src.index("static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy)\n{"):]
+    push = push[:push.index("extern \"C\" int vdl2gpu_sync")]
+    assert "getenv" not in push                                             # every knob is read once, in create_impl
+
+
+def test_msgblk_offsets_are_checked_against_the_reference_header(tmp_path):
+    """oracle/ref_layout_check.c (_Static_assert against the reference's own vdlm2.h) is part of `make -C oracle ref`;
+    with one constant of include/vdl2gpu.h changed it must refuse to compile."""
+    import subprocess
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("needs /root/reference")
+    src = os.path.join(ROOT, "oracle", "ref_layout_check.c")
+    ok = subprocess.run(["gcc", "-std=c11", "-DWITH_RTL", "-I/root/reference", "-I" + os.path.join(ROOT, "include"), "-w",
+                         "-c", "-o", str(tmp_path / "a.o"), src], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    hdr = open(os.path.join(ROOT, "include", "vdl2gpu.h")).read().replace("VDL2GPU_MSGBLK_OFF_NBROW 36", "VDL2GPU_MSGBLK_OFF_NBROW 40")
+    (tmp_path / "vdl2gpu.h").write_text(hdr)
+    bad = subprocess.run(["gcc", "-std=c11", "-DWITH_RTL", "-I/root/reference", "-I" + str(tmp_path), "-w",
+                          "-c", "-o", str(tmp_path / "b.o"), src], capture_output=True, text=True)
+    assert bad.returncode != 0 and "msgblk_t.nbrow" in bad.stderr

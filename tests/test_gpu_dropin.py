@@ -34,15 +34,18 @@ def test_reference_host_path_with_gpu_front_end(built, tmp_path, name):
     blocks, frames = {}, {}
     for line in open(out):
         p = line.split()
-        chn = int(p[4 if p[0] == "F" else 5][1:]) if multi else 0
+        chn = int(p[4 if p[0] == "F" else 6][1:]) if multi else 0
         if p[0] == "B":
-            blocks.setdefault(chn, []).append((int(p[1]), int(p[2]), int(p[4], 16), p[-1]))
+            sec, usec = p[5][1:].split(".")         # msgblk_t.tv as the shim set it (the harness's clock counts samples)
+            blocks.setdefault(chn, []).append((int(p[1]), int(p[2]), int(p[4], 16), p[-1], int(sec) * 1_000_000 + int(usec)))
         elif p[0] == "F":
             frames.setdefault(chn, []).append(p[-1])
     for c in meta["channels"]:
         want_b = [(b["nbrow"], b["nlbyte"], b["df_bits"], b["data"]) for b in c["blocks"]]
-        got_b = [(a, b, d, x) for (a, b, d, x) in blocks.get(c["chn"], [])]
+        got_b = [(a, b, d, x) for (a, b, d, x, _) in blocks.get(c["chn"], [])]
         assert got_b == want_b, (name, c["chn"])
+        # d8psk.c:295: every block carries the time its sync trigger was seen at -- the all-CPU reference's stamp
+        assert [t for (_, _, _, _, t) in blocks.get(c["chn"], [])] == [b["tv"] for b in c["blocks"]], (name, c["chn"])
         assert frames.get(c["chn"], []) == c["frames"], (name, c["chn"])
 
 

@@ -149,3 +149,41 @@ def test_reference_built_with_its_own_flags_hands_over_the_same_blocks(O, tmp_pa
         assert fa == fb                                                                  # CRC-pass level
         for x, y in zip(ba, bb):
             assert abs(int(x[2]) - int(y[2])) <= 16                                      # df: same sign/exponent, a few ulp
+
+
+def _soak_scenario(seed):
+    """the soak's randomised scenarios (scripts/soak.py), small: rate, format, channel count, burst density, lengths"""
+    rng = np.random.default_rng(9000 + seed)
+    rate = int(rng.choice([2_000_000, 2_000_000, 5_000_000, 10_000_000]))
+    fmt = "f32" if (rate == 5_000_000 and seed % 3 == 0) else str(rng.choice(["cu8", "cs16"]))
+    nch = int(rng.integers(1, 4))
+    pool = S.FO8_AIR_5MS if fmt == "f32" else (S.FO8 if rate == 2_000_000 else S.FO8_10MS)
+    fos = [int(x) for x in rng.choice(pool, size=nch, replace=False)]
+    ns = int(rng.integers(3, 8)) * 200_000 * (rate // 2_000_000 if rate > 2_000_000 else 1)
+    dens = float(rng.choice([8.0, 20.0, 40.0, 80.0])) * rate / 2_000_000 / (rate // 2_000_000 if rate > 2_000_000 else 1)
+    spec = synth.random_scenario(rate, fos, ns, seed=9000 + seed, bursts_per_s=dens, info_max=int(rng.choice([30, 120, 400])))
+    if seed % 5 == 4:
+        spec.noise = 5.0        # low SNR: decisions near their thresholds
+    return spec, fmt
+
+
+def test_ofast_build_hands_over_the_same_blocks_on_the_soak_scenarios(O, tmp_path):
+    """The same decision-level comparison (sliced bits and CRC-clean frames equal, df within a few ulp) over 54
+    randomised scenarios of the soak's kind -- 2 / 5 / 10 MS/s, cu8 / cs16 / real f32, 1-3 channels, 8-80 bursts
+    a second, payloads up to 400 bytes, every fifth at low SNR -- instead of four fixed recordings."""
+    if not os.path.exists(os.path.join(O.REF_DIR, "ref_rtl_ofast")):
+        pytest.skip("oracle/_ref/ref_rtl_ofast not built")
+    nblocks = nscen = 0
+    for seed in range(54):
+        spec, fmt = _soak_scenario(seed)
+        raw = synth.synth_stream(spec, fmt)
+        a = _ref_outputs(O, raw, fmt, spec, tmp_path, False)
+        b = _ref_outputs(O, raw, fmt, spec, tmp_path, True)
+        for (ba, fa), (bb, fb) in zip(a, b):
+            assert [(x[0], x[1], x[3]) for x in ba] == [(x[0], x[1], x[3]) for x in bb], seed
+            assert fa == fb, seed
+            for x, y in zip(ba, bb):
+                assert abs(int(x[2]) - int(y[2])) <= 16, seed
+            nblocks += len(ba)
+        nscen += 1
+    assert nscen >= 50 and nblocks >= 300

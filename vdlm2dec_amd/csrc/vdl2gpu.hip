@@ -348,15 +348,15 @@ extern "C" const char *vdl2gpu_last_error(vdl2gpu_t *h)
 /* msgblk_t, vdlm2.h:39-47, LP64: prev@0(8) chn@8 Fr@12 tv@16(16) ppm@32 nbrow@36 nlbyte@40 data@44 */
 extern "C" int vdl2gpu_burst_to_msgblk(const vdl2gpu_burst_t *b, void *msgblk, size_t msgblk_size)
 {
-	if (!b || !msgblk || msgblk_size < 16624)
+	if (!b || !msgblk || msgblk_size < VDL2GPU_MSGBLK_SIZE)
 		return VDL2GPU_EINVAL;
-	char *m = (char *)msgblk;
-	memcpy(m + 8, &b->chn, 4);
-	memcpy(m + 12, &b->Fr, 4);
-	memcpy(m + 32, &b->ppm, 4);
-	memcpy(m + 36, &b->nbrow, 4);
-	memcpy(m + 40, &b->nlbyte, 4);
-	memcpy(m + 44, b->data, VDL2GPU_MAXROWS * VDL2GPU_ROWLEN);
+	char *m = (char *)msgblk;	/* the offsets are held against the reference's own header at build time (see VDL2GPU_MSGBLK_SIZE in include/vdl2gpu.h) */
+	memcpy(m + VDL2GPU_MSGBLK_OFF_CHN, &b->chn, 4);
+	memcpy(m + VDL2GPU_MSGBLK_OFF_FR, &b->Fr, 4);
+	memcpy(m + VDL2GPU_MSGBLK_OFF_PPM, &b->ppm, 4);
+	memcpy(m + VDL2GPU_MSGBLK_OFF_NBROW, &b->nbrow, 4);
+	memcpy(m + VDL2GPU_MSGBLK_OFF_NLBYTE, &b->nlbyte, 4);
+	memcpy(m + VDL2GPU_MSGBLK_OFF_DATA, b->data, VDL2GPU_MAXROWS * VDL2GPU_ROWLEN);
 	return VDL2GPU_OK;
 }
 
