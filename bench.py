@@ -31,6 +31,11 @@ Extra objects on the JSON line:
                 the process exits 1.
   cpu_baseline  the real reference (oracle/_ref: its own sources, its own compile flags) on this host's cores on a bounded
                 sample; beside it ("port") the oracle, the CPU restatement pinned bit-equal to it.
+  configs       (N = 1, default workload only; --no-extra skips it) the other BASELINE.json configurations measured in the
+                same run, each checked against the oracle like the headline (value withheld on a mismatch):
+                config3_8ch_10MSps, config4_share_8x8ch (one GPU's share of the 512 channels), config2_busy_15 / _30
+                (the headline's workload at 15 and 30 bursts per second and channel offered), config5_live_ring (32768-sample
+                cu8 blocks through vdl2gpu_ring_*, paced every 16.384 ms: p50 / p99 / max of commit -> bursts on the host).
 """
 from __future__ import annotations
 
@@ -71,9 +76,9 @@ def synth_default():
     return synth.DEFAULT_FO_8CH
 
 
-def make_tile(seed: int, fmt: str, rate: int, fos):
+def make_tile(seed: int, fmt: str, rate: int, fos, bursts_per_s: float = 4.0):
     from vdlm2dec_amd import synth
-    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=4.0, info_max=240)   # the same traffic per channel-second at every rate
+    spec = synth.random_scenario(rate, fos, TILE, seed=seed, bursts_per_s=bursts_per_s, info_max=240)   # the same traffic per channel-second at every rate
     return spec, synth.synth_stream(spec, fmt)
 
 
@@ -232,6 +237,194 @@ def canon(recs: np.ndarray) -> bytes:
     return recs[order].tobytes()
 
 
+def oracle_streams(tiles, fmt, rate, fos, ntiles):
+    """oracle_stream() for several streams side by side (one thread per channel and stream)"""
+    res = [None] * len(tiles)
+
+    def work(i):
+        res[i] = oracle_stream(tiles[i], fmt, rate, fos, ntiles)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(tiles))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return [r[0] for r in res], max(r[1] for r in res)
+
+
+def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, steps, warmup, seed0, check_streams=4):
+    """One more workload inside the same `bench.py --gpus 1` run (the `configs` object of the JSON line): resident input,
+    pushes of ntiles x 4.2 MS per stream, bursts delivered to the host -- measured like the headline (pipelined, everything
+    drained before the clock stops) and checked like it: every burst of the WHOLE run (first push included) against the
+    oracle run over the same stream; `value` is withheld on a mismatch.  Also reported: the very first push of the handle
+    (synchronous: what a cold start or a sudden load costs), the slowest of three synchronous pushes afterwards, and how
+    much went through the serial machine."""
+    import torch
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd import shard
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    dev = torch.device("cuda", local)
+    sample_bytes = {"cs16": 4, "cu8": 2}[fmt]
+    batch = ntiles * TILE
+    tile_dec = TILE * 21 // (rate // 4000)
+    tiles_np = [make_tile(seed=seed0 + g, fmt=fmt, rate=rate, fos=fos, bursts_per_s=bursts_per_s)[1] for g in range(nstr)]
+    NBUF = 2
+    dbufs = [torch.stack([torch.from_numpy(t).to(dev).repeat(ntiles) for t in tiles_np]).contiguous() for _ in range(NBUF)]
+    stride_bytes = dbufs[0].stride(0) * dbufs[0].element_size()
+    cap = 1 << 19
+    store = (_lib.BurstT * cap)()
+    nrec = 0
+    npush = 0
+    with Receiver(rate, [plan_channels(FC, fos)] * nstr, fmt=fmt, max_push=batch, device=local, max_bursts=1 << 18) as rx:
+        def drain(ready_only):
+            nonlocal nrec
+            while True:
+                room = min(16384, cap - nrec)
+                if room <= 0:
+                    raise RuntimeError("bench.py: record store full")
+                ptr = C.cast(C.byref(store, nrec * C.sizeof(_lib.BurstT)), C.POINTER(_lib.BurstT))
+                n = rx.poll_ready_raw(ptr, room) if ready_only else rx.poll_raw(ptr, room)
+                nrec += n
+                if n < room:
+                    break
+
+        def push():
+            nonlocal npush
+            rx.push_device(dbufs[npush % NBUF].data_ptr(), batch, stride_bytes)
+            npush += 1
+
+        def sync_push():
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            push()
+            drain(False)
+            return (time.perf_counter() - t0) * 1e3
+
+        # (the headline run before this leg has loaded the library's code objects: the first push is a cold HANDLE, not a cold process)
+        first_ms = sync_push()
+        for _ in range(max(0, warmup - 1)):
+            push()
+            drain(False)
+        rx.sync()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            push()
+            drain(True)
+        drain(False)
+        rx.sync()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        slow = [sync_push() for _ in range(3)]
+        st = rx.stats()
+    total_tiles = npush * ntiles
+    got = shard.pack_records(np.frombuffer(store, dtype=shard.BURST_DTYPE, count=nrec))
+    tidx = got["trig_dec"] // tile_dec
+    t_hi = total_tiles - 1
+    ncheck = min(nstr, check_streams)
+    exp, osec = oracle_streams(tiles_np[:ncheck], fmt, rate, fos, total_tiles)
+    nb, bad = 0, 0
+    for sidx in range(ncheck):
+        e = exp[sidx]
+        e = e[(e["trig_dec"] // tile_dec) < t_hi]
+        g = got[(got["stream"] == sidx) & (tidx < t_hi)].copy()
+        g["stream"] = 0
+        nb += len(g)
+        if canon(g) != canon(e):
+            bad += 1
+    equal = bad == 0 and nb > 0
+    value = nstr * batch * steps / dt / 1e6
+    dec_total = st["dec_samples"] * 8 * nstr
+    return {"workload": workload, "value": value if equal else None, "unit": "MS/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "warmup": warmup, "fmt": fmt, "sdrinrate": rate, "streams": nstr, "channels": 8 * nstr, "samples_per_step": batch * nstr,
+            "bursts_per_s_per_channel_offered": bursts_per_s, "bursts_per_step": int(round(nrec / max(1, npush))),
+            "first_push_ms": first_ms, "max_push_ms": max(slow),
+            "serial_samples_frac": st["serial_samples"] / max(1, dec_total), "serial_redos": st["serial_redos"], "overflowed": st["overflowed"],
+            "parity": {"equal": equal, "bursts_checked": nb, "streams_checked": ncheck, "tiles_checked": t_hi, "oracle_seconds": osec,
+                       "what": "every burst from the first sample of the run on, vs the oracle over the same stream"}}
+
+
+def live_leg(local=0, nblocks=300, paced=True, nslots=8, bursts_per_s=8.0, seed=77):
+    """configs[4]: the live path.  A producer hands 32768-sample cu8 blocks (one RTL-SDR USB transfer,
+    RTLINBUFSZ = 65536 bytes, vdlm2.h:35: 16.384 ms of air time at 2 MS/s) to the ingest ring -- acquire a page-locked slot,
+    fill it in place (what rtlsdr_read_async's buffer copy / in_callback do, rtl.c:274-295; 8 slots like its 8 asynchronous
+    buffers, rtl.c:302), commit -- paced at real time, and a consumer takes the bursts: latency = from vdl2gpu_ring_commit()
+    of a block until every burst that ends in it is on the host (vdl2gpu_poll returns).  The bursts must be the oracle's."""
+    import torch
+    from oracle import oracle as O
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd import synth
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    rate, blk = 2_000_000, 32768
+    fos = synth.DEFAULT_FO_8CH
+    spec = synth.random_scenario(rate, fos, nblocks * blk, seed=seed, bursts_per_s=bursts_per_s, info_max=200)
+    raw = synth.synth_stream(spec, "cu8")
+    want = sorted(b.key() for b in O.run_oracle(raw, "cu8", rate, fos, FC))
+    rawb = raw.view(np.uint8).reshape(-1)
+    period = blk / rate
+    buf = (_lib.BurstT * 4096)()
+    got, lat, late = [], [], 0
+    with Receiver(rate, plan_channels(FC, fos), fmt="cu8", max_push=blk, device=local) as rx:
+        rx.ring_init(blk, nslots=nslots)
+        t_start = time.perf_counter()
+        for i in range(nblocks):
+            if paced:
+                due = t_start + i * period
+                while True:
+                    now = time.perf_counter()
+                    if now >= due:
+                        break
+                    time.sleep(min(0.002, due - now))
+                late += (time.perf_counter() - due) > period
+            slot = rx.ring_acquire()
+            slot[0, :2 * blk] = rawb[2 * i * blk:2 * (i + 1) * blk]     # the producer's fill
+            t0 = time.perf_counter()
+            rx.ring_commit(blk)
+            n = rx.poll_raw(buf, 4096)                                  # waits for everything committed so far
+            lat.append((time.perf_counter() - t0) * 1e3)
+            for k in range(n):
+                b = buf[k]
+                got.append((b.chn, b.nbrow, b.nlbyte, bytes(b.data)))
+        wall = time.perf_counter() - t_start
+        st = rx.stats()
+    lat = np.array(lat[8:])             # the first blocks load the kernels' code objects
+    equal = sorted(got) == want and len(want) > 0
+    return {"workload": "configs[4]: 8 ch live rtl_sdr USB -> pinned ring -> GPU demod, real-time latency path (USB simulated: "
+                        "32768-sample cu8 blocks every 16.384 ms)",
+            "blocks": nblocks, "paced": bool(paced), "ring_slots": nslots, "block_air_time_ms": period * 1e3,
+            "latency_ms": {"p50": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max()),
+                           "definition": "vdl2gpu_ring_commit(block) -> vdl2gpu_poll() has returned every burst ending in it"} if equal else None,
+            "blocks_started_late": int(late), "wall_s": wall, "bursts": len(got), "serial_samples": st["serial_samples"],
+            "parity": {"equal": equal, "bursts_checked": len(want), "what": "every burst of the run vs the oracle over the same recording"}}
+
+
+def extra_legs(local):
+    """The `configs` object: configs[2], the per-GPU share of configs[3], configs[1] on busy channels, configs[4]."""
+    from vdlm2dec_amd import synth
+    fo2 = synth.DEFAULT_FO_8CH
+    legs = {}
+    plan = [
+        ("config3_8ch_10MSps", dict(workload=CONFIGS[3]["workload"], rate=10_000_000, fos=FO8_10MS, fmt="cs16", nstr=1, ntiles=64,
+                                    bursts_per_s=4.0, steps=4, warmup=2, seed0=1234)),
+        ("config4_share_8x8ch", dict(workload=CONFIGS[4]["workload"] + " -- one GPU's share", rate=2_000_000, fos=fo2, fmt="cs16", nstr=8,
+                                     ntiles=16, bursts_per_s=4.0, steps=4, warmup=2, seed0=1234)),
+        ("config2_busy_15", dict(workload=CONFIGS[2]["workload"] + " -- 15 bursts/s/channel offered", rate=2_000_000, fos=fo2, fmt="cs16",
+                                 nstr=1, ntiles=16, bursts_per_s=15.0, steps=8, warmup=3, seed0=77)),
+        ("config2_busy_30", dict(workload=CONFIGS[2]["workload"] + " -- 30 bursts/s/channel offered (channels saturated)", rate=2_000_000,
+                                 fos=fo2, fmt="cs16", nstr=1, ntiles=16, bursts_per_s=30.0, steps=8, warmup=3, seed0=77)),
+    ]
+    for name, kw in plan:
+        try:
+            legs[name] = run_leg(name, local=local, **kw)
+        except Exception as e:      # a leg must not cost the run its line
+            legs[name] = {"error": repr(e)}
+    try:
+        legs["config5_live_ring"] = live_leg(local)
+    except Exception as e:
+        legs["config5_live_ring"] = {"error": repr(e)}
+    return legs
+
+
 def respawn(args, argv):
     """`python bench.py --gpus N` on its own: become N ranks."""
     import torch
@@ -263,6 +456,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ring", action="store_true", help="skip the PCIe-inclusive extra pass (ingest ring from pinned host memory)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `configs` object (configs[2], [3]-share, busy channels, [4] live ring)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn(args, sys.argv[1:])
@@ -337,13 +531,19 @@ def main():
                 if m < 4096:
                     break
 
+    host_s = [0.0, 0.0]     # seconds this thread spent inside vdl2gpu_push / inside the poll calls (timed region)
+
     def step(pipelined):
         # one hand-off of resident samples + delivery of decoded msgblk records to the host.  pipelined: take what
         # earlier pushes have finished (vdl2gpu_poll_ready) while this push runs; everything is drained inside the
         # timed region after the last step.
+        ta = time.perf_counter()
         rx.push_device(dbufs[npush[0] % NBUF].data_ptr(), batch, stride_bytes)
+        tb = time.perf_counter()
         npush[0] += 1
         drain(ready_only=pipelined)
+        host_s[0] += tb - ta
+        host_s[1] += time.perf_counter() - tb
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -359,6 +559,7 @@ def main():
     first_timed_tile = npush[0] * ntiles
 
     fence()
+    host_s[0] = host_s[1] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -530,6 +731,10 @@ def main():
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
                                            "candidates", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,
+            "host_ms_per_step": {"in_push": host_s[0] / args.steps * 1e3, "in_poll_ready": host_s[1] / args.steps * 1e3,
+                                 "note": "wall time of the calling thread inside vdl2gpu_push (enqueues the step's ~20 launches) and inside "
+                                         "vdl2gpu_poll_ready (record read-back); the GPU works meanwhile -- the step is host-bound if their sum "
+                                         "approaches ms_per_step"},
         }
         if gathered is not None:
             out["gather"] = gathered
@@ -548,11 +753,19 @@ def main():
                 out["cpu_baseline"] = ref
             else:
                 out["cpu_baseline"] = port
-        print(json.dumps(out))
         if not parity_ok:
             print("bench.py: PARITY FAILED -- value withheld", file=sys.stderr)
             rc = 1
     rx.close()
+    if rank == 0:
+        if world == 1 and not args.no_extra and args.config == 2 and not (args.rate or args.streams or args.tiles):
+            del dbufs
+            torch.cuda.empty_cache()
+            out["configs"] = extra_legs(local)
+            if any(isinstance(v, dict) and (v.get("parity") or {}).get("equal") is False for v in out["configs"].values()):
+                print("bench.py: a `configs` leg differs from the oracle -- its value is withheld", file=sys.stderr)
+                rc = 1
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     sys.exit(rc)

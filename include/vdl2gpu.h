@@ -79,13 +79,14 @@ typedef struct {
 	int32_t nbch;		/* channels per wideband stream, 1..8 */
 	int32_t nstreams;	/* independent wideband streams decoded side by side (>=1) */
 	const vdl2gpu_chan_t *chan;	/* nstreams*nbch entries, stream-major */
-	uint64_t max_push;	/* largest nsamples a single vdl2gpu_push() will carry.  Throughput grows with the push (≈ 0.5 ms of
-				 * fixed work per push).  The parallel sync tables of a push hold 4096 trigger candidates per channel,
-				 * what a busy channel produces in roughly 40 s; a channel that exceeds them in a push is handled by
-				 * the serial machine for that push (exact, ~100x slower; stats.serial_samples shows it).  A push
-				 * longer than 36 s of air time (72 MS at 2 MS/s) is therefore cut into equal parts inside the
-				 * library -- the bursts are the same for any cut -- and the parts are halved whenever a channel's
-				 * tables overflow all the same (doubled again after 1024 pushes without one). */
+	uint64_t max_push;	/* largest nsamples a single vdl2gpu_push() will carry.  Throughput grows with the push (≈ 0.4 ms of
+				 * fixed work per push).  The parallel sync tables of a push hold 4096 trigger candidates per channel
+				 * (a burst leaves about 18: a channel at 4 bursts a second fills them in 50 s, a saturated one in
+				 * 16 s); a channel that exceeds them is handled by the serial machine for that stretch (exact, ~100x
+				 * slower; stats.serial_samples shows it).  Long pushes are therefore cut into equal parts inside the
+				 * library -- the bursts are the same for any cut --: 4.2 s of air time until the first pushes have
+				 * been collected, then as long as fills 55 % of the tables at the candidate density of the busiest
+				 * channel over the last eight pushes, at most 36 s (72 MS at 2 MS/s). */
 	int32_t device;		/* HIP device ordinal */
 	uint32_t max_bursts;	/* burst-record ring capacity (0 = default 65536) */
 	uint32_t flags;		/* VDL2GPU_F_* */

@@ -1,0 +1,11 @@
+#!/bin/bash
+# dev aid: the same bench arguments on the round-2 tree (.ab_r02, a git worktree of 6c1981f) and on this tree, same box, alternating
+cd "$(dirname "$0")/../.."
+for rep in 1 2; do
+for t in .ab_r02 .; do
+  ( cd $t && python bench.py "$@" --no-cpu 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$t', round(d['value']), round(d['ms_per_step'],4), {k:round(v,3) for k,v in d['kernels_ms'].items()}, d['roofline']['avg_launch_ms'])
+" )
+done; done

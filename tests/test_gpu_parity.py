@@ -406,17 +406,19 @@ def test_resolver_builds_the_clusters_it_is_not_given(built, oracle, monkeypatch
     assert _gpu_keys(got) == want and len(want) >= 20
 
 
-def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracle):
-    """More than 4096 trigger candidates of one channel in one push (500 short bursts in 10 s of air time): the
-    parallel tables are unusable for that push and the channel is handled by the serial machine -- slower, and
-    still the oracle's bursts; the next, ordinary push goes through the tables again."""
+def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracle, monkeypatch):
+    """More than 4096 trigger candidates of one channel in one part (500 short bursts in 10 s of air time, the part
+    length pinned to the whole push through the test build's VDL2GPU_SPLIT_SAMPLES): the parallel tables are unusable
+    for that push and the channel is handled by the serial machine -- slower, and still the oracle's bursts; the next,
+    ordinary push goes through the tables again."""
     from vdlm2dec_amd.demod import Receiver, plan_channels
     n = 20_000_000
     spec = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=110.0, info_max=4)
     raw = synth.synth_stream(spec, "cs16")
     want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
     assert len(want) >= 450
-    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=n) as rx:
+    monkeypatch.setenv("VDL2GPU_SPLIT_SAMPLES", str(n))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=n, testhooks=True) as rx:
         got = rx.run(raw, block=n)
         st = rx.stats()
         assert _gpu_keys(got) == want
@@ -427,12 +429,13 @@ def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracl
         assert rx.stats()["serial_samples"] - s0 < 100_000
 
 
-def test_overflowing_pushes_are_cut_shorter_from_then_on(built, oracle):
-    """The same dense recording pushed whole again and again: after the first overflows the library halves the parts
-    it cuts pushes into until the tables hold a part's candidates -- the last pushes do not touch the serial machine,
-    and every burst is still the oracle's."""
+def test_dense_pushes_never_reach_the_serial_machine(built, oracle):
+    """The same dense recording (50 bursts a second on one channel: 8500 trigger candidates in a 10 s push, twice what
+    the tables hold) pushed whole again and again through the PRODUCT library: the first pushes are cut into 4.2 s
+    parts, the later ones into parts sized by the measured candidate density -- no push touches the serial machine,
+    and every burst is the oracle's."""
     from vdlm2dec_amd.demod import Receiver, plan_channels
-    n, reps = 20_000_000, 7
+    n, reps = 20_000_000, 5
     spec = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=110.0, info_max=4)
     raw = synth.synth_stream(spec, "cs16")
     want = sorted(b.key() for b in oracle.run_oracle(np.tile(raw, reps), "cs16", spec.rate, spec.fo, S.FC))
@@ -443,8 +446,30 @@ def test_overflowing_pushes_are_cut_shorter_from_then_on(built, oracle):
             got += rx.poll()
             serial.append(rx.stats()["serial_samples"])
     assert _gpu_keys(got) == want
-    assert serial[0] > 400_000                              # the first push went through the serial machine
-    assert serial[-1] - serial[-2] < 100_000                # the last one through the tables
+    assert serial[-1] < 100_000, serial                     # 840 000 decimated samples per push: none of them serial
+
+
+def test_a_sudden_load_overflows_once_and_the_parts_adapt(built, oracle):
+    """Quiet pushes first (the parts grow to the 36 s limit), then the dense recording: its first push overflows the
+    tables (serial machine for that push: exact, counted), the following ones are cut by the density it showed and go
+    through the tables."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    n = 20_000_000
+    dense = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=110.0, info_max=4)
+    quiet = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=8, bursts_per_s=1.0, info_max=40)
+    rd, rq = synth.synth_stream(dense, "cs16"), synth.synth_stream(quiet, "cs16")
+    seq = [rq] * 10 + [rd] * 4          # ten quiet pushes: the density window (eight pushes) has forgotten the start-up parts
+    want = sorted(b.key() for b in oracle.run_oracle(np.concatenate(seq), "cs16", 2_000_000, dense.fo, S.FC))
+    with Receiver(2_000_000, plan_channels(S.FC, dense.fo), fmt="cs16", max_push=n) as rx:
+        got, serial = [], []
+        for r in seq:
+            rx.push(r)
+            got += rx.poll()
+            serial.append(rx.stats()["serial_samples"])
+    assert _gpu_keys(got) == want
+    assert serial[9] < 100_000                              # quiet: tables
+    assert serial[10] - serial[9] > 400_000                 # the first dense push: one part, overflow, serial machine
+    assert serial[13] - serial[12] < 100_000                # two pushes later the parts fit
 
 
 def test_pipelined_polling_delivers_everything_once(built, oracle):
@@ -533,3 +558,22 @@ def test_ingest_ring_multi_stream(built, oracle):
         want = sorted(b.key() for b in oracle.run_oracle(raws[s][:2 * n], "cs16", sp.rate, sp.fo, S.FC))
         mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
         assert mine == want and len(want) >= 8
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("bps", [15.0, 30.0])
+def test_busy_channels_stay_on_the_parallel_path(built, oracle, bps):
+    """BASELINE configs[1] with 15 and 30 bursts a second and channel offered (at 30 the channels are saturated), through
+    bench.py's own leg: every burst of the run -- the first push of the handle included -- equals the oracle's, no push
+    takes longer than 5 ms (round 2: 57 ms for the first one, through the serial machine), and less than 1 % of the
+    decimated samples go through the serial machine."""
+    import bench
+    from vdlm2dec_amd import synth as sy
+    with _rx(2_000_000, S.FO8, "cs16", max_push=1 << 20) as rx:     # (a cold process loads the kernels' code objects on their
+        rx.push(np.zeros(2 << 20, np.int16))                        #  first launch: not what the first push of a HANDLE costs)
+        rx.poll()
+    r = bench.run_leg("busy", "test", 0, 2_000_000, sy.DEFAULT_FO_8CH, "cs16", 1, 16, bps, steps=4, warmup=2, seed0=77)
+    assert r["parity"]["equal"] and r["parity"]["bursts_checked"] > 10_000
+    assert r["serial_samples_frac"] < 0.01 and r["overflowed"] == 0
+    assert r["first_push_ms"] < 5.0 and r["max_push_ms"] < 5.0, r
+    assert r["value"] > 20_000          # MS/s; the measured figure is in the bench line (configs.config2_busy_*)

@@ -123,6 +123,10 @@ struct vdl2gpu {
 					 * whenever a channel's candidate tables overflow */
 	size_t split_default = 0;
 	unsigned long long last_ovf_push = 0;
+	size_t ring_samples[2] = {0, 0};	/* samples (per stream) of the push that filled each output ring */
+	double cand_dens[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* candidates per input sample of the busiest channel, last eight pushes collected */
+	unsigned cand_dens_n = 0;
+	size_t split_unit = 32768;	/* parts are multiples of this (k1_fast takes whole superperiods; the RTL quirk needs whole blocks) */
 	unsigned redos_seen = 0, repairs_seen = 0;
 	uint64_t last_redo_push = 0;
 	unsigned long long *d_dbg = nullptr;
@@ -150,7 +154,7 @@ struct vdl2gpu {
 	size_t fready_pos = 0;
 	uint64_t frames_dropped = 0;
 	vdl2gpu_burst_t *h_pin = nullptr;	/* pinned bounce buffer for record read-back */
-	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [24*ring + {0..6}] counters, [24*ring + 8 ..] redo mask */
+	unsigned *h_pin_cnt = nullptr;	/* pinned, written by k3_rebase: [32*ring + {0..6}] counters, [7] overflowed channels, [8..23] redo mask, [24] most candidates of any channel */
 	unsigned *d_pin_cnt = nullptr;	/* its device address */
 	unsigned pin_recs = 0;
 	bool failed = false;	/* a HIP call failed while work was being enqueued: device and host state no longer agree */
@@ -629,8 +633,11 @@ static int create_impl(vdl2gpu_t *h)
 	/* A push in which a channel's verify pass fails with no round scheduled costs a serial redo of that channel's whole
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
 	 * round is always scheduled. */
-	h->split_samples = (size_t)(36.0 * (double)h->cfg.sdrinrate) / 32768 * 32768;
-	h->split_default = h->split_samples;
+	/* Parts (see push_checked): at most 36 s of air time; until the first pushes have been collected and their candidate
+	 * density is known, 4.2 s -- a saturated channel (250 candidates a second) fills a quarter of the tables in that long. */
+	h->split_unit = ((cfg.flags & VDL2GPU_F_RTL_QUIRK) || h->sdrclk != 500 || h->L != 80) ? 32768 : K1F_PER_IN;
+	h->split_default = (size_t)(36.0 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit;
+	h->split_samples = std::max(h->split_unit, (size_t)(4.2 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit);
 #ifdef VDL2GPU_TESTHOOKS
 	if (getenv("VDL2GPU_SPLIT_SAMPLES")) {
 		h->split_samples = (size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES"));
@@ -643,8 +650,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->quirk = (cfg.flags & VDL2GPU_F_RTL_QUIRK) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 48 * sizeof(unsigned), hipHostMallocMapped));
-	memset(h->h_pin_cnt, 0, 48 * sizeof(unsigned));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 64 * sizeof(unsigned), hipHostMallocMapped));
+	memset(h->h_pin_cnt, 0, 64 * sizeof(unsigned));
 	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
 	HIPCHK(h, hipMalloc(&h->d_k4tab, K4_TABW * sizeof(unsigned)));
 	hipLaunchKernelGGL(k4_tables, dim3(1), dim3(64), 0, h->stream, h->d_k4tab);
@@ -825,10 +832,12 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 		h->err = "an earlier HIP error left the handle unusable: " + h->err;
 		return VDL2GPU_EHIP;
 	}
-	/* A push carries at most ~36 s of air time through the tables: their 4096 trigger candidates per channel are what a
-	 * busy channel produces in about that long, and a channel that overflows them is handled by the serial machine for
-	 * the whole push (40 ms for a 54 s push of 8 channels).  Longer pushes are cut into equal parts (multiples of the
-	 * reference's 32768-sample block, which VDL2GPU_F_RTL_QUIRK needs anyway); any cut gives the same bursts. */
+	/* A push carries at most ~36 s of air time through the tables, and less on busy channels: the tables hold 4096 trigger
+	 * candidates per channel, and a channel that overflows them is handled by the serial machine for the whole part
+	 * (exact, ~15 ms for 34 s of 8 channels).  Longer pushes are cut into equal parts whose length follows the candidate
+	 * density of the pushes collected lately (harvest_ring) -- multiples of a k1_fast superperiod (8000 samples at
+	 * 2 MS/s: the parts then need no general channeliser launch at their edges) or of the reference's 32768-sample block
+	 * (other rates; VDL2GPU_F_RTL_QUIRK needs whole blocks anyway); any cut gives the same bursts. */
 	int rc = VDL2GPU_OK;
 	const size_t lim = h ? h->split_samples : 0;
 	if (!h || !iq || lim == 0 || nsamples <= lim)
@@ -837,7 +846,8 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 		if (nsamples > h->cfg.max_push)
 			return VDL2GPU_EINVAL;
 		const size_t parts = (nsamples + lim - 1) / lim;
-		const size_t part = ((nsamples + parts - 1) / parts + 32767) / 32768 * 32768;
+		const size_t unit = h->split_unit;
+		const size_t part = ((nsamples + parts - 1) / parts + unit - 1) / unit * unit;
 		for (size_t off = 0; off < nsamples && rc == VDL2GPU_OK; off += part)
 			rc = push_impl(h, (const char *)iq + off * h->sample_bytes, std::min(part, nsamples - off), stream_stride_bytes, memkind, wait_copy);
 	}
@@ -1378,7 +1388,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k3.outc = h->d_outc;
 		k3.fmask = h->d_fmask;
 		k3.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
-		k3.host_cnt = h->d_pin_cnt + 24 * ring;
+		k3.host_cnt = h->d_pin_cnt + 32 * ring;
 		k3.ring = ring;
 		k3.ctl = h->d_ctl;
 		k3.nstreams = h->S;
@@ -1394,6 +1404,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	/* (the same event tells the host that this push's output ring is complete: ring == par) */
 	h->ring_busy[ring] = true;
 	h->ring_push[ring] = h->pushes;
+	h->ring_samples[ring] = nsamples;
 	h->pending.push_back(pt);
 	h->total_in += nsamples;
 	h->pushes++;
@@ -1427,26 +1438,37 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		}
 	}
 	HIPCHK(h, hipEventSynchronize(h->k2_done[ring]));
-	const unsigned c0 = h->h_pin_cnt[24 * ring], c1 = h->h_pin_cnt[24 * ring + 1];
+	const unsigned c0 = h->h_pin_cnt[32 * ring], c1 = h->h_pin_cnt[32 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
-	{
-		/* a channel whose candidates overflowed the tables went through the serial machine (milliseconds): cut the
-		 * pushes into shorter parts from now on; back up slowly when it has been quiet for long */
-		const unsigned novf = h->h_pin_cnt[24 * ring + 7];
-		if (novf && !h->knob.split_fixed) {
-			h->split_samples = std::max<size_t>(8 * 32768, h->split_samples / 2 / 32768 * 32768);
+	if (!h->knob.split_fixed && h->ring_samples[ring]) {
+		/* How long a part may be follows from how many trigger candidates the busiest channel produced per input sample
+		 * in the pushes collected lately (the highest of the last eight): parts are sized to fill 55 % of the tables, so
+		 * that traffic may grow by 80 % from one push to the next before a channel overflows them.  A channel that does
+		 * overflow is handled by the serial machine for that part (exact, milliseconds); its density then counts as
+		 * twice what the tables hold.  Round 2 halved the parts on an overflow and doubled them again after 1024 quiet
+		 * pushes: busy channels ended up in parts a quarter full. */
+		const unsigned novf = h->h_pin_cnt[32 * ring + 7];
+		const unsigned maxc = h->h_pin_cnt[32 * ring + 24];
+		double d = (double)std::min<unsigned>(maxc, VDL2_CAND_CAP) / (double)h->ring_samples[ring];
+		if (novf)
+			d = 2.0 * (double)VDL2_CAND_CAP / (double)h->ring_samples[ring];
+		h->cand_dens[h->cand_dens_n++ & 7u] = d;
+		double dmax = 0.0;
+		for (double x : h->cand_dens)
+			dmax = std::max(dmax, x);
+		size_t lim = h->split_default;
+		if (dmax > 0.0)
+			lim = (size_t)std::min((double)h->split_default, 0.55 * (double)VDL2_CAND_CAP / dmax);
+		h->split_samples = std::max(h->split_unit, lim / h->split_unit * h->split_unit);
+		if (novf)
 			h->last_ovf_push = h->ring_push[ring];
-		} else if (h->split_samples < h->split_default && h->ring_push[ring] > h->last_ovf_push + 1024) {
-			h->split_samples = std::min(h->split_default, h->split_samples * 2);
-			h->last_ovf_push = h->ring_push[ring];
-		}
 	}
 	{
 		/* repair rounds only cost launches while nothing fails, so: none until the first verify
 		 * failure shows up (as a serial redo), then as many as it takes to get rid of the serial
 		 * redos, and back down one at a time after long quiet stretches */
-		const unsigned redos = h->h_pin_cnt[24 * ring + 2], repairs = h->h_pin_cnt[24 * ring + 3];
+		const unsigned redos = h->h_pin_cnt[32 * ring + 2], repairs = h->h_pin_cnt[32 * ring + 3];
 		if (redos != h->redos_seen) {
 			h->redos_seen = redos;
 			h->last_redo_push = h->ring_push[ring];
@@ -1497,7 +1519,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 		if (h->ring_spec[ring]) {
 			/* K2d ran ahead of the verify pass: for a channel that K2f then redid serially, its records
 			 * (trig_sample == 0 on the device) are void; K2f's own (== 1) are the channel's bursts */
-			const unsigned *mask = h->h_pin_cnt + 24 * ring + 8;
+			const unsigned *mask = h->h_pin_cnt + 32 * ring + 8;
 			bool any = false;
 			for (int i = 0; i < 16; ++i)
 				any = any || mask[i] != 0;
@@ -1536,8 +1558,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	}
 	if (h->frames_on) {
 		const unsigned arena0 = h->rec_cap * K4_SLOT;
-		const unsigned nbytes = std::min(h->h_pin_cnt[24 * ring + 6], h->frame_cap - arena0);
-		h->frames_dropped += h->h_pin_cnt[24 * ring + 5];
+		const unsigned nbytes = std::min(h->h_pin_cnt[32 * ring + 6], h->frame_cap - arena0);
+		h->frames_dropped += h->h_pin_cnt[32 * ring + 5];
 		if (n) {
 			{	/* bounded like the burst queue: the oldest frames go, counted */
 				const size_t qmax = 4 * (size_t)h->rec_cap;

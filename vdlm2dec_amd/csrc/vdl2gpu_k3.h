@@ -60,13 +60,20 @@ __global__ void k3_rebase(K3Params p)
 	const int s = blockIdx.x;
 	/* channels that went through the serial machine because their candidates did not fit the tables (the host then
 	 * shortens the parts it cuts pushes into): one lane per channel slot, not one load after the other */
-	unsigned novf = 0;
-	if (s == 0)
+	unsigned novf = 0, maxc = 0;
+	if (s == 0) {
 		for (int sc = (int)threadIdx.x; sc < (p.nstreams * VDL2_CS + 63) / 64 * 64; sc += 64) {
-			const bool over = sc < p.nstreams * VDL2_CS && sc % VDL2_CS < p.nbch &&
-					  (p.ctl[CTL_CAND0 + sc] > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc]);
+			const bool live = sc < p.nstreams * VDL2_CS && sc % VDL2_CS < p.nbch;
+			const unsigned nc = live ? p.ctl[CTL_CAND0 + sc] : 0u;
+			const bool over = live && (nc > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc]);
 			novf += (unsigned)__popcll(__ballot(over));
+			maxc = nc > maxc ? nc : maxc;
 		}
+		for (int d = 32; d > 0; d >>= 1) {	/* the busiest channel's candidate count: what the host sizes the next parts by */
+			const unsigned o = (unsigned)__shfl_xor((int)maxc, d, 64);
+			maxc = o > maxc ? o : maxc;
+		}
+	}
 	if (threadIdx.x != 0)
 		return;
 	if (s == 0) {
@@ -79,6 +86,7 @@ __global__ void k3_rebase(K3Params p)
 		for (int i = 0; i < 16; ++i)
 			p.host_cnt[8 + i] = p.fmask[i];
 		p.host_cnt[7] = novf;
+		p.host_cnt[24] = maxc;
 	}
 	StreamState *ss = p.ss + s;
 	long long mn = 0x7fffffffffffffffLL;

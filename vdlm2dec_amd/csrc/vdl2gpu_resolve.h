@@ -538,6 +538,8 @@ void k2c_resolve(K2Params p)
 			st.pos = ncand_t;
 			mach_materialize<K2_NT, false>(sh, cx, st.pos, st.r);
 			replay = true;
+			if (tid == 0 && p.dbg)
+				atomicAdd(p.dbg + 25, 1ull);	/* replays of clusters K2b did not make */
 			continue;
 		}
 		/* CL_NONSTEADY: its bursts count, then continue from the explicit state it stopped in */
@@ -548,6 +550,8 @@ void k2c_resolve(K2Params p)
 				atomicMin(p.fail + sc, 0);
 			++nvis;
 		}
+		if (tid == 0 && p.dbg)
+			atomicAdd(p.dbg + 26, 1ull);	/* non-steady clusters continued serially */
 		mach_load(sh, &cl->saved);
 		st.pos = cl->saved.pos;
 		st.r = cl->saved.r;
@@ -648,6 +652,9 @@ void k2c_resolve(K2Params p)
 			atomicAdd(p.dbg + 18, (unsigned long long)(tk3 - tk2));
 			atomicAdd(p.dbg + 19, (unsigned long long)(tk4 - tk3));
 			atomicAdd(p.dbg + 20, 1ull);
+			atomicAdd(p.dbg + 27, (unsigned long long)ncand);
+			atomicAdd(p.dbg + 28, (unsigned long long)s_walk[3]);	/* visited-list entries */
+			atomicAdd(p.dbg + 29, n_slow);
 		}
 	}
 }

@@ -311,7 +311,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	constexpr float rc[16] = {C1, -C1, -S1, -C1, C1, S1, S1, -C1, S1, C1, -S1, -S1, S1, -S1, C1, -C1};
 	constexpr float rs[16] = {-S1, -S1, -C1, S1, -S1, -C1, C1, S1, -C1, S1, -C1, C1, C1, C1, S1, -S1};
 	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
-	const bool prof = p.dbg && mode == 2 && tid == 0 && (blockIdx.x & 7) == 0;
+	const bool prof = p.dbg && (mode == 2 || (mode == 0 && S == 1 && skip_r >= 0)) && tid == 0 && (blockIdx.x & 7) == 0;	/* probe, region scan */
 	long long tq = prof ? clock64() : 0;
 #define K2A_STAMP(slot) do { if (prof) { const long long tn = clock64(); sh.prof[slot] += (unsigned long long)(tn - tq); tq = tn; } } while (0)
 	if (!pre.loaded)
@@ -430,8 +430,11 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				__syncthreads();	/* everyone has read nwl before it is reset */
 				continue;
 			}
-			if (ndl0 + nwl > K2A_DEF)	/* no room for this pass's survivors: work the list off first */
+			if (ndl0 + nwl > K2A_DEF) {	/* no room for this pass's survivors: work the list off first */
+				K2A_STAMP(6);
 				k2a_flush(sh, p, sc, dec_base, mode, fail, skip_r, skip_par);
+				K2A_STAMP(7);
+			}
 			/* second screen: lag-2 steps as products of neighbouring rotated lag-1 phasors */
 			for (int k = tid; k < nwl; k += K2A_THREADS) {
 				const int j = sh.wl[k];
@@ -736,15 +739,31 @@ void k2a_region(K2Params p)
 	const long long dec_base = p.ss[s].dec_base;
 	const int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
 	const int skip_r = p.cs[sc].r, skip_par = (int)(p.cs[sc].pos & 1);
+	if (threadIdx.x < 16)
+		sh.prof[threadIdx.x] = 0;
 	k2a_tables(sh);
 	K2aPre<1> pre;
 	pre.loaded = false;
+	const bool prof = p.dbg && threadIdx.x == 0 && (blockIdx.x & 7) == 0;
+	const long long t0 = prof ? clock64() : 0;
 	for (unsigned k = blockIdx.x; k < nreg; k += gridDim.x) {
 		const int2 rg = regs[k];
 		const int2 rn = (k + gridDim.x < nreg) ? regs[k + gridDim.x] : make_int2(0, 0);
 		k2a_tile<1>(sh, p, sc, dec_base, dec_base + rg.x, rg.y, 0xfu, 0, 0, 0, nullptr, pre, dec_base + rn.x, rn.y, skip_r, skip_par);
+		if (prof)
+			sh.prof[15] += (unsigned long long)rg.y;	/* instants */
 	}
+	const long long t1 = prof ? clock64() : 0;
+	if (prof)
+		sh.prof[13] += (unsigned long long)sh.ndl;	/* survivors left for the final flush */
 	k2a_flush(sh, p, sc, dec_base, 0, nullptr, skip_r, skip_par);
+	if (prof) {
+		sh.prof[14] += (unsigned long long)(clock64() - t1);	/* final flush */
+		sh.prof[12] += (unsigned long long)(t1 - t0);		/* all tiles */
+	}
+	__syncthreads();
+	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
+		atomicAdd(p.dbg + 48 + threadIdx.x, sh.prof[threadIdx.x]);
 }
 
 /* one workgroup = K2A_VRUN tiles of 2*K2A_TS samples; every piece of a verify segment inside a tile
