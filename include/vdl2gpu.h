@@ -84,8 +84,8 @@ typedef struct {
 				 * (a burst leaves about 18: a channel at 4 bursts a second fills them in 50 s, a saturated one in
 				 * 16 s); a channel that exceeds them is handled by the serial machine for that stretch (exact, ~100x
 				 * slower; stats.serial_samples shows it).  Long pushes are therefore cut into equal parts inside the
-				 * library -- the bursts are the same for any cut --: 4.2 s of air time until the first pushes have
-				 * been collected, then as long as fills 55 % of the tables at the candidate density of the busiest
+				 * library -- the bursts are the same for any cut --: 8.4 s of air time until the first pushes have
+				 * been collected, then as long as fills 90 % of the tables at the candidate density of the busiest
 				 * channel over the last eight pushes, at most 36 s (72 MS at 2 MS/s). */
 	int32_t device;		/* HIP device ordinal */
 	uint32_t max_bursts;	/* burst-record ring capacity (0 = default 65536) */
@@ -139,14 +139,14 @@ typedef struct {
 } vdl2gpu_stats_t;
 
 typedef struct {
-	double channelise_ms;	/* sum over pushes of the channeliser kernel, HIP events */
+	double channelise_ms;	/* sum over pushes of the channeliser kernels (HIP events on every stage_every-th push, scaled to all) */
 	double demod_ms;	/* sum of the demodulator kernels (scan + cluster + resolve) */
 	double scan_ms;		/* K2a sync scan */
 	double cluster_ms;	/* K2b burst clusters */
 	double resolve_ms;	/* K2c resolver + K2d gather */
 	double other_ms;	/* compaction / bookkeeping kernels */
 	double channelise_fast_ms;	/* the k1_fast launches alone (2 MS/s path): sum over fast_pushes launches */
-	uint64_t fast_pushes;	/* number of k1_fast launches (a push may split its channeliser into two) */
+	uint64_t fast_pushes;	/* number of fast-kernel launches behind channelise_fast_ms (the timed ones) */
 	uint64_t pushes;
 	uint64_t samples;	/* input samples per stream covered by the sums */
 } vdl2gpu_timing_t;

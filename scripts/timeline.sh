@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find the 5th k2a_probe and print until the 6th
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k2a_probe")]
-a, b = idx[4], idx[5]
+a, b = idx[-7], idx[-6]      # a step of the timed region (the last four pushes of bench.py are its synchronous "alone" measurement; the very first push runs as several parts)
 t0 = int(rows[a]["Start_Timestamp"])
 last_end = {}
 for r in rows[a - 3:b + 1]:

@@ -431,7 +431,7 @@ def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracl
 
 def test_dense_pushes_never_reach_the_serial_machine(built, oracle):
     """The same dense recording (50 bursts a second on one channel: 8500 trigger candidates in a 10 s push, twice what
-    the tables hold) pushed whole again and again through the PRODUCT library: the first pushes are cut into 4.2 s
+    the tables hold) pushed whole again and again through the PRODUCT library: the first pushes are cut into 8.4 s
     parts, the later ones into parts sized by the measured candidate density -- no push touches the serial machine,
     and every burst is the oracle's."""
     from vdlm2dec_amd.demod import Receiver, plan_channels
@@ -577,3 +577,16 @@ def test_busy_channels_stay_on_the_parallel_path(built, oracle, bps):
     assert r["serial_samples_frac"] < 0.01 and r["overflowed"] == 0
     assert r["first_push_ms"] < 5.0 and r["max_push_ms"] < 5.0, r
     assert r["value"] > 20_000          # MS/s; the measured figure is in the bench line (configs.config2_busy_*)
+
+
+def test_paced_live_ring_equals_the_oracle(built, oracle):
+    """BASELINE configs[4] through bench.py's own leg: 32768-sample cu8 blocks (one RTL-SDR USB transfer) written in place
+    into the 8-slot page-locked ring every 16.384 ms, bursts collected block by block -- the bursts are the oracle's, and
+    a block's bursts are on the host long before the next block is due."""
+    import bench
+    r = bench.live_leg(0, nblocks=90, paced=True)
+    assert r["parity"]["equal"] and r["parity"]["bursts_checked"] >= 30
+    lat = r["latency_ms"]
+    assert lat["p50"] < 2.0 and lat["p99"] < 16.384 and r["blocks_started_late"] == 0, r
+    r2 = bench.live_leg(0, nblocks=90, paced=False, seed=78)      # as fast as the producer can: the same bursts, no pacing to hide behind
+    assert r2["parity"]["equal"]

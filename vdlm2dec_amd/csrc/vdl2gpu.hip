@@ -35,7 +35,8 @@ extern "C" void sincosf(float, float *, float *);
 	} while (0)
 
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
-#define NEVX 13	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain */
+#define NEVX 15	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain; e[12] = before the verify pass
+			 * (main stream, behind the wait for the resolver); e[13], e[14] = around the resolver (its own stream when hoisted) */
 struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
@@ -80,22 +81,22 @@ struct vdl2gpu {
 	bool ring_busy[2] = { false, false };
 	uint64_t ring_push[2] = { 0, 0 };	/* which push filled the ring */
 	hipStream_t copy_stream = nullptr;
-	unsigned *d_ctl = nullptr;	/* control words, see CTL_* in vdl2gpu_kernels.h */
+	unsigned *d_ctl[2] = {nullptr, nullptr};	/* control words, see CTL_* in vdl2gpu_kernels.h */
 	size_t ctl_words = 0;
 	unsigned rec_cap = 0;
-	Cand *d_cands = nullptr;
-	Cluster *d_clusters = nullptr;
-	int2 *d_clhead = nullptr;
-	BurstDesc *d_stage = nullptr;
-	unsigned *d_sel_list = nullptr;
-	int2 *d_regs = nullptr;
-	Seg *d_segs = nullptr;
-	int *d_fail = nullptr;
-	int *d_redo = nullptr;
-	ChanState *d_cs_out = nullptr;
-	int *d_skey = nullptr;
-	unsigned short *d_sidx = nullptr, *d_prim = nullptr;
-	int *d_seeds = nullptr;
+	Cand *d_cands[2] = {nullptr, nullptr};
+	Cluster *d_clusters[2] = {nullptr, nullptr};
+	int2 *d_clhead[2] = {nullptr, nullptr};
+	BurstDesc *d_stage[2] = {nullptr, nullptr};
+	unsigned *d_sel_list[2] = {nullptr, nullptr};
+	int2 *d_regs[2] = {nullptr, nullptr};
+	Seg *d_segs[2] = {nullptr, nullptr};
+	int *d_fail[2] = {nullptr, nullptr};
+	int *d_redo[2] = {nullptr, nullptr};
+	ChanState *d_cs_out[2] = {nullptr, nullptr};
+	int *d_skey[2] = {nullptr, nullptr};
+	unsigned short *d_sidx[2] = {nullptr, nullptr}, *d_prim[2] = {nullptr, nullptr};
+	int *d_seeds[2] = {nullptr, nullptr};
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
@@ -107,12 +108,11 @@ struct vdl2gpu {
 	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown): an event record between two kernels of the chain
 					 * costs ~3 us, so only every stage_every-th push carries them (the sums are scaled up in harvest) */
 	int stage_every = 4;
-	hipStream_t k1_stream = nullptr;	/* channeliser of push N+1 runs beside the demodulator of push N */
 	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
 	bool k2_rec[2] = {false, false};
 	hipStream_t pay_stream = nullptr;	/* K2d beside the verify pass (when no repair rounds are scheduled) */
 	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
-	unsigned *d_fmask = nullptr;	/* K2f's redo mask of the push in flight, 16 words */
+	unsigned *d_fmask[2] = {nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
 	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
 	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
@@ -163,7 +163,6 @@ struct vdl2gpu {
 	 * The test handicaps (VDL2GPU_PRIM_DROP, VDL2GPU_SPLIT_SAMPLES, VDL2GPU_F_TEST_NOREGION) exist only in the
 	 * library built with -DVDL2GPU_TESTHOOKS (libvdl2gpu_test.so, which the tests load). */
 	struct {
-		bool k1_early = false;		/* VDL2GPU_K1_EARLY: start the channeliser beside the previous push's scan */
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
 		bool k1_pp = false;		/* VDL2GPU_K1_PP: k1_pp at 2 MS/s as well */
 		bool debug_counters = false;	/* VDL2GPU_DEBUG_COUNTERS: cycle counters of the demodulator kernels */
@@ -172,8 +171,33 @@ struct vdl2gpu {
 		int k1_dbg = 0;			/* VDL2GPU_K1_DBG */
 		int k1_nsub = 0;		/* VDL2GPU_K1_NSUB */
 	} knob;
+	/* A push's work is two stages on two streams, and two pushes are in flight at once -- the tables (candidates, clusters,
+	 * descriptors, control words ...) exist twice:
+	 *   FRONT (fstream): carry copy, channeliser, scan of one class + regions, sort, clusters -- wide kernels that need
+	 *                    nothing of the previous push's RESULT: the scan starts at the first carried frame and in a fixed
+	 *                    class (what the resolver consumes is decided by where it stands, not by where the scan began),
+	 *                    the stream-time base is the host's arithmetic, the carry is a fixed 49152 frames;
+	 *   BACK  (stream):  resolver, verify pass (+ payload decode beside it), repair rounds, commit, block path, counters --
+	 *                    needs the channel state the previous push's BACK committed, so backs run one behind the other.
+	 * FRONT(N+1) runs beside BACK(N): the back's one-workgroup-per-channel kernels (resolver, commit) no longer leave the
+	 * GPU idle, and the channeliser's planes are still in the Infinity Cache when the scan reads them.  Pushes too short
+	 * for the parallel path (the live path: one SDR block) keep everything on the one stream: a hop costs ~30 us. */
+	struct Back {
+		bool valid = false;
+		K2Params k2{};
+		int64_t J = 0;
+		int par = 0, ring = 0;
+		bool staged = false, serial = false, two_streams = false;
+		unsigned tiles = 0;
+		size_t pt_index = 0;	/* its PushTiming in `pending` */
+	} back;
+	hipStream_t fstream = nullptr;
+	hipEvent_t f_done[2] = {nullptr, nullptr};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
+	hipEvent_t k1_ev = nullptr;	/* the latest channeliser (whichever stream it ran on) */
+	bool k1_ev_rec = false, last_two_streams = false;
+	int64_t last_J = 0;	/* outputs of the previous push: where its last 49152 frames lie */
 	/* stage sums of the pushes that carried stage events, unscaled, and how many those were */
-	double st_scan = 0, st_cluster = 0, st_resolve = 0, st_demod = 0, st_other = 0;
+	double st_scan = 0, st_cluster = 0, st_resolve = 0, st_demod = 0, st_other = 0, st_k1 = 0;
 	uint64_t st_pushes = 0;
 };
 
@@ -446,8 +470,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipSetDevice(h->cfg.device);
 	if (h->in_stream)
 		(void)hipStreamSynchronize(h->in_stream);
-	if (h->k1_stream)
-		(void)hipStreamSynchronize(h->k1_stream);
+	if (h->fstream)
+		(void)hipStreamSynchronize(h->fstream);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
 	if (h->pay_stream)
@@ -497,6 +521,15 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	}
 	if (h->k2_mid)
 		(void)hipEventDestroy(h->k2_mid);
+	if (h->fstream) {
+		(void)hipStreamSynchronize(h->fstream);
+		(void)hipStreamDestroy(h->fstream);
+	}
+	for (int r = 0; r < 2; ++r)
+		if (h->f_done[r])
+			(void)hipEventDestroy(h->f_done[r]);
+	if (h->k1_ev)
+		(void)hipEventDestroy(h->k1_ev);
 	if (h->pay_stream) {
 		(void)hipStreamSynchronize(h->pay_stream);
 		(void)hipStreamDestroy(h->pay_stream);
@@ -505,26 +538,40 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipEventDestroy(h->k2c_done);
 	if (h->pay_done)
 		(void)hipEventDestroy(h->pay_done);
-	(void)hipFree(h->d_fmask);
+	(void)hipFree(h->d_fmask[0]);
+	(void)hipFree(h->d_fmask[1]);
 	if (h->k2_mid_a)
 		(void)hipEventDestroy(h->k2_mid_a);
-	if (h->k1_stream)
-		(void)hipStreamDestroy(h->k1_stream);
-	(void)hipFree(h->d_ctl);
-	(void)hipFree(h->d_cands);
-	(void)hipFree(h->d_clusters);
-	(void)hipFree(h->d_clhead);
-	(void)hipFree(h->d_stage);
-	(void)hipFree(h->d_sel_list);
-	(void)hipFree(h->d_regs);
-	(void)hipFree(h->d_segs);
-	(void)hipFree(h->d_fail);
-	(void)hipFree(h->d_redo);
-	(void)hipFree(h->d_cs_out);
-	(void)hipFree(h->d_skey);
-	(void)hipFree(h->d_sidx);
-	(void)hipFree(h->d_prim);
-	(void)hipFree(h->d_seeds);
+	(void)hipFree(h->d_ctl[0]);
+	(void)hipFree(h->d_ctl[1]);
+	(void)hipFree(h->d_cands[0]);
+	(void)hipFree(h->d_cands[1]);
+	(void)hipFree(h->d_clusters[0]);
+	(void)hipFree(h->d_clusters[1]);
+	(void)hipFree(h->d_clhead[0]);
+	(void)hipFree(h->d_clhead[1]);
+	(void)hipFree(h->d_stage[0]);
+	(void)hipFree(h->d_stage[1]);
+	(void)hipFree(h->d_sel_list[0]);
+	(void)hipFree(h->d_sel_list[1]);
+	(void)hipFree(h->d_regs[0]);
+	(void)hipFree(h->d_regs[1]);
+	(void)hipFree(h->d_segs[0]);
+	(void)hipFree(h->d_segs[1]);
+	(void)hipFree(h->d_fail[0]);
+	(void)hipFree(h->d_fail[1]);
+	(void)hipFree(h->d_redo[0]);
+	(void)hipFree(h->d_redo[1]);
+	(void)hipFree(h->d_cs_out[0]);
+	(void)hipFree(h->d_cs_out[1]);
+	(void)hipFree(h->d_skey[0]);
+	(void)hipFree(h->d_skey[1]);
+	(void)hipFree(h->d_sidx[0]);
+	(void)hipFree(h->d_sidx[1]);
+	(void)hipFree(h->d_prim[0]);
+	(void)hipFree(h->d_prim[1]);
+	(void)hipFree(h->d_seeds[0]);
+	(void)hipFree(h->d_seeds[1]);
 	(void)hipFree(h->d_dbg);
 	(void)hipFree(h->d_headtap);
 	(void)hipFree(h->d_headtap_n);
@@ -580,47 +627,69 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_outc, 8 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 8 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-	{
-		/* the demodulator chain is the critical path: the channeliser only fills what it leaves idle */
-		int prio_lo = 0, prio_hi = 0;
-		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, prio_lo));
-	}
+	/* (HIP multiplexes its streams onto four hardware queues: a fifth stream shares one with another, and kernels that
+	 * were meant to run side by side then run one behind the other -- this handle makes exactly main, copy, resolver, payload;
+	 * host input adds one for its copies, which may share a queue with the record read-back) */
 	for (int r = 0; r < 2; ++r) {
 		HIPCHK(h, hipEventCreateWithFlags(&h->k1_done[r], hipEventDisableTiming));
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
 	}
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid, hipEventDisableTiming));
+	{
+		int prio_lo = 0, prio_hi = 0;
+		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+		HIPCHK(h, hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, prio_lo));	/* the back stage (main stream, high priority) is the shorter one: it goes first */
+	}
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipEventCreateWithFlags(&h->f_done[r], hipEventDisableTiming));
+	HIPCHK(h, hipEventCreateWithFlags(&h->k1_ev, hipEventDisableTiming));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->pay_stream, hipStreamNonBlocking));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2c_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->pay_done, hipEventDisableTiming));
-	HIPCHK(h, hipMalloc(&h->d_fmask, 16 * sizeof(unsigned)));
-	HIPCHK(h, hipMemsetAsync(h->d_fmask, 0, 16 * sizeof(unsigned), h->stream));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_fmask[r], 16 * sizeof(unsigned)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMemsetAsync(h->d_fmask[r], 0, 16 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid_a, hipEventDisableTiming));
 	h->ctl_words = CTL_CAND0 + 8 * (size_t)S * VDL2_CS;
-	HIPCHK(h, hipMalloc(&h->d_ctl, h->ctl_words * sizeof(unsigned)));
-	HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, h->ctl_words * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipMalloc(&h->d_cands, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
-	HIPCHK(h, hipMalloc(&h->d_clusters, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
-	HIPCHK(h, hipMalloc(&h->d_clhead, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int2)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_ctl[r], h->ctl_words * sizeof(unsigned)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMemsetAsync(h->d_ctl[r], 0, h->ctl_words * sizeof(unsigned), h->stream));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_cands[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_clusters[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_clhead[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int2)));
 	h->stage_cap = (unsigned)S * VDL2_CS * VDL2_CAND_CAP * VDL2_CL_MAXB + 65536u;	/* static slots + dynamic tail */
-	HIPCHK(h, hipMalloc(&h->d_stage, (size_t)h->stage_cap * sizeof(BurstDesc)));
-	HIPCHK(h, hipMalloc(&h->d_sel_list, (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
-	HIPCHK(h, hipMalloc(&h->d_regs, (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
-	HIPCHK(h, hipMalloc(&h->d_segs, (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
-	HIPCHK(h, hipMalloc(&h->d_fail, (size_t)S * VDL2_CS * sizeof(int)));
-	HIPCHK(h, hipMalloc(&h->d_redo, (size_t)S * VDL2_CS * sizeof(int)));
-	HIPCHK(h, hipMalloc(&h->d_cs_out, (size_t)S * VDL2_CS * sizeof(ChanState)));
-	HIPCHK(h, hipMalloc(&h->d_skey, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
-	HIPCHK(h, hipMalloc(&h->d_sidx, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
-	HIPCHK(h, hipMalloc(&h->d_prim, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
-	HIPCHK(h, hipMalloc(&h->d_seeds, (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_stage[r], (size_t)h->stage_cap * sizeof(BurstDesc)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_sel_list[r], (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_regs[r], (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_segs[r], (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_fail[r], (size_t)S * VDL2_CS * sizeof(int)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_redo[r], (size_t)S * VDL2_CS * sizeof(int)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_cs_out[r], (size_t)S * VDL2_CS * sizeof(ChanState)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_skey[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_sidx[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_prim[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
+	for (int r = 0; r < 2; ++r)
+		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	h->stage_every = std::max(1, env_int("VDL2GPU_STAGE_EVERY", h->stage_every));
 	h->k2d_grid = std::max(1, env_int("VDL2GPU_K2D_GRID", h->k2d_grid));
-	h->knob.k1_early = getenv("VDL2GPU_K1_EARLY") != nullptr;
 	h->knob.no_k1_fast = getenv("VDL2GPU_NO_K1_FAST") != nullptr;
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
 	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
@@ -634,10 +703,10 @@ static int create_impl(vdl2gpu_t *h)
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
 	 * round is always scheduled. */
 	/* Parts (see push_checked): at most 36 s of air time; until the first pushes have been collected and their candidate
-	 * density is known, 4.2 s -- a saturated channel (250 candidates a second) fills a quarter of the tables in that long. */
+	 * density is known, 8.4 s -- a saturated channel (250 candidates a second) fills half of the tables in that long. */
 	h->split_unit = ((cfg.flags & VDL2GPU_F_RTL_QUIRK) || h->sdrclk != 500 || h->L != 80) ? 32768 : K1F_PER_IN;
 	h->split_default = (size_t)(36.0 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit;
-	h->split_samples = std::max(h->split_unit, (size_t)(4.2 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit);
+	h->split_samples = std::max(h->split_unit, (size_t)(8.4 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit);
 #ifdef VDL2GPU_TESTHOOKS
 	if (getenv("VDL2GPU_SPLIT_SAMPLES")) {
 		h->split_samples = (size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES"));
@@ -783,19 +852,23 @@ static int harvest_timing(vdl2gpu_t *h)
 	for (auto &pt : h->pending) {
 		float d[NEV - 1] = {0};
 		for (int i = 0; i + 1 < NEV; ++i) {	/* the demodulator chain starts at e[10], not where the channeliser ended */
-			if (i > 0 && !pt.staged)
+			if (!pt.staged)
 				break;
-			HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : pt.e[i], pt.e[i + 1]));
+			if (i == 3)	/* the resolver alone (it may have run on its own stream, the next push's channeliser beside it) */
+				HIPCHK(h, hipEventElapsedTime(&d[i], pt.e[13], pt.e[14]));
+			else
+				HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : (i == 4 ? pt.e[12] : pt.e[i]), pt.e[i + 1]));
 		}
-		if (pt.fast) {	/* kernel intervals only: first period | (wait for the previous push's resolver) | fast kernel | tail */
+		if (pt.fast && pt.staged) {	/* kernel intervals only: first period | fast kernel | tail */
 			float a = 0, b = 0, c = 0;
 			HIPCHK(h, hipEventElapsedTime(&a, pt.e[0], pt.e[11]));
 			HIPCHK(h, hipEventElapsedTime(&b, pt.e[8], pt.e[9]));
 			HIPCHK(h, hipEventElapsedTime(&c, pt.e[9], pt.e[1]));
 			d[0] = a + b + c;
 		}
-		h->tm.channelise_ms += d[0];
-		if (pt.staged) {	/* only some pushes carry the chain's events: their mean stands for all (see vdl2gpu_get_timing) */
+		if (pt.staged) {	/* only some pushes carry events (each costs the stream ~3 us, and the channeliser now sits on the main
+					 * stream): their mean stands for all (see vdl2gpu_get_timing) */
+			h->st_k1 += d[0];
 			h->st_scan += d[1] + d[4];
 			h->st_cluster += d[2];
 			h->st_resolve += d[3] + d[5];
@@ -803,11 +876,11 @@ static int harvest_timing(vdl2gpu_t *h)
 			h->st_other += d[6];
 			h->st_pushes++;
 		}
-		if (pt.fast) {
+		if (pt.fast && pt.staged) {
 			float f = 0;
 			HIPCHK(h, hipEventElapsedTime(&f, pt.e[8], pt.e[9]));
 			h->tm.channelise_fast_ms += f;
-			h->tm.fast_pushes++;	/* counts fast-kernel launches */
+			h->tm.fast_pushes++;	/* counts the fast-kernel launches that were timed */
 		}
 		h->tm.pushes++;
 		h->tm.samples += pt.samples;
@@ -818,6 +891,7 @@ static int harvest_timing(vdl2gpu_t *h)
 }
 
 static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking);
+static int enqueue_back(vdl2gpu_t *h);
 
 template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
 {
@@ -925,6 +999,140 @@ extern "C" int vdl2gpu_ring_commit(vdl2gpu_t *h, size_t nsamples)
 	return rc;
 }
 
+
+/* The BACK stage of a push (see vdl2gpu::Back): resolver, payload decode beside the verify pass, repair rounds, commit,
+ * block path, counters -- on the main stream, behind the previous push's back stage and behind this push's front. */
+static int enqueue_back(vdl2gpu_t *h)
+{
+	if (!h->back.valid)
+		return VDL2GPU_OK;
+	h->back.valid = false;
+	const K2Params &k2 = h->back.k2;
+	const int64_t J = h->back.J;
+	const int par = h->back.par, ring = h->back.ring;
+	const bool staged = h->back.staged, serial = h->back.serial;
+	const unsigned tiles = h->back.tiles;
+	PushTiming &pt = h->pending[h->back.pt_index];
+	const dim3 gch((unsigned)h->C, (unsigned)h->S);
+	hipStream_t rs = h->stream;
+	if (h->back.two_streams)
+		HIPCHK(h, hipStreamWaitEvent(rs, h->f_done[par], 0));
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[13], rs));
+	hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, rs, k2);
+	HIPCHK(h, hipGetLastError());
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[14], rs));
+	/* The resolver's selection is final unless the verify pass fails -- then a repair round re-resolves the
+	 * channel, or K2f redoes it serially, and the host drops what K2d made of it (see harvest_ring; K2d decodes
+	 * a repaired selection in a second pass behind the rounds): decode the payloads beside the verify pass
+	 * instead of behind it. */
+	const bool spec = !h->full_scan && !serial && h->S * VDL2_CS <= 512;
+	h->ring_spec[ring] = spec;
+	if (spec)
+		HIPCHK(h, hipEventRecord(h->k2c_done, rs));
+	if (spec) {
+		HIPCHK(h, hipStreamWaitEvent(h->pay_stream, h->k2c_done, 0));
+		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
+		HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
+	}
+	if (staged) {
+		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
+		HIPCHK(h, hipEventRecord(pt.e[12], h->stream));
+	}
+	if (!serial)
+		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+	HIPCHK(h, hipGetLastError());
+	if (!h->full_scan && !serial) {
+		/* repair round: channels whose verify found an unlisted hit are re-sorted, re-clustered,
+		 * re-resolved and re-verified with that hit in their table; every other channel's
+		 * workgroups exit at once.  What still fails is redone serially by K2f. */
+		K2Params k2r = k2;
+		if (spec && h->repair_rounds > 0)	/* a repair round rewrites the selection K2d is reading */
+			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));
+		for (int rr = 1; rr <= h->repair_rounds; ++rr) {
+			k2r.round = rr;
+			/* The LAST scheduled round does not repair, it starts over: the channels that still fail are scanned
+			 * completely -- every class at every instant, like VDL2GPU_F_FULLSCAN but for them alone (≈ 0.1 ms for
+			 * a channel of a 67 MS push) --, which leaves nothing to verify and nothing to cascade; before it,
+			 * rounds that only scan around what the verify pass found (cheaper when they suffice). */
+			k2r.full_round = (rr == h->repair_rounds) ? 1 : 0;
+			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2r);
+			if (k2r.full_round) {
+				const unsigned want = tiles;
+				unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
+				per = per > want ? want : per;
+				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+			} else
+			hipLaunchKernelGGL(k2a_region, dim3(32, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
+			hipLaunchKernelGGL(k2b_clusters, dim3(k2r.full_round ? (unsigned)(h->n_cu * 4 * K2B_WAVES) : 256u, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
+			hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
+			if (!k2r.full_round)	/* (complete tables leave nothing to verify) */
+				hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+		}
+		HIPCHK(h, hipGetLastError());
+	}
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
+	hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
+	if (h->ring_spec[ring]) {
+		HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
+		if (h->repair_rounds > 0 && !h->full_scan && !serial) {
+			K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
+			k2p.pay_final = 1;
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2p);
+		}
+	} else
+		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2);
+	HIPCHK(h, hipGetLastError());
+	if (h->frames_on) {
+		/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
+		 * a latency-bound kernel like this one and the next push's scan slow each other down by
+		 * more than the overlap saves. */
+		K4Params k4{};
+		k4.recs = h->d_recs[ring];
+		k4.nrecs_dev = h->d_outc + 2 * ring;
+		k4.rec_cap = h->rec_cap;
+		k4.frames = h->d_frames[ring];
+		k4.nframes = h->d_fcnt + 4 * ring;
+		k4.frame_cap = h->frame_cap;
+		k4.compact = 1;
+		k4.tabs = h->d_k4tab;
+		k4.fmask = h->ring_spec[ring] ? h->d_fmask[par] : nullptr;
+		k4.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
+		hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 16), dim3(K4_NT), 0, h->stream, k4);
+		HIPCHK(h, hipGetLastError());
+	}
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
+	{
+		K3Params k3{};
+		k3.src = h->d_dec[par];
+		k3.dst = h->d_dec[par ^ 1];
+		k3.cap = h->cap;
+		k3.nbch = h->C;
+		k3.J = J;
+		k3.ss = h->d_ss;
+		k3.cs = h->d_cs;
+		k3.outc = h->d_outc;
+		k3.fmask = h->d_fmask[par];
+		k3.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
+		k3.host_cnt = h->d_pin_cnt + 32 * ring;
+		k3.ring = ring;
+		k3.ctl = h->d_ctl[par];
+		k3.nstreams = h->S;
+		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
+		HIPCHK(h, hipGetLastError());
+	}
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
+	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
+	h->k2_rec[par] = true;
+	/* (the same event tells the host that this push's output ring is complete: ring == par) */
+	return VDL2GPU_OK;
+}
+
 static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy)
 {
 	if (!h || (!iq && nsamples))
@@ -941,19 +1149,13 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	}
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	if (h->pending.size() >= 256) {	/* bound the event backlog */
-		HIPCHK(h, hipStreamSynchronize(h->k1_stream));
+		HIPCHK(h, hipStreamSynchronize(h->fstream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		int rc = harvest_timing(h);
 		if (rc)
 			return rc;
 	}
-	/* output ring of this push; if the push that last used it has not been collected yet, collect it now */
-	const int ring = (int)(h->pushes & 1);
-	if (h->ring_busy[ring]) {
-		int rc = harvest_ring(h, ring, true);
-		if (rc < 0)
-			return rc;
-	}
+	const int ring = (int)(h->pushes & 1);	/* output ring of this push (collected below, once the GPU has been given work to do meanwhile) */
 	const void *src = iq;
 	size_t stride = stream_stride_bytes;
 	bool staged_in = false;
@@ -967,7 +1169,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				HIPCHK(h, hipEventCreateWithFlags(&h->raw_copied[i], hipEventDisableTiming));
 		}
 		if (need > h->raw_bytes[stg]) {
-			HIPCHK(h, hipStreamSynchronize(h->k1_stream));
+			HIPCHK(h, hipStreamSynchronize(h->fstream));
+			HIPCHK(h, hipStreamSynchronize(h->stream));
 			HIPCHK(h, hipStreamSynchronize(h->in_stream));
 			(void)hipFree(h->d_raw[stg]);
 			h->d_raw[stg] = nullptr;
@@ -1010,6 +1213,18 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	k1.dec = h->d_dec[par];
 	k1.cap = h->cap;
 	k1.ss = h->d_ss;
+	/* A short push (a live SDR block is 1376 frames per channel) is cheaper on the serial machine alone
+	 * than through the scan's ten launches: the parallel path only pays from a few thousand frames on. */
+#ifdef VDL2GPU_TESTHOOKS
+	const bool noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) != 0;
+#else
+	const bool noregion = false;
+#endif
+	const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !noregion);
+	const bool two_streams = !serial;	/* see vdl2gpu::Back */
+	hipStream_t fs = two_streams ? h->fstream : h->stream;
+	/* stream time of frame 0 of this push's planes: the outputs completed before it, minus the carried frames in front */
+	const long long dec_base = (long long)(((unsigned __int128)h->total_in * 21u) / (unsigned)h->sdrclk) - VDL2_CARRY_FRAMES;
 
 	PushTiming pt{};
 	int rc = get_events(h, pt);
@@ -1019,21 +1234,34 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	pt.fast = false;
 	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
 	const bool staged = pt.staged;
-	/* Two streams.  The channeliser of this push only needs the plane set it writes to be free
-	 * (the demodulator of the push before last has finished with it), so it runs on its own
-	 * stream beside the demodulator chain of the previous push, whose one-workgroup-per-channel
-	 * steps leave most of the GPU idle. */
-	hipStream_t ks = h->k1_stream;
+	/* The channeliser goes on the MAIN stream, in front of the previous push's back half (see vdl2gpu::Back): in stream
+	 * order it follows that push's cluster kernel and runs beside its resolver.  The plane set it writes was released by
+	 * the push before last, earlier on the same stream. */
+	hipStream_t ks = fs;
+	if (two_streams) {
+		/* the plane set and the table set of this parity were last used by the push before last */
+		if (h->k2_rec[par])
+			HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par], 0));
+		if (h->k1_ev_rec && !h->last_two_streams)	/* the previous push's channeliser ran on the main stream */
+			HIPCHK(h, hipStreamWaitEvent(fs, h->k1_ev, 0));
+	}
 	if (staged_in)
 		HIPCHK(h, hipStreamWaitEvent(ks, h->raw_copied[stg], 0));
-	if (h->k2_rec[par])
-		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_done[par], 0));
-	/* start beside the previous push's candidate sort, not beside its scan: the first period's small kernel
-	 * runs there, so that the big one starts the moment the resolver does (waiting with both until then
-	 * saves an event record, 3 us, and loses 15) */
-	if (h->k2_mid_rec && !h->knob.k1_early)
-		HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid_a, 0));
-	HIPCHK(h, hipEventRecord(pt.e[0], ks));
+	if (h->pushes > 0) {
+		/* the carry: the last 49152 frames of the previous push's planes (its own carry included if it was shorter) go in
+		 * front of this push's output -- a fixed amount, so that it does not wait for the previous push's resolver to say
+		 * how much is still unconsumed (3 MB per stream) */
+		K3Params k3{};
+		k3.src = h->d_dec[par ^ 1];
+		k3.dst = h->d_dec[par];
+		k3.cap = h->cap;
+		k3.nbch = h->C;
+		k3.J = h->last_J;
+		hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, fs, k3);
+		HIPCHK(h, hipGetLastError());
+	}
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
 		const long long per_block = K1_OPB * K1_PASSES;
 		const size_t smem = ((size_t)(h->L + h->maxwin) * VDL2_CS + (size_t)K1_OPB * h->maxwin) * sizeof(float2);
@@ -1083,16 +1311,16 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			const bool whole = k1.c0 == 0 && nsamples % K1F_PER_IN == 0 && J == nsp * K1F_PER_OUT;
 			if (!whole)
 				generic(0, K1F_PER_OUT - 1);
-			(void)hipEventRecord(pt.e[11], ks);	/* the wait for the resolver that follows is not channeliser time */
+			if (staged)
+				(void)hipEventRecord(pt.e[11], ks);	/* the wait for the resolver that follows is not channeliser time */
 			pt.fast = true;
 			k1.per_lo = whole ? 0 : 1;
 			k1.per_n = whole ? nsp : nsp - 2;
 			k1.edge_state = whole ? 1 : 0;
 			k1.lo_ext = h->d_lo_ext;
 			k1.lo_stride = h->L + 48;
-			if (h->k2_mid_rec && !h->knob.k1_early)	/* beside the previous push's resolver */
-				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
-			(void)hipEventRecord(pt.e[8], ks);
+			if (staged)
+				(void)hipEventRecord(pt.e[8], ks);
 			/* The grid is resident as a whole: n_cu * 2 * K1F_WAVES_OF(fmt) workgroups of two wavefronts fit.  Per stream
 			 * 21 roles x 8 XCDs families of `nfam` workgroups each, which take the family's tickets in turn (see k1_fast);
 			 * a family needs no more workgroups than it has tickets.  With several streams the families are many and
@@ -1127,13 +1355,15 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CF32>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 			default: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_F32R>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 			}
-			(void)hipEventRecord(pt.e[9], ks);
+			if (staged)
+				(void)hipEventRecord(pt.e[9], ks);
 			pt.fast_parts = 1;
 			if (!whole)
 				generic((nsp - 1) * K1F_PER_OUT, J);
 		} else if (fast) {
 			generic(0, K1P_PER_OUT - 1);
-			(void)hipEventRecord(pt.e[11], ks);
+			if (staged)
+				(void)hipEventRecord(pt.e[11], ks);
 			pt.fast = true;
 			kp.raw = src;
 			kp.stream_stride = stride;
@@ -1181,9 +1411,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				best = h->knob.k1_nsub;
 			kp.nsub = best;
 			kp.wpt = K1P_PER_OUT / best;
-			if (h->k2_mid_rec && !h->knob.k1_early)	/* beside the previous push's resolver */
-				HIPCHK(h, hipStreamWaitEvent(ks, h->k2_mid, 0));
-			(void)hipEventRecord(pt.e[8], ks);
+			if (staged)
+				(void)hipEventRecord(pt.e[8], ks);
 			const dim3 grid((unsigned)(blocks * kp.nsub), (unsigned)h->S);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CU8>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
@@ -1191,31 +1420,46 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			case VDL2GPU_FMT_CF32: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CF32>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
 			default: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_F32R>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
 			}
-			(void)hipEventRecord(pt.e[9], ks);
+			if (staged)
+				(void)hipEventRecord(pt.e[9], ks);
 			pt.fast_parts = 1;
 			generic((periods - 1) * K1P_PER_OUT, J);
 		} else
 			generic(0, J);
 		HIPCHK(h, hipGetLastError());
 	}
-	HIPCHK(h, hipEventRecord(pt.e[1], ks));
-	HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
-	h->k1_rec[par] = true;
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[1], ks));
+	if (staged_in) {	/* (only the staging copy of the push after next waits for it) */
+		HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
+		h->k1_rec[par] = true;
+	}
+	if (!two_streams) {	/* a later push's front stage must see this channeliser's planes and carry state */
+		HIPCHK(h, hipEventRecord(h->k1_ev, ks));
+		h->k1_ev_rec = true;
+	}
+	/* The output ring of this push: if the push that last used it (the one before last) has not been collected yet,
+	 * collect it now -- the GPU has the previous push's chain and this push's channeliser to work on while this thread
+	 * waits for that push's records and copies them. */
+	if (h->ring_busy[ring]) {
+		const int rch = harvest_ring(h, ring, true);
+		if (rch < 0)
+			return rch;
+	}
 	{
 		KInitParams ki{};
-		ki.ctl = h->d_ctl + CTL_STAGE;
+		ki.ctl = h->d_ctl[par] + CTL_STAGE;
 		ki.ctl_words = (int)(h->ctl_words - CTL_STAGE);
 		ki.outc = h->d_outc + 2 * ring;
-		ki.fail = h->d_fail;
-		ki.redo = h->d_redo;
+		ki.fail = h->d_fail[par];
+		ki.redo = h->d_redo[par];
 		ki.nsc = h->S * VDL2_CS;
-		ki.fmask = h->d_fmask;
+		ki.fmask = h->d_fmask[par];
 		ki.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
-		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, h->stream, ki);
+		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, fs, ki);
 	}
-	HIPCHK(h, hipStreamWaitEvent(h->stream, h->k1_done[par], 0));
 	if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[10], h->stream));
+		HIPCHK(h, hipEventRecord(pt.e[10], fs));
 	{
 		K2Params k2{};
 		k2.dec = h->d_dec[par];
@@ -1227,26 +1471,22 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.cs = h->d_cs;
 		k2.cfg = h->d_cfg;
 		k2.pn = h->d_pn;
-		k2.cands = h->d_cands;
-		k2.clusters = h->d_clusters;
-		k2.clhead = h->d_clhead;
-		k2.ctl = h->d_ctl;
-		k2.stage = h->d_stage;
-		k2.sel_list = h->d_sel_list;
+		k2.cands = h->d_cands[par];
+		k2.clusters = h->d_clusters[par];
+		k2.clhead = h->d_clhead[par];
+		k2.ctl = h->d_ctl[par];
+		k2.stage = h->d_stage[par];
+		k2.sel_list = h->d_sel_list[par];
 		k2.stage_cap = h->stage_cap;
 		k2.recs = h->d_recs[ring];
 		k2.outc = h->d_outc + 2 * ring;
 		k2.outc_total_redo = h->d_outc + 4;
-		k2.fmask = h->d_fmask;
+		k2.fmask = h->d_fmask[par];
 		k2.rec_cap = h->rec_cap;
-		/* A short push (a live SDR block is 1376 frames per channel) is cheaper on the serial machine alone
-		 * than through the scan's ten launches: the parallel path only pays from a few thousand frames on. */
-#ifdef VDL2GPU_TESTHOOKS
-		const bool noregion = (h->cfg.flags & VDL2GPU_F_TEST_NOREGION) != 0;
-#else
-		const bool noregion = false;
-#endif
-		const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !noregion);
+		k2.dec_base = dec_base;
+		k2.scan_lo = dec_base + VDL2_HIST;	/* the scan starts at the first carried frame that has its history */
+		k2.probe_r = 0;				/* the one class scanned everywhere: fixed, not the class the channel is in */
+		k2.probe_par = (int)((dec_base + VDL2_HIST) & 1);
 		k2.force_serial = serial ? 1 : 0;
 		k2.prim_drop = h->prim_drop;
 		k2.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
@@ -1254,19 +1494,19 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.headtap_n = h->d_headtap_n;
 		k2.headtap_cap = h->headtap_cap;
 		if (h->d_headtap)
-			HIPCHK(h, hipMemsetAsync(h->d_headtap_n, 0, sizeof(unsigned), h->stream));
+			HIPCHK(h, hipMemsetAsync(h->d_headtap_n, 0, sizeof(unsigned), fs));
 		k2.full_scan = h->full_scan;
 		k2.test_noregion = noregion ? 1 : 0;
-		k2.regs = h->d_regs;
-		k2.segs = h->d_segs;
-		k2.fail = h->d_fail;
-		k2.redo = h->d_redo;
+		k2.regs = h->d_regs[par];
+		k2.segs = h->d_segs[par];
+		k2.fail = h->d_fail[par];
+		k2.redo = h->d_redo[par];
 		k2.round = 0;
-		k2.cs_out = h->d_cs_out;
-		k2.skey = h->d_skey;
-		k2.sidx = h->d_sidx;
-		k2.prim = h->d_prim;
-		k2.seeds = h->d_seeds;
+		k2.cs_out = h->d_cs_out[par];
+		k2.skey = h->d_skey[par];
+		k2.sidx = h->d_sidx[par];
+		k2.prim = h->d_prim[par];
+		k2.seeds = h->d_seeds[par];
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
 		if (!serial) {
@@ -1275,137 +1515,46 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				const unsigned want = h->full_scan ? tiles : tiles / 2 + 1;
 				unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * h->S - 1) / (h->C * h->S));
 				per = per < 1 ? 1 : (per > want ? want : per);
-				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, fs, k2);
 			}
-			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2);
-			hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs, k2);
+			hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, fs, k2);
 			HIPCHK(h, hipGetLastError());
 		}
-		HIPCHK(h, hipEventRecord(h->k2_mid_a, h->stream));
 		if (!serial)
-			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2);
+			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs, k2);
 		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[2], h->stream));
+		HIPCHK(h, hipEventRecord(pt.e[2], fs));
 		if (!serial)
-			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2);
+			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs, k2);
 		HIPCHK(h, hipGetLastError());
 		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[3], h->stream));
-		HIPCHK(h, hipEventRecord(h->k2_mid, h->stream));
-		h->k2_mid_rec = true;
-		hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2);
-		HIPCHK(h, hipGetLastError());
-		/* The resolver's selection is final unless the verify pass fails -- then a repair round re-resolves the
-		 * channel, or K2f redoes it serially, and the host drops what K2d made of it (see harvest_ring; K2d decodes
-		 * a repaired selection in a second pass behind the rounds): decode the payloads beside the verify pass
-		 * instead of behind it. */
-		const bool spec = !h->full_scan && !serial && h->S * VDL2_CS <= 512;
-		h->ring_spec[ring] = spec;
-		if (spec) {
-			HIPCHK(h, hipEventRecord(h->k2c_done, h->stream));
-			HIPCHK(h, hipStreamWaitEvent(h->pay_stream, h->k2c_done, 0));
-			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
-			HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
-		}
-		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
-		if (!serial)
-			hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
-		HIPCHK(h, hipGetLastError());
-		if (!h->full_scan && !serial) {
-			/* repair round: channels whose verify found an unlisted hit are re-sorted, re-clustered,
-			 * re-resolved and re-verified with that hit in their table; every other channel's
-			 * workgroups exit at once.  What still fails is redone serially by K2f. */
-			K2Params k2r = k2;
-			if (spec && h->repair_rounds > 0)	/* a repair round rewrites the selection K2d is reading */
-				HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));
-			for (int rr = 1; rr <= h->repair_rounds; ++rr) {
-				k2r.round = rr;
-				/* The LAST scheduled round does not repair, it starts over: the channels that still fail are scanned
-				 * completely -- every class at every instant, like VDL2GPU_F_FULLSCAN but for them alone (≈ 0.1 ms for
-				 * a channel of a 67 MS push) --, which leaves nothing to verify and nothing to cascade; before it,
-				 * rounds that only scan around what the verify pass found (cheaper when they suffice). */
-				k2r.full_round = (rr == h->repair_rounds) ? 1 : 0;
-				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2r);
-				if (k2r.full_round) {
-					const unsigned want = tiles;
-					unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
-					per = per > want ? want : per;
-					hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
-				} else
-				hipLaunchKernelGGL(k2a_region, dim3(32, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
-				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
-				hipLaunchKernelGGL(k2b_clusters, dim3(k2r.full_round ? (unsigned)(h->n_cu * 4 * K2B_WAVES) : 256u, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
-				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
-				if (!k2r.full_round)	/* (complete tables leave nothing to verify) */
-					hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
-			}
-			HIPCHK(h, hipGetLastError());
-		}
-		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
-		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
-		if (h->ring_spec[ring]) {
-			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
-			if (h->repair_rounds > 0 && !h->full_scan && !serial) {
-				K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
-				k2p.pay_final = 1;
-				hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2p);
-			}
-		} else
-			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2);
-		HIPCHK(h, hipGetLastError());
-		if (h->frames_on) {
-			/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
-			 * a latency-bound kernel like this one and the next push's scan slow each other down by
-			 * more than the overlap saves. */
-			K4Params k4{};
-			k4.recs = h->d_recs[ring];
-			k4.nrecs_dev = h->d_outc + 2 * ring;
-			k4.rec_cap = h->rec_cap;
-			k4.frames = h->d_frames[ring];
-			k4.nframes = h->d_fcnt + 4 * ring;
-			k4.frame_cap = h->frame_cap;
-			k4.compact = 1;
-			k4.tabs = h->d_k4tab;
-			k4.fmask = h->ring_spec[ring] ? h->d_fmask : nullptr;
-			k4.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
-			hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 16), dim3(K4_NT), 0, h->stream, k4);
-			HIPCHK(h, hipGetLastError());
-		}
+		HIPCHK(h, hipEventRecord(pt.e[3], fs));
+		/* ---- end of the FRONT stage */
+		if (two_streams)
+			HIPCHK(h, hipEventRecord(h->f_done[par], fs));
+		h->back.valid = true;
+		h->back.k2 = k2;
+		h->back.J = J;
+		h->back.par = par;
+		h->back.ring = ring;
+		h->back.staged = staged;
+		h->back.serial = serial;
+		h->back.two_streams = two_streams;
+		h->back.tiles = tiles;
+		h->back.pt_index = h->pending.size();
 	}
-	if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
+	h->pending.push_back(pt);
 	{
-		K3Params k3{};
-		k3.src = h->d_dec[par];
-		k3.dst = h->d_dec[par ^ 1];
-		k3.cap = h->cap;
-		k3.nbch = h->C;
-		k3.J = J;
-		k3.ss = h->d_ss;
-		k3.cs = h->d_cs;
-		k3.outc = h->d_outc;
-		k3.fmask = h->d_fmask;
-		k3.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
-		k3.host_cnt = h->d_pin_cnt + 32 * ring;
-		k3.ring = ring;
-		k3.ctl = h->d_ctl;
-		k3.nstreams = h->S;
-		hipLaunchKernelGGL(k3_compact, dim3((unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, h->stream, k3);
-		HIPCHK(h, hipGetLastError());
-		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
-		HIPCHK(h, hipGetLastError());
+		const int rcb = enqueue_back(h);
+		if (rcb)
+			return rcb;
 	}
-	if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
-	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
-	h->k2_rec[par] = true;
-	/* (the same event tells the host that this push's output ring is complete: ring == par) */
+	h->last_J = J;
+	h->last_two_streams = two_streams;
 	h->ring_busy[ring] = true;
 	h->ring_push[ring] = h->pushes;
 	h->ring_samples[ring] = nsamples;
-	h->pending.push_back(pt);
 	h->total_in += nsamples;
 	h->pushes++;
 	return VDL2GPU_OK;
@@ -1416,7 +1565,7 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 	if (!h)
 		return VDL2GPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
-	HIPCHK(h, hipStreamSynchronize(h->k1_stream));
+	HIPCHK(h, hipStreamSynchronize(h->fstream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	return harvest_timing(h);
 }
@@ -1443,8 +1592,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	h->overflowed += c1;
 	if (!h->knob.split_fixed && h->ring_samples[ring]) {
 		/* How long a part may be follows from how many trigger candidates the busiest channel produced per input sample
-		 * in the pushes collected lately (the highest of the last eight): parts are sized to fill 55 % of the tables, so
-		 * that traffic may grow by 80 % from one push to the next before a channel overflows them.  A channel that does
+		 * in the pushes collected lately (the highest of the last eight): parts are sized to fill 90 % of the tables, so
+		 * that traffic may grow by a tenth from one push to the next before a channel overflows them.  A channel that does
 		 * overflow is handled by the serial machine for that part (exact, milliseconds); its density then counts as
 		 * twice what the tables hold.  Round 2 halved the parts on an overflow and doubled them again after 1024 quiet
 		 * pushes: busy channels ended up in parts a quarter full. */
@@ -1459,7 +1608,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			dmax = std::max(dmax, x);
 		size_t lim = h->split_default;
 		if (dmax > 0.0)
-			lim = (size_t)std::min((double)h->split_default, 0.55 * (double)VDL2_CAND_CAP / dmax);
+			lim = (size_t)std::min((double)h->split_default, 0.90 * (double)VDL2_CAND_CAP / dmax);
 		h->split_samples = std::max(h->split_unit, lim / h->split_unit * h->split_unit);
 		if (novf)
 			h->last_ovf_push = h->ring_push[ring];
@@ -1850,6 +1999,7 @@ extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset
 		/* stage sums: mean of the pushes that carried stage events x all pushes (the staged ones are every
 		 * stage_every-th: scaling their sum by stage_every was biased whenever pushes % stage_every != 0) */
 		const double k = h->st_pushes ? (double)h->tm.pushes / (double)h->st_pushes : 0.0;
+		out->channelise_ms = k * h->st_k1;
 		out->scan_ms = k * h->st_scan;
 		out->cluster_ms = k * h->st_cluster;
 		out->resolve_ms = k * h->st_resolve;
@@ -1858,7 +2008,7 @@ extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset
 	}
 	if (reset) {
 		h->tm = vdl2gpu_timing_t{};
-		h->st_scan = h->st_cluster = h->st_resolve = h->st_demod = h->st_other = 0;
+		h->st_scan = h->st_cluster = h->st_resolve = h->st_demod = h->st_other = h->st_k1 = 0;
 		h->st_pushes = 0;
 	}
 	return VDL2GPU_OK;
@@ -1945,11 +2095,11 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) & 1] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, VDL2_CAND_CAP);
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_cands + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_cands[(h->pushes - 1) & 1] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -1962,7 +2112,7 @@ extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
-	HIPCHK(h, hipMemcpy(out, h->d_fail, (size_t)h->S * VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(out, h->d_fail[(h->pushes - 1) & 1], (size_t)h->S * VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
 	return h->S * VDL2_CS;
 }
 
@@ -1975,10 +2125,10 @@ extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, in
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) & 1] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, (unsigned)std::min(max_segs, VDL2_SEG_CAP));
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_segs + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_segs[(h->pushes - 1) & 1] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 

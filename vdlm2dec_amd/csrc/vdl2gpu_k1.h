@@ -55,7 +55,7 @@ void k1_channelise(K1Params p)
 	}
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride;
 	StreamState *ss = p.ss + s;
-	const long long fill = ss->dec_fill;
+	const long long fill = VDL2_CARRY_FRAMES;	/* a push's output always starts at that frame */
 	const long long jb = p.jbeg + (long long)blockIdx.x * (K1_OPB * K1_PASSES);
 	if (blockIdx.x == 0 && tid == 0 && p.jbeg == 0) {
 		ss->last_fill = fill;
@@ -325,7 +325,7 @@ void k1_pp(K1PParams p)
 	const int k0 = sub * p.wpt, k1 = k0 + p.wpt;		/* this task's windows of the period */
 	const int pb = blk * 64;				/* its first period, counted from per_lo */
 	const int nper = (p.per_n - pb < 64) ? p.per_n - pb : 64;
-	const long long fill = p.ss[s].dec_fill;
+	const long long fill = VDL2_CARRY_FRAMES;
 	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride + (size_t)p.sbase0 * B;	/* first sample of period per_lo */
 
@@ -781,7 +781,7 @@ void k1_fast(K1Params p)
 	if (p.edge_state && blockIdx.x == 0 && tid < VDL2_CS) {	/* (rank 0 of XCD 0: never empty) what k1_channelise leaves at a push's two ends */
 		StreamState *ss = p.ss + s;
 		if (tid == 0) {
-			ss->last_fill = ss->dec_fill;
+			ss->last_fill = VDL2_CARRY_FRAMES;
 			ss->last_J = p.J;
 		}
 		ss->acc[p.parity ^ 1][tid] = make_float2(0.0f, 0.0f);	/* the push ends on a window boundary: nothing carried */
@@ -855,7 +855,7 @@ void k1_fast(K1Params p)
 	}
 	const float fn = (float)nwin;
 	const float rfn = 1.0f / fn;	/* RN(1/nf) for the exact FMA division below */
-	const float2 *dec = p.dec + (size_t)s * VDL2_CS * p.cap + p.ss[s].dec_fill + (p.per_lo + x) * K1F_PER_OUT + g * 16;	/* workgroup-uniform */
+	const float2 *dec = p.dec + (size_t)s * VDL2_CS * p.cap + VDL2_CARRY_FRAMES + (p.per_lo + x) * K1F_PER_OUT + g * 16;	/* workgroup-uniform */
 	const unsigned dvo = (unsigned)(((size_t)(active ? c : 0) * p.cap + kk) * sizeof(float2));	/* planes are < 4 GB apart */
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* from here on the only memory operations are the counted ones below */
 #pragma unroll

@@ -3,38 +3,30 @@
 #define VDL2GPU_K3_H
 
 /* ======================================================================= K3
- * Move the frames no channel has consumed yet (plus history) to the front of
- * the other ping-pong plane set and rebase stream time.  Normally ~170 frames
- * per plane; up to one full burst when a channel waits for the end of one.
+ * The carry: the last VDL2_CARRY_FRAMES frames of the previous push's planes (49152: the longest burst plus history) go
+ * in front of this push's output in the other plane set, right-aligned below frame VDL2_CARRY_FRAMES where the
+ * channeliser starts writing.  A FIXED amount: round 2 copied only what no channel had consumed yet, which made the
+ * copy -- and with it the next push's scan -- wait for the resolver.  p.J = outputs of the previous push: its frames
+ * [J, J + VDL2_CARRY_FRAMES) are the stretch (part of ITS carry if it was shorter than that).
  */
 #define K3_THREADS 256
 __global__ __launch_bounds__(K3_THREADS)
-void k3_compact(K3Params p)
+void k3_carry(K3Params p)
 {
-	const int s = blockIdx.y, c = blockIdx.x;
-	const StreamState *ss = p.ss + s;
-	long long mn = 0x7fffffffffffffffLL;
-	for (int k = 0; k < p.nbch; ++k) {
-		const long long q = p.cs[(size_t)s * VDL2_CS + k].pos;
-		mn = q < mn ? q : mn;
-	}
-	const long long base = ss->dec_base;
-	const long long end = base + ss->dec_fill + p.J;
-	long long nb = mn - VDL2_HIST;
-	if (nb > end - VDL2_HIST)
-		nb = end - VDL2_HIST;	/* always keep the history */
-	if (nb < base)
-		nb = base;
-	if (nb < end - VDL2_CARRY_FRAMES)
-		nb = end - VDL2_CARRY_FRAMES;	/* cannot happen: no burst is that long */
-	const long long keep = end - nb;
-	/* the carry sits right-aligned below frame VDL2_CARRY_FRAMES of the other plane set, so that the
-	 * channeliser of the next push -- which writes from that frame on -- does not depend on how
-	 * much is carried and may run while this push is still being demodulated */
-	const float2 *src = p.src + ((size_t)s * VDL2_CS + c) * p.cap + (nb - base);
-	float2 *dst = p.dst + ((size_t)s * VDL2_CS + c) * p.cap + (VDL2_CARRY_FRAMES - keep);
-	for (long long i = threadIdx.x; i < keep; i += K3_THREADS)
-		dst[i] = src[i];
+	const int c = blockIdx.y, s = blockIdx.z;
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	const size_t plane = ((size_t)s * VDL2_CS + c) * p.cap;
+	const float2 *src = p.src + plane + p.J;
+	float2 *dst = p.dst + plane;
+	const int i0 = (int)(blockIdx.x * K3_THREADS + threadIdx.x), step = (int)(gridDim.x * K3_THREADS);
+	if ((p.J & 1) == 0) {	/* planes start on 128-byte lines: an even offset keeps 16-byte alignment */
+		const v4f *s4 = reinterpret_cast<const v4f *>(src);
+		v4f *d4 = reinterpret_cast<v4f *>(dst);
+		for (int i = i0; i < VDL2_CARRY_FRAMES / 2; i += step)
+			d4[i] = s4[i];
+	} else
+		for (int i = i0; i < VDL2_CARRY_FRAMES; i += step)
+			dst[i] = src[i];
 }
 
 /* one launch instead of four memsets */
@@ -88,18 +80,8 @@ __global__ void k3_rebase(K3Params p)
 		p.host_cnt[7] = novf;
 		p.host_cnt[24] = maxc;
 	}
-	StreamState *ss = p.ss + s;
-	long long mn = 0x7fffffffffffffffLL;
-	for (int k = 0; k < p.nbch; ++k) {
-		const long long q = p.cs[(size_t)s * VDL2_CS + k].pos;
-		mn = q < mn ? q : mn;
-	}
-	const long long base = ss->dec_base;
-	const long long end = base + ss->dec_fill + p.J;
-	long long nb = mn - VDL2_HIST;
-	if (nb > end - VDL2_HIST)
-		nb = end - VDL2_HIST;
-	ss->dec_base = end - VDL2_CARRY_FRAMES;	/* frame VDL2_CARRY_FRAMES = first output of the next push */
+	StreamState *ss = p.ss + s;	/* (diagnostics: the kernels take the time base from their parameters) */
+	ss->dec_base = ss->dec_base + ss->dec_fill + p.J - VDL2_CARRY_FRAMES;	/* frame VDL2_CARRY_FRAMES = first output of the next push */
 	ss->dec_fill = VDL2_CARRY_FRAMES;
 }
 

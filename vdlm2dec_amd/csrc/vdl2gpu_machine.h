@@ -662,10 +662,9 @@ template <int NT, bool XL> __device__ __forceinline__ int machine_run(MachShared
 
 __device__ __forceinline__ void mach_ctx(MachCtx &cx, const K2Params &p, int s, int c, bool to_stage)
 {
-	const StreamState *ss = p.ss + s;
 	cx.x = p.dec + ((size_t)s * VDL2_CS + c) * p.cap;
-	cx.dec_base = ss->dec_base;
-	cx.avail_end = ss->dec_base + ss->dec_fill + p.J;
+	cx.dec_base = p.dec_base;
+	cx.avail_end = p.dec_base + VDL2_CARRY_FRAMES + p.J;
 	cx.pn = p.pn;
 	cx.sc = s * VDL2_CS + c;
 	cx.dbg = to_stage ? p.dbg : nullptr;

@@ -33,7 +33,7 @@ void k2s_sort(K2Params p)
 	if (tid == 0)
 		s_np = 0;
 	__syncthreads();
-	wg_sort_u64<K2S_NT>(sbuf, ws, ncand, 18, (unsigned)(p.ss[s].dec_fill + p.J));
+	wg_sort_u64<K2S_NT>(sbuf, ws, ncand, 18, (unsigned)(VDL2_CARRY_FRAMES + p.J));
 	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
 	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
 	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
@@ -311,8 +311,7 @@ void k2c_resolve(K2Params p)
 	st.pos = cs->pos;
 	st.r = cs->r;
 	st.fresh = cs->fresh;
-	const int r_probe = cs->r;
-	const int par_probe = (int)(cs->pos & 1);	/* the probe scanned class (r_probe, par_probe) everywhere */
+	const int r_probe = p.probe_r, par_probe = p.probe_par;	/* the probe scanned class (r_probe, instants of parity par_probe) everywhere */
 	const int t_end = (int)(cx.avail_end - cx.dec_base);
 	const bool lazy = !p.full_scan && !p.full_round;	/* (a full round's tables hold every class: nothing is left to verify) */
 	mach_init_taps(sh);
@@ -749,7 +748,7 @@ void k2d_payload(K2Params p)
 		if (slot != 0xffffffffu) {
 			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
-			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.ss[s].dec_base;
+			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.dec_base;
 			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc);
 		}
 		__syncthreads();

@@ -119,6 +119,15 @@ __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long de
 	if (mode == 0 || mode == 2) {
 		if (r == skip_r && (int)(n & 1) == skip_par)
 			return;	/* that class is the probe's: already in the table */
+		/* The free-running test fires at EVERY rising step while the previous error is below 4 -- two or three instants
+		 * in a row behind each minimum (17.6 candidates per burst: 8 classes x 2.2) --, but a real detector takes the
+		 * first and is busy from then on; a later one of the run could only be taken by a chain that turns idle exactly
+		 * between two of them (one burst ending inside another's sync word).  Only the first of a run is listed: the
+		 * tables hold twice the bursts.  Should a chain ever stand between two steps of a run, the verify pass finds the
+		 * unlisted hit (it tests every instant of the stretch the chain idled through) and the repair rounds, which list
+		 * everything, put it in. */
+		if (p.round == 0 && p2err < 4.0f && perr > p2err)
+			return;
 	} else {
 		if (n < chk_lo || n >= chk_hi)
 			return;
@@ -482,9 +491,8 @@ void k2a_probe(K2Params p)
 	__shared__ K2aShared sh;
 	const int c = blockIdx.y, s = blockIdx.z;
 	const int sc = s * VDL2_CS + c;
-	const StreamState *ss = p.ss + s;
-	const long long dec_base = ss->dec_base;
-	const long long avail_end = dec_base + ss->dec_fill + p.J;
+	const long long dec_base = p.dec_base;
+	const long long avail_end = dec_base + VDL2_CARRY_FRAMES + p.J;
 	if (p.force_serial)
 		return;
 	if (p.round > 0 && (!p.full_round || p.fail[sc] >= VDL2_VERIFIED))
@@ -497,7 +505,7 @@ void k2a_probe(K2Params p)
 		K2aPre<1> pre;
 		pre.loaded = false;
 		const long long step = (long long)gridDim.x * K2A_TS;
-		for (long long n0 = p.cs[sc].pos + (long long)blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
+		for (long long n0 = p.scan_lo + (long long)blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
 			const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
 			const long long n1 = n0 + step;
 			const int nt1 = n1 < avail_end ? (int)((avail_end - n1 < K2A_TS) ? (avail_end - n1) : K2A_TS) : 0;
@@ -506,12 +514,13 @@ void k2a_probe(K2Params p)
 		k2a_flush(sh, p, sc, dec_base, 0, nullptr, -1, 0);
 		return;
 	}
-	/* the class the channel's detector is in right now: sub-phase r, parity of pos */
+	/* ONE class everywhere: sub-phase probe_r at the instants of scan_lo's parity -- any class finds the bursts; which
+	 * stretches the chain relied on in OTHER classes is what the verify pass re-scans */
 	K2aPre<2> pre;
 	pre.loaded = false;
-	const unsigned rmask = 1u << p.cs[sc].r;
+	const unsigned rmask = 1u << p.probe_r;
 	const long long step = 2LL * gridDim.x * K2A_TS;
-	for (long long n0 = p.cs[sc].pos + 2LL * blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
+	for (long long n0 = p.scan_lo + 2LL * blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
 		const long long left = (avail_end - n0 + 1) / 2;
 		const int nt = (int)(left < K2A_TS ? left : K2A_TS);
 		const long long n1 = n0 + step;
@@ -674,16 +683,15 @@ void k2r_regions(K2Params p)
 	for (int i = tid; i < ncand; i += K2R_NT)	/* the index makes equal instants distinct keys (the sort ranks keys) */
 		key64[i] = ((unsigned long long)(unsigned)seeds[i] << 16) | (unsigned)i;
 	__syncthreads();
-	wg_sort_u64<K2R_NT>(key64, ws, ncand, 16, (unsigned)(p.ss[s].dec_fill + p.J));
+	wg_sort_u64<K2R_NT>(key64, ws, ncand, 16, (unsigned)(VDL2_CARRY_FRAMES + p.J));
 	for (int i = tid; i < ncand; i += K2R_NT)
 		key[i] = (int)(key64[i] >> 16);
 	__syncthreads();
 	{
 		/* every run of hits closer than VDL2_REG_GAP becomes a region (order is irrelevant) */
 		__shared__ int s_nreg;
-		const StreamState *ss = p.ss + s;
-		const int lo_lim = (int)(p.cs[sc].pos - ss->dec_base);
-		const int hi_lim = (int)(ss->dec_fill + p.J);
+		const int lo_lim = (int)(p.scan_lo - p.dec_base);
+		const int hi_lim = (int)(VDL2_CARRY_FRAMES + p.J);
 		int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
 		if (tid == 0)
 			s_nreg = 0;
@@ -736,9 +744,9 @@ void k2a_region(K2Params p)
 	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
 	if (blockIdx.x >= nreg)	/* nothing for this workgroup (64 channels x 128 workgroups, 40 regions each): not even the tables */
 		return;
-	const long long dec_base = p.ss[s].dec_base;
+	const long long dec_base = p.dec_base;
 	const int2 *regs = p.regs + (size_t)sc * VDL2_REG_CAP;
-	const int skip_r = p.cs[sc].r, skip_par = (int)(p.cs[sc].pos & 1);
+	const int skip_r = p.probe_r, skip_par = p.probe_par;
 	if (threadIdx.x < 16)
 		sh.prof[threadIdx.x] = 0;
 	k2a_tables(sh);
@@ -785,10 +793,9 @@ void k2a_verify(K2Params p)
 		return;
 	if (p.round > 0 && !p.redo[sc])
 		return;
-	const StreamState *ss = p.ss + s;
-	const long long dec_base = ss->dec_base;
+	const long long dec_base = p.dec_base;
 	const int r_lo = (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * K2A_VRUN * 2 * K2A_TS;
-	const int t_end = (int)(ss->dec_fill + p.J);
+	const int t_end = (int)(VDL2_CARRY_FRAMES + p.J);
 	if (r_lo >= t_end)
 		return;
 	const int r_hi = r_lo + K2A_VRUN * 2 * K2A_TS < t_end ? r_lo + K2A_VRUN * 2 * K2A_TS : t_end;

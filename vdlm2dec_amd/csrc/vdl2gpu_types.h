@@ -136,6 +136,10 @@ struct K2Params {
 	long long cap;
 	int nbch, nstreams;
 	long long J;
+	long long dec_base;	/* stream time of frame 0 of the planes (host arithmetic: outputs before this push - VDL2_CARRY_FRAMES) */
+	long long scan_lo;	/* first instant the scans look at: dec_base + VDL2_HIST (NOT the channel's position: the front stage of a
+				 * push runs before the previous push has committed where its channels stand) */
+	int probe_r, probe_par;	/* the class the probe scans everywhere (fixed), parity of its instants */
 	StreamState *ss;
 	ChanState *cs;
 	const ChanCfg *cfg;
