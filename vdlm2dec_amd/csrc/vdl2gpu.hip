@@ -194,6 +194,7 @@ struct vdl2gpu {
 	hipStream_t fstream = nullptr;
 	hipEvent_t f_done[2] = {nullptr, nullptr};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
 	hipEvent_t k1_ev = nullptr;	/* the latest channeliser (whichever stream it ran on) */
+	hipEvent_t f_tail = nullptr;	/* the end of the latest front stage on fstream (carry copy included) */
 	bool k1_ev_rec = false, last_two_streams = false;
 	int64_t last_J = 0;	/* outputs of the previous push: where its last 49152 frames lie */
 	/* stage sums of the pushes that carried stage events, unscaled, and how many those were */
@@ -530,6 +531,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 			(void)hipEventDestroy(h->f_done[r]);
 	if (h->k1_ev)
 		(void)hipEventDestroy(h->k1_ev);
+	if (h->f_tail)
+		(void)hipEventDestroy(h->f_tail);
 	if (h->pay_stream) {
 		(void)hipStreamSynchronize(h->pay_stream);
 		(void)hipStreamDestroy(h->pay_stream);
@@ -643,6 +646,7 @@ static int create_impl(vdl2gpu_t *h)
 	for (int r = 0; r < 2; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->f_done[r], hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k1_ev, hipEventDisableTiming));
+	HIPCHK(h, hipEventCreateWithFlags(&h->f_tail, hipEventDisableTiming));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->pay_stream, hipStreamNonBlocking));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2c_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->pay_done, hipEventDisableTiming));
@@ -857,7 +861,7 @@ static int harvest_timing(vdl2gpu_t *h)
 			if (i == 3)	/* the resolver alone (it may have run on its own stream, the next push's channeliser beside it) */
 				HIPCHK(h, hipEventElapsedTime(&d[i], pt.e[13], pt.e[14]));
 			else
-				HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : (i == 4 ? pt.e[12] : pt.e[i]), pt.e[i + 1]));
+				HIPCHK(h, hipEventElapsedTime(&d[i], i == 1 ? pt.e[10] : (i == 4 ? pt.e[12] : pt.e[i]), i == 1 ? pt.e[4] : pt.e[i + 1]));
 		}
 		if (pt.fast && pt.staged) {	/* kernel intervals only: first period | fast kernel | tail */
 			float a = 0, b = 0, c = 0;
@@ -1017,6 +1021,15 @@ static int enqueue_back(vdl2gpu_t *h)
 	hipStream_t rs = h->stream;
 	if (h->back.two_streams)
 		HIPCHK(h, hipStreamWaitEvent(rs, h->f_done[par], 0));
+	/* the cluster kernel needs nothing of the previous push's result either, but it is wide, and the stages are better
+	 * balanced with it here: FRONT = channeliser + scan, BACK = clusters + resolver + verify */
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[2], rs));
+	if (!serial)
+		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
+	HIPCHK(h, hipGetLastError());
+	if (staged)
+		HIPCHK(h, hipEventRecord(pt.e[3], rs));
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[13], rs));
 	hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, rs, k2);
@@ -1036,10 +1049,8 @@ static int enqueue_back(vdl2gpu_t *h)
 		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->pay_stream, k2);
 		HIPCHK(h, hipEventRecord(h->pay_done, h->pay_stream));
 	}
-	if (staged) {
-		HIPCHK(h, hipEventRecord(pt.e[4], h->stream));
+	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[12], h->stream));
-	}
 	if (!serial)
 		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 	HIPCHK(h, hipGetLastError());
@@ -1238,6 +1249,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	 * order it follows that push's cluster kernel and runs beside its resolver.  The plane set it writes was released by
 	 * the push before last, earlier on the same stream. */
 	hipStream_t ks = fs;
+	if (!two_streams && h->last_two_streams)	/* the previous push's channeliser state and carry were written on the front stream */
+		HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
 	if (two_streams) {
 		/* the plane set and the table set of this parity were last used by the push before last */
 		if (h->k2_rec[par])
@@ -1247,19 +1260,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	}
 	if (staged_in)
 		HIPCHK(h, hipStreamWaitEvent(ks, h->raw_copied[stg], 0));
-	if (h->pushes > 0) {
-		/* the carry: the last 49152 frames of the previous push's planes (its own carry included if it was shorter) go in
-		 * front of this push's output -- a fixed amount, so that it does not wait for the previous push's resolver to say
-		 * how much is still unconsumed (3 MB per stream) */
-		K3Params k3{};
-		k3.src = h->d_dec[par ^ 1];
-		k3.dst = h->d_dec[par];
-		k3.cap = h->cap;
-		k3.nbch = h->C;
-		k3.J = h->last_J;
-		hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, fs, k3);
-		HIPCHK(h, hipGetLastError());
-	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
@@ -1524,15 +1524,31 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (!serial)
 			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs, k2);
 		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[2], fs));
-		if (!serial)
-			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs, k2);
+		HIPCHK(h, hipEventRecord(pt.e[4], fs));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
 		HIPCHK(h, hipGetLastError());
-		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[3], fs));
 		/* ---- end of the FRONT stage */
 		if (two_streams)
 			HIPCHK(h, hipEventRecord(h->f_done[par], fs));
+		{
+			/* the carry for the NEXT push: the last 49152 frames of this push's planes (its own carry included if it is
+			 * shorter) go in front of where the next push's output will start, in the other plane set -- a fixed amount,
+			 * so that it does not wait for the resolver to say how much is still unconsumed (3 MB per stream).  Behind
+			 * this push's scan rather than in front of the next push's channeliser: there the copy sat for 100 us
+			 * behind the cluster kernel, which has the higher priority.  The other plane set was last read by the
+			 * previous push's back stage. */
+			if (two_streams && h->k2_rec[par ^ 1])
+				HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par ^ 1], 0));
+			K3Params k3{};
+			k3.src = h->d_dec[par];
+			k3.dst = h->d_dec[par ^ 1];
+			k3.cap = h->cap;
+			k3.nbch = h->C;
+			k3.J = J;
+			hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, fs, k3);
+			HIPCHK(h, hipGetLastError());
+			if (two_streams)	/* a following push that keeps to the main stream must see the carry */
+				HIPCHK(h, hipEventRecord(h->f_tail, fs));
+		}
 		h->back.valid = true;
 		h->back.k2 = k2;
 		h->back.J = J;
