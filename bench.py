@@ -310,7 +310,8 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
         t0 = time.perf_counter()
         for _ in range(steps):
             push()
-            drain(True)
+            if not os.environ.get("BENCH_LEG_NO_DRAIN"):      # development: how fast without the record read-back in the loop
+                drain(True)
         drain(False)
         rx.sync()
         torch.cuda.synchronize(dev)
@@ -405,9 +406,9 @@ def extra_legs(local):
     legs = {}
     plan = [
         ("config3_8ch_10MSps", dict(workload=CONFIGS[3]["workload"], rate=10_000_000, fos=FO8_10MS, fmt="cs16", nstr=1, ntiles=64,
-                                    bursts_per_s=4.0, steps=4, warmup=2, seed0=1234)),
+                                    bursts_per_s=4.0, steps=8, warmup=3, seed0=1234)),
         ("config4_share_8x8ch", dict(workload=CONFIGS[4]["workload"] + " -- one GPU's share", rate=2_000_000, fos=fo2, fmt="cs16", nstr=8,
-                                     ntiles=16, bursts_per_s=4.0, steps=4, warmup=2, seed0=1234)),
+                                     ntiles=16, bursts_per_s=4.0, steps=6, warmup=3, seed0=1234)),
         ("config2_busy_15", dict(workload=CONFIGS[2]["workload"] + " -- 15 bursts/s/channel offered", rate=2_000_000, fos=fo2, fmt="cs16",
                                  nstr=1, ntiles=16, bursts_per_s=15.0, steps=8, warmup=3, seed0=77)),
         ("config2_busy_30", dict(workload=CONFIGS[2]["workload"] + " -- 30 bursts/s/channel offered (channels saturated)", rate=2_000_000,

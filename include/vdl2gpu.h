@@ -86,7 +86,7 @@ typedef struct {
 				 * slower; stats.serial_samples shows it).  Long pushes are therefore cut into equal parts inside the
 				 * library -- the bursts are the same for any cut --: 8.4 s of air time until the first pushes have
 				 * been collected, then as long as fills 90 % of the tables at the candidate density of the busiest
-				 * channel over the last eight pushes, at most 36 s (72 MS at 2 MS/s). */
+				 * channel over the last four parts, at most 36 s (72 MS at 2 MS/s). */
 	int32_t device;		/* HIP device ordinal */
 	uint32_t max_bursts;	/* burst-record ring capacity (0 = default 65536) */
 	uint32_t flags;		/* VDL2GPU_F_* */

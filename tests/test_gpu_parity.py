@@ -458,7 +458,7 @@ def test_a_sudden_load_overflows_once_and_the_parts_adapt(built, oracle):
     dense = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=110.0, info_max=4)
     quiet = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=8, bursts_per_s=1.0, info_max=40)
     rd, rq = synth.synth_stream(dense, "cs16"), synth.synth_stream(quiet, "cs16")
-    seq = [rq] * 10 + [rd] * 4          # ten quiet pushes: the density window (eight pushes) has forgotten the start-up parts
+    seq = [rq] * 10 + [rd] * 4          # ten quiet pushes: the density window (four parts) has forgotten the start-up parts
     want = sorted(b.key() for b in oracle.run_oracle(np.concatenate(seq), "cs16", 2_000_000, dense.fo, S.FC))
     with Receiver(2_000_000, plan_channels(S.FC, dense.fo), fmt="cs16", max_push=n) as rx:
         got, serial = [], []

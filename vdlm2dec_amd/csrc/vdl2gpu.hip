@@ -124,7 +124,7 @@ struct vdl2gpu {
 	size_t split_default = 0;
 	unsigned long long last_ovf_push = 0;
 	size_t ring_samples[2] = {0, 0};	/* samples (per stream) of the push that filled each output ring */
-	double cand_dens[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* candidates per input sample of the busiest channel, last eight pushes collected */
+	double cand_dens[4] = {0, 0, 0, 0};	/* candidates per input sample of the busiest channel, last four parts collected */
 	unsigned cand_dens_n = 0;
 	size_t split_unit = 32768;	/* parts are multiples of this (k1_fast takes whole superperiods; the RTL quirk needs whole blocks) */
 	unsigned redos_seen = 0, repairs_seen = 0;
@@ -140,7 +140,12 @@ struct vdl2gpu {
 	std::vector<PushTiming> free_ev;
 	vdl2gpu_timing_t tm{};
 	std::vector<vdl2gpu_burst_t> ready;	/* fetched, not yet handed out (storage order) */
-	std::vector<uint32_t> ready_idx;	/* hand-out order: indices into `ready`, consumed from ready_pos */
+	/* hand-out order, consumed from ready_pos: bits 32-33 = where the record lies (0: `ready`, 1 + ring: that ring's slab of
+	 * page-locked host memory, which the GPU itself fills at the end of the push -- k_export_records -- so that collecting a
+	 * push's bursts is an index sort and ONE copy per record, into the caller's buffer), bits 0-31 = index there */
+	std::vector<uint64_t> ready_idx;
+	vdl2gpu_burst_t *h_slab[2] = {nullptr, nullptr}, *d_slab[2] = {nullptr, nullptr};	/* the slabs and their device addresses */
+	unsigned slab_cap = 0;
 	size_t ready_pos = 0;
 	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
 	bool frames_on = false;
@@ -580,6 +585,9 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_headtap_n);
 	if (h->h_pin)
 		(void)hipHostFree(h->h_pin);
+	for (int r = 0; r < 2; ++r)
+		if (h->h_slab[r])
+			(void)hipHostFree(h->h_slab[r]);
 	if (h->h_pin_cnt)
 		(void)hipHostFree(h->h_pin_cnt);
 	if (h->stream)
@@ -723,6 +731,11 @@ static int create_impl(vdl2gpu_t *h)
 	h->quirk = (cfg.flags & VDL2GPU_F_RTL_QUIRK) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
+	h->slab_cap = std::min<unsigned>(h->rec_cap, 65536u);	/* 138 MB of page-locked memory per ring at most; a push with more bursts takes the bounce buffer for the rest */
+	for (int r = 0; r < 2; ++r) {
+		HIPCHK(h, hipHostMalloc(&h->h_slab[r], (size_t)h->slab_cap * sizeof(vdl2gpu_burst_t), hipHostMallocMapped));
+		HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_slab[r], h->h_slab[r], 0));
+	}
 	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 64 * sizeof(unsigned), hipHostMallocMapped));
 	memset(h->h_pin_cnt, 0, 64 * sizeof(unsigned));
 	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
@@ -896,6 +909,7 @@ static int harvest_timing(vdl2gpu_t *h)
 
 static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking);
 static int enqueue_back(vdl2gpu_t *h);
+static void spill_slab(vdl2gpu_t *h, int ring);
 
 template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
 {
@@ -1133,6 +1147,16 @@ static int enqueue_back(vdl2gpu_t *h)
 		k3.ring = ring;
 		k3.ctl = h->d_ctl[par];
 		k3.nstreams = h->S;
+		{
+			/* the push's records go to the host by the GPU's own hand: page-locked memory, coalesced 8-byte stores */
+			KExportParams ke{};
+			ke.recs = h->d_recs[ring];
+			ke.count = h->d_outc + 2 * ring;
+			ke.dst = h->d_slab[ring];
+			ke.cap = std::min(h->slab_cap, h->rec_cap);
+			hipLaunchKernelGGL(k_export_records, dim3((unsigned)h->n_cu), dim3(256), 0, h->stream, ke);
+			HIPCHK(h, hipGetLastError());
+		}
 		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
 		HIPCHK(h, hipGetLastError());
 	}
@@ -1561,6 +1585,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		h->back.pt_index = h->pending.size();
 	}
 	h->pending.push_back(pt);
+	spill_slab(h, ring);	/* (the ring was collected above: whatever of it the caller has not taken yet) */
 	{
 		const int rcb = enqueue_back(h);
 		if (rcb)
@@ -1586,6 +1611,23 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 	return harvest_timing(h);
 }
 
+static inline vdl2gpu_burst_t *rec_of(vdl2gpu_t *h, uint64_t hd)
+{
+	const unsigned src = (unsigned)(hd >> 32) & 3u;
+	return (src ? h->h_slab[src - 1] : h->ready.data()) + (uint32_t)hd;
+}
+
+/* A ring's slab is about to be written again (its push's back stage is being enqueued): whatever of it has not been
+ * handed out yet moves to the pageable queue.  A consumer that polls after every push never gets here with anything. */
+static void spill_slab(vdl2gpu_t *h, int ring)
+{
+	for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
+		if (((h->ready_idx[i] >> 32) & 3u) == (unsigned)(1 + ring)) {
+			h->ready.push_back(h->h_slab[ring][(uint32_t)h->ready_idx[i]]);
+			h->ready_idx[i] = (uint64_t)(h->ready.size() - 1);
+		}
+}
+
 /* Move the records of the push that filled `ring` to the host queue.  blocking = false: only if
  * that push has finished (returns 1 if it has not).  The copy runs on its own stream, so a later
  * push keeps the GPU busy meanwhile. */
@@ -1608,23 +1650,25 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	h->overflowed += c1;
 	if (!h->knob.split_fixed && h->ring_samples[ring]) {
 		/* How long a part may be follows from how many trigger candidates the busiest channel produced per input sample
-		 * in the pushes collected lately (the highest of the last eight): parts are sized to fill 90 % of the tables, so
+		 * in the parts collected lately (the highest of the last four): parts are sized to fill 90 % of the tables, so
 		 * that traffic may grow by a tenth from one push to the next before a channel overflows them.  A channel that does
 		 * overflow is handled by the serial machine for that part (exact, milliseconds); its density then counts as
 		 * twice what the tables hold.  Round 2 halved the parts on an overflow and doubled them again after 1024 quiet
 		 * pushes: busy channels ended up in parts a quarter full. */
 		const unsigned novf = h->h_pin_cnt[32 * ring + 7];
 		const unsigned maxc = h->h_pin_cnt[32 * ring + 24];
-		double d = (double)std::min<unsigned>(maxc, VDL2_CAND_CAP) / (double)h->ring_samples[ring];
+		/* (a part's scan starts at the first carried frame: its count covers the part plus 49152 frames of the one before) */
+		const double span = (double)h->ring_samples[ring] + (double)VDL2_CARRY_FRAMES * (double)h->sdrclk / 21.0;
+		double d = (double)std::min<unsigned>(maxc, VDL2_CAND_CAP) / span;
 		if (novf)
-			d = 2.0 * (double)VDL2_CAND_CAP / (double)h->ring_samples[ring];
-		h->cand_dens[h->cand_dens_n++ & 7u] = d;
+			d = 2.0 * (double)VDL2_CAND_CAP / span;
+		h->cand_dens[h->cand_dens_n++ & 3u] = d;
 		double dmax = 0.0;
 		for (double x : h->cand_dens)
 			dmax = std::max(dmax, x);
 		size_t lim = h->split_default;
 		if (dmax > 0.0)
-			lim = (size_t)std::min((double)h->split_default, 0.90 * (double)VDL2_CAND_CAP / dmax);
+			lim = (size_t)std::min((double)h->split_default, std::max(0.0, 0.90 * (double)VDL2_CAND_CAP / dmax - (double)VDL2_CARRY_FRAMES * (double)h->sdrclk / 21.0));
 		h->split_samples = std::max(h->split_unit, lim / h->split_unit * h->split_unit);
 		if (novf)
 			h->last_ovf_push = h->ring_push[ring];
@@ -1663,57 +1707,49 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			std::vector<vdl2gpu_burst_t> keep;
 			keep.reserve(h->ready_idx.size() - h->ready_pos);
 			for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
-				keep.push_back(h->ready[h->ready_idx[i]]);
+				keep.push_back(*rec_of(h, h->ready_idx[i]));
 			h->ready.swap(keep);
 			h->ready_idx.resize(h->ready.size());
 			for (size_t i = 0; i < h->ready_idx.size(); ++i)
-				h->ready_idx[i] = (uint32_t)i;
+				h->ready_idx[i] = (uint64_t)i;
 			h->ready_pos = 0;
 		}
+		/* the first slab_cap records are already in this ring's slab (k_export_records ran before the event this call
+		 * waited for); a push with more than that brings the rest through the bounce buffer */
+		const unsigned ns = std::min(n, h->slab_cap);
 		const size_t old = h->ready.size();
-		for (unsigned done = 0; done < n; done += h->pin_recs) {
+		for (unsigned done = ns; done < n; done += h->pin_recs) {
 			const unsigned m = std::min(h->pin_recs, n - done);
 			HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_recs[ring] + done, (size_t)m * sizeof(vdl2gpu_burst_t),
 						 hipMemcpyDeviceToHost, h->copy_stream));
 			HIPCHK(h, hipStreamSynchronize(h->copy_stream));
-			/* appended, not resized-then-overwritten: a resize would zero 2 KB per record first, and this
-			 * thread's time per push is not much shorter than the GPU's */
 			const vdl2gpu_burst_t *pin = reinterpret_cast<const vdl2gpu_burst_t *>(h->h_pin);
 			h->ready.insert(h->ready.end(), pin, pin + m);
 		}
-		if (h->ring_spec[ring]) {
-			/* K2d ran ahead of the verify pass: for a channel that K2f then redid serially, its records
-			 * (trig_sample == 0 on the device) are void; K2f's own (== 1) are the channel's bursts */
-			const unsigned *mask = h->h_pin_cnt + 32 * ring + 8;
-			bool any = false;
+		/* K2d ran ahead of the verify pass: for a channel that K2f then redid serially, its records
+		 * (trig_sample == 0 on the device) are void; K2f's own (== 1) are the channel's bursts */
+		const unsigned *mask = h->h_pin_cnt + 32 * ring + 8;
+		bool any = false;
+		if (h->ring_spec[ring])
 			for (int i = 0; i < 16; ++i)
 				any = any || mask[i] != 0;
-			if (any) {
-				size_t w = old;
-				for (size_t i = old; i < h->ready.size(); ++i) {
-					const vdl2gpu_burst_t &b = h->ready[i];
-					const unsigned sc = (unsigned)b.end_sample;
-					if (b.trig_sample == 0 && sc < 512 && (mask[sc >> 5] >> (sc & 31) & 1u))
-						continue;
-					if (w != i)
-						h->ready[w] = b;
-					++w;
-				}
-				h->ready.resize(w);
-			}
-		}
 		const size_t iold = h->ready_idx.size();
-		for (size_t i = old; i < h->ready.size(); ++i) {
-			vdl2gpu_burst_t &b = h->ready[i];
+		auto take = [&](vdl2gpu_burst_t &b, uint64_t handle) {
+			const unsigned sc = (unsigned)b.end_sample;
+			if (any && b.trig_sample == 0 && sc < 512 && (mask[sc >> 5] >> (sc & 31) & 1u))
+				return;
 			b.trig_sample = dec_to_sample(b.trig_dec, (unsigned)h->sdrclk);
 			b.end_sample = dec_to_sample(b.end_dec, (unsigned)h->sdrclk);
 			/* d8psk.c:302, same mixed float/double expression */
 			b.ppm = (float)((double)(10500.0f * b.df) / (2.0 * M_PI * (double)b.Fr) * 1e6);
-			h->ready_idx.push_back((uint32_t)i);
-		}
-		const vdl2gpu_burst_t *rd = h->ready.data();
-		std::sort(h->ready_idx.begin() + iold, h->ready_idx.end(), [rd](uint32_t x, uint32_t y) {
-			const vdl2gpu_burst_t &a = rd[x], &b = rd[y];
+			h->ready_idx.push_back(handle);
+		};
+		for (unsigned i = 0; i < ns; ++i)
+			take(h->h_slab[ring][i], ((uint64_t)(1 + ring) << 32) | i);
+		for (size_t i = old; i < h->ready.size(); ++i)
+			take(h->ready[i], (uint64_t)i);
+		std::sort(h->ready_idx.begin() + iold, h->ready_idx.end(), [h](uint64_t x, uint64_t y) {
+			const vdl2gpu_burst_t &a = *rec_of(h, x), &b = *rec_of(h, y);
 			if (a.end_dec != b.end_dec)
 				return a.end_dec < b.end_dec;
 			if (a.stream != b.stream)
@@ -1829,7 +1865,7 @@ static int hand_out(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	const int n = std::min<int>(max, (int)(h->ready_idx.size() - h->ready_pos));
 	for (int i = 0; i < n; ++i)
-		out[i] = h->ready[h->ready_idx[h->ready_pos + i]];
+		out[i] = *rec_of(h, h->ready_idx[h->ready_pos + i]);
 	h->ready_pos += (size_t)n;
 	return n;
 }

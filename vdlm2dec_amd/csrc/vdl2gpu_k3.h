@@ -85,6 +85,29 @@ __global__ void k3_rebase(K3Params p)
 	ss->dec_fill = VDL2_CARRY_FRAMES;
 }
 
+/* The push's burst records, device ring -> page-locked host memory, by the GPU itself at the end of the back stage: when
+ * the host sees the push's completion event the records are already where vdl2gpu_poll*() hands them out from (round 2:
+ * hipMemcpyAsync into a bounce buffer, a stream synchronise and two memcpy per record on the collecting thread -- 1.5 ms per
+ * push with 3500 bursts, more than the GPU needed for the push). */
+struct KExportParams {
+	const vdl2gpu_burst_t *recs;
+	const unsigned *count;	/* records written (device counter of this push's ring) */
+	vdl2gpu_burst_t *dst;	/* device address of the ring's slab */
+	unsigned cap;		/* records the slab holds */
+};
+__global__ __launch_bounds__(256)
+void k_export_records(KExportParams p)
+{
+	static_assert(sizeof(vdl2gpu_burst_t) % 8 == 0, "records are copied as 8-byte words");
+	unsigned n = *p.count;
+	n = n < p.cap ? n : p.cap;
+	const size_t words = (size_t)n * (sizeof(vdl2gpu_burst_t) / 8);
+	const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recs);
+	unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.dst);
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
+		dst[i] = src[i];
+}
+
 /* test hook: both device forms of atan2f; a disagreement between them comes back as NaN */
 __global__ void k_atan2f(const float *y, const float *x, float *out, size_t n)
 {
