@@ -694,7 +694,8 @@ def main():
         ms_step = dt / args.steps * 1e3
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_pmc_hbm.json")))
+            pmf = [f for f in ("r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
             if args.config == 2 and not args.tiles and args.fmt == "cs16" and not args.rate and not args.streams:
                 fk = [k for k in pm["FETCH_SIZE_KB_per_launch"] if kname in k][0]
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"][fk] + pm["WRITE_SIZE_KB_per_launch"][fk]) * 1024.0
@@ -726,7 +727,7 @@ def main():
                                  "bytes x samples, read once for all 8 channels; the kernel also writes the 84 kS/s planes (2.7 B per "
                                  "input sample at 2 MS/s), which is intermediate traffic, not algorithmic (SURVEY.md 8d); `traffic` is "
                                  "not measured by this run (PMC counters need rocprofv3): traffic_from_profiles is the committed "
-                                 "measurement of this command (profiles/r02_bench_pmc_hbm.json: 2 x FETCH_SIZE + WRITE_SIZE)"},
+                                 "measurement of this command (profiles/r03_bench_pmc_hbm.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"},
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
                            "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms, "demod_chain": k2_ms},
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
