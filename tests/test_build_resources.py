@@ -32,7 +32,7 @@ def resources():
 def test_every_kernel_is_listed(resources):
     names = " ".join(resources)
     for k in ("k1_fast", "k1_pp", "k1_channelise", "k2a_probe", "k2a_region", "k2a_verify", "k2s_sort", "k2b_clusters",
-              "k2c_resolve", "k2f_commit", "k2d_payload", "k3_compact", "k4_frames"):
+              "k2c_resolve", "k2f_commit", "k2d_payload", "k3_carry", "k3_rebase", "k_export_records", "k4_frames"):
         assert k in names, k
 
 
@@ -48,3 +48,11 @@ def test_no_channeliser_kernel_uses_scratch(resources):
     for k, r in resources.items():
         if "k1_" in k:
             assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, k
+
+
+def test_the_critical_kernels_touch_no_scratch(resources):
+    """the cluster kernel spilled 12 registers (72 bytes of scratch per lane), the resolver passed the serial
+    machine's context through 264 bytes of scratch; build() refuses either now, and this is what it reads."""
+    for k, r in resources.items():
+        if any(n in k for n in ("k2b_clusters", "k2c_resolve", "k2f_commit")):
+            assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
