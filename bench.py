@@ -722,14 +722,19 @@ def main():
                          "alone": {"avg_launch_ms": iso_ms, "achieved": alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0,
                                    "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else 0.0,
                                    "how": "4 pushes after the timed region, each synchronised before the next: no other kernel on the GPU"},
-                         "note": "live: HIP events around the one full-rate launch of each push inside the timed region, where it runs "
-                                 "beside the previous push's demodulator kernels on a second stream; algorithmic bytes = sample "
+                         "note": "live: HIP events around the one full-rate launch of each push inside the timed region (every fourth push "
+                                 "carries them), where it runs beside the PREVIOUS push's back stage -- its cluster kernel or verify pass, "
+                                 "both of which fill the GPU by themselves: two pushes are in flight (DESIGN.md 4, Host side), so the "
+                                 "kernel takes longer here than alone (`alone`) while the step as a whole got shorter; algorithmic bytes = sample "
                                  "bytes x samples, read once for all 8 channels; the kernel also writes the 84 kS/s planes (2.7 B per "
                                  "input sample at 2 MS/s), which is intermediate traffic, not algorithmic (SURVEY.md 8d); `traffic` is "
                                  "not measured by this run (PMC counters need rocprofv3): traffic_from_profiles is the committed "
                                  "measurement of this command (profiles/r03_bench_pmc_hbm.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"},
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
-                           "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms, "demod_chain": k2_ms},
+                           "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms, "demod_chain": k2_ms,
+                           "note": "kernel intervals from HIP events; the front stage of one push (channeliser, scan) runs beside the back "
+                                   "stage of the one before (clusters, resolver, verify): the intervals overlap and are longer than the "
+                                   "kernels alone -- their sum (demod_chain + k1) exceeds ms_per_step, it is not a critical path"},
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
                                            "candidates", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,

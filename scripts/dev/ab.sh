@@ -6,6 +6,6 @@ for t in .ab_r02 .; do
   ( cd $t && python bench.py "$@" --no-cpu 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$t', round(d['value']), round(d['ms_per_step'],4), {k:round(v,3) for k,v in d['kernels_ms'].items()}, d['roofline']['avg_launch_ms'])
+print('$t', round(d['value']), round(d['ms_per_step'],4), {k:round(v,3) for k,v in d['kernels_ms'].items() if k!='note'}, d['roofline']['avg_launch_ms'])
 " )
 done; done

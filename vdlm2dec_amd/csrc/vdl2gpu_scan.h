@@ -126,7 +126,7 @@ __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long de
 		 * tables hold twice the bursts.  Should a chain ever stand between two steps of a run, the verify pass finds the
 		 * unlisted hit (it tests every instant of the stretch the chain idled through) and the repair rounds, which list
 		 * everything, put it in. */
-		if (p.round == 0 && p2err < 4.0f && perr > p2err)
+		if (p.round == 0 && !p.full_scan && p2err < 4.0f && perr > p2err)	/* (VDL2GPU_F_FULLSCAN has no verify pass behind it: it lists everything) */
 			return;
 	} else {
 		if (n < chk_lo || n >= chk_hi)
