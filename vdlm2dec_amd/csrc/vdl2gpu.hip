@@ -1,10 +1,11 @@
 /*
  * vdl2gpu.hip -- host side of libvdl2gpu.so: the C ABI of include/vdl2gpu.h.
  *
- * One handle = one HIP stream on one MI355X.  vdl2gpu_push() enqueues
- *   [H2D copy] -> K1 channelise -> K2 demod -> K3 compact
- * and returns; vdl2gpu_poll() synchronises and hands burst records back in
- * stream-time order.  There is no CPU fallback: without a HIP device
+ * One handle = one MI355X, two pushes in flight.  vdl2gpu_push() enqueues
+ *   front stage (fstream):  [H2D copy] -> K1 channelise -> K2a probe / regions -> K2s sort -> carry for the next push
+ *   back stage  (stream):   K2b clusters -> K2c resolve -> K2a verify (K2d payload beside it) -> commit -> export -> counters
+ * and returns; the front stage of one push runs beside the back stage of the one before (see vdl2gpu::Back).
+ * vdl2gpu_poll() synchronises and hands burst records back in stream-time order.  There is no CPU fallback: without a HIP device
  * vdl2gpu_create() fails with VDL2GPU_ENODEV.
  *
  * Build (see __graft_entry__.build()):
@@ -114,9 +115,6 @@ struct vdl2gpu {
 	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
 	unsigned *d_fmask[2] = {nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
 	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
-	hipEvent_t k2_mid_a = nullptr;	/* ... before the candidate sort */
-	hipEvent_t k2_mid = nullptr;	/* recorded in the demodulator chain where its low-occupancy steps begin */
-	bool k2_mid_rec = false;
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
 	int rounds_floor = 0;		/* many channels: one (complete) round is always scheduled, see create */
 	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked; halved
@@ -525,8 +523,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		if (h->k2_done[r])
 			(void)hipEventDestroy(h->k2_done[r]);
 	}
-	if (h->k2_mid)
-		(void)hipEventDestroy(h->k2_mid);
 	if (h->fstream) {
 		(void)hipStreamSynchronize(h->fstream);
 		(void)hipStreamDestroy(h->fstream);
@@ -548,8 +544,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipEventDestroy(h->pay_done);
 	(void)hipFree(h->d_fmask[0]);
 	(void)hipFree(h->d_fmask[1]);
-	if (h->k2_mid_a)
-		(void)hipEventDestroy(h->k2_mid_a);
 	(void)hipFree(h->d_ctl[0]);
 	(void)hipFree(h->d_ctl[1]);
 	(void)hipFree(h->d_cands[0]);
@@ -645,7 +639,6 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipEventCreateWithFlags(&h->k1_done[r], hipEventDisableTiming));
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
 	}
-	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid, hipEventDisableTiming));
 	{
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -662,7 +655,6 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_fmask[r], 16 * sizeof(unsigned)));
 	for (int r = 0; r < 2; ++r)
 		HIPCHK(h, hipMemsetAsync(h->d_fmask[r], 0, 16 * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipEventCreateWithFlags(&h->k2_mid_a, hipEventDisableTiming));
 	h->ctl_words = CTL_CAND0 + 8 * (size_t)S * VDL2_CS;
 	for (int r = 0; r < 2; ++r)
 		HIPCHK(h, hipMalloc(&h->d_ctl[r], h->ctl_words * sizeof(unsigned)));

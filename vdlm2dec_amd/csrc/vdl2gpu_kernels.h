@@ -19,20 +19,25 @@
  *            under all 8 timing hypotheses (K2a) + what happens after each (K2b).
  *   bursts   staging pool (K2b) and output ring (K2c/K2d) of vdl2gpu_burst_t.
  *
- * Pipeline of one push (two more streams beside the main one: K1 of the NEXT push, and the block kernel)
+ * Pipeline of one push.  Two stages on two streams, the tables below exist twice: the FRONT stage of push N+1 runs beside
+ * the BACK stage of push N (host side: vdl2gpu.hip, struct Back).
+ *  front
  *   K1   channelise       time-parallel over the whole GPU, the only full-rate kernel (vdl2gpu_k1.h)
- *   K2a  sync scan        probe (one detector class over the whole push), regions (all classes around
- *                         what it found), verify (the classes the resolved chain relied on).  Screens that
- *                         prove where the detector cannot fire; exact FIR / atan2f / fit only for what
- *                         survives them (vdl2gpu_scan.h)
+ *   K2a  sync scan        probe (ONE fixed detector class over the whole push, carry included), regions (all classes
+ *                         around what it found).  Screens that prove where the detector cannot fire; exact FIR /
+ *                         atan2f / fit only for what survives them; only the first firing of a run is listed (vdl2gpu_scan.h)
  *   K2s  sort             candidates by time, primaries marked (vdl2gpu_resolve.h)
+ *   K3   carry            the last 49152 frames of every plane to the other plane set (a fixed amount: depends on nothing
+ *                         the resolver decides)
+ *  back
  *   K2b  burst clusters   one wavefront per primary candidate: exact state machine (vdl2gpu_machine.h)
  *                         from the trigger until the detector is history-free again
  *   K2c  resolve          one workgroup per VDL channel: walks the real chain of bursts through the tables
+ *   K2a  verify           every stretch the chain idled through, in the class it idled in, unless the probe covered it
+ *   K2d  payload          symbols, slicer, descrambler, de-interleaver of the bursts on the chain (beside the verify pass)
  *   K2f  commit           (or serial redo of a channel whose verify pass failed)
- *   K2d  payload          symbols, slicer, descrambler, de-interleaver of the bursts on the chain
- *   K3   compact          carry to the other plane set, counters to the host
  *   K4   block path       optional: RS / HDLC / FCS per burst (vdl2gpu_blocks.h)
+ *   K3   export, rebase   records into page-locked host memory by the GPU's own hand; counters to the host
  *
  * Why the tables are exact: between bursts the reference detector evaluates
  * every 2nd 84 kS/s sample with a sticky FIR sub-phase r = clk%4 and sample
