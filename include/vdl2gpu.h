@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VDL2GPU_ABI_VERSION 2
+#define VDL2GPU_ABI_VERSION 3	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_* */
 #define VDL2GPU_MAXCH 8		/* MAXNBCHANNELS vdlm2.h:26 */
 #define VDL2GPU_MAXROWS 8	/* bursts with more rows are rejected, d8psk.c:103 */
 #define VDL2GPU_ROWLEN 255
