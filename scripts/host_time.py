@@ -7,12 +7,14 @@ import torch
 import bench as B
 from vdlm2dec_amd import lib as _lib
 from vdlm2dec_amd.demod import Receiver, plan_channels
-spec, tile = B.make_tile(0, "cs16")
+from vdlm2dec_amd import synth
+RATE = 2_000_000
+spec, tile = B.make_tile(0, "cs16", RATE, synth.DEFAULT_FO_8CH)
 fos = list(spec.fo)
 batch = 16 * len(tile) // 2
 dev = torch.device("cuda:0")
 dbatch = torch.from_numpy(np.tile(tile, 16)).to(dev)
-rx = Receiver(B.RATE, [plan_channels(B.FC, fos)], fmt="cs16", max_push=batch, max_bursts=1 << 18)
+rx = Receiver(RATE, [plan_channels(B.FC, fos)], fmt="cs16", max_push=batch, max_bursts=1 << 18)
 buf = (_lib.BurstT * 16384)()
 for _ in range(4):
     rx.push_device(dbatch.data_ptr(), batch, 0); rx.poll_raw(buf, 16384)

@@ -42,7 +42,18 @@ while time.time() < t_end:
         from vdlm2dec_amd import lib as _lib
         flags = _lib.F_TEST_NOREGION
     with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=max(block, 1 << 16), frames=frames_too, flags=flags, testhooks=True) as rx:
-        got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in rx.run(raw, block=block))
+        if seed & 2:
+            # two pushes in flight: hand-offs back to back, what has finished is taken in between (vdl2gpu_poll_ready),
+            # everything else at the end -- the front stage of one push runs beside the back stage of the one before
+            per = O.PER_SAMPLE[fmt]
+            bl, nsm = [], raw.size // per
+            for s0 in range(0, nsm, block):
+                rx.push(raw[s0 * per:min(nsm, s0 + block) * per])
+                bl += rx.poll_ready()
+            bl += rx.poll()
+            got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in bl)
+        else:
+            got = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in rx.run(raw, block=block))
         gotf = sorted(rx.poll_frames()) if frames_too else []
         st = rx.stats()
     ok = got == want
@@ -50,7 +61,7 @@ while time.time() < t_end:
         wantf = sorted((0, b.chn, f) for b in ob for f in O.frames_of_block(b.nbrow, b.nlbyte, b.data))
         ok = ok and gotf == wantf
     n_ok += ok; n_bad += (not ok)
-    print("seed %d rate %d ch %d %s ns %d dens %.0f block %d mode %d: %d bursts %s redos %d" % (seed, rate, nch, fmt, ns, dens, block, mode, len(want), "OK" if ok else "MISMATCH", st["serial_redos"]), flush=True)
+    print("seed %d rate %d ch %d %s ns %d dens %.0f block %d mode %d%s: %d bursts %s redos %d" % (seed, rate, nch, fmt, ns, dens, block, mode, " pipelined" if seed & 2 else "", len(want), "OK" if ok else "MISMATCH", st["serial_redos"]), flush=True)
     seed += 1
 print("soak: %d ok, %d bad" % (n_ok, n_bad))
 sys.exit(1 if n_bad else 0)
