@@ -1,5 +1,6 @@
 #!/bin/bash
-# dev aid: the same bench arguments on the round-2 tree (.ab_r02, a git worktree of 6c1981f) and on this tree, same box, alternating
+# dev aid: the same bench arguments on the round-2 tree and on this tree, same box, alternating.  Needs the round-2 tree beside
+# this one:  git worktree add -f .ab_r02 6c1981f && (cd .ab_r02 && python -c 'import __graft_entry__ as g; g.build()')   [git-ignored]
 cd "$(dirname "$0")/../.."
 for rep in 1 2; do
 for t in .ab_r02 .; do
