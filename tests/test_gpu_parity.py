@@ -590,3 +590,28 @@ def test_paced_live_ring_equals_the_oracle(built, oracle):
     assert lat["p50"] < 2.0 and lat["p99"] < 16.384 and r["blocks_started_late"] == 0, r
     r2 = bench.live_leg(0, nblocks=90, paced=False, seed=78)      # as fast as the producer can: the same bursts, no pacing to hide behind
     assert r2["parity"]["equal"]
+
+
+def test_records_beyond_the_slab_and_uncollected_records_survive(built, oracle, monkeypatch):
+    """Collecting: the GPU writes a push's records into a slab of page-locked host memory (k_export_records); what
+    exceeds the slab comes through the bounce buffer, and what the caller has not taken when the slab is due again (two
+    pushes later) moves to the pageable queue.  Slab pinned to 5 records (test build), several pushes without polling:
+    every burst once, in order, equal to the oracle's."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv("VDL2GPU_SLAB_CAP", "5")
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 4_000_000, seed=901, bursts_per_s=30.0, info_max=60)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    assert len(want) >= 60
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20, testhooks=True) as rx:
+        n = spec.nsamples
+        got = []
+        for i, s0 in enumerate(range(0, n, 500_000)):       # eight pushes (21 000 frames each: the parallel path), ~10 bursts a push
+            rx.push(raw[2 * s0:2 * min(n, s0 + 500_000)])
+            if i == 5:
+                got += rx.poll_ready()                       # once in the middle, never waiting
+        got += rx.poll()
+        assert rx.stats()["overflowed"] == 0
+    assert _gpu_keys(got) == want
+    ends = [(b.end_dec, b.stream, b.chn) for b in got]
+    assert ends == sorted(ends)                              # hand-out order: (end, stream, channel)

@@ -196,7 +196,7 @@ struct vdl2gpu {
 	} back;
 	hipStream_t fstream = nullptr;
 	hipEvent_t f_done[2] = {nullptr, nullptr};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
-	hipEvent_t k1_ev = nullptr;	/* the latest channeliser (whichever stream it ran on) */
+	hipEvent_t k1_ev = nullptr;	/* channeliser + carry copy of the latest push that kept to the main stream */
 	hipEvent_t f_tail = nullptr;	/* the end of the latest front stage on fstream (carry copy included) */
 	bool k1_ev_rec = false, last_two_streams = false;
 	int64_t last_J = 0;	/* outputs of the previous push: where its last 49152 frames lie */
@@ -724,6 +724,9 @@ static int create_impl(vdl2gpu_t *h)
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
 	h->slab_cap = std::min<unsigned>(h->rec_cap, 65536u);	/* 138 MB of page-locked memory per ring at most; a push with more bursts takes the bounce buffer for the rest */
+#ifdef VDL2GPU_TESTHOOKS
+	h->slab_cap = std::max(1u, std::min<unsigned>(h->slab_cap, (unsigned)env_int("VDL2GPU_SLAB_CAP", (int)h->slab_cap)));	/* (tests: force the bounce path) */
+#endif
 	for (int r = 0; r < 2; ++r) {
 		HIPCHK(h, hipHostMalloc(&h->h_slab[r], (size_t)h->slab_cap * sizeof(vdl2gpu_burst_t), hipHostMallocMapped));
 		HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_slab[r], h->h_slab[r], 0));
@@ -1450,10 +1453,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
 		h->k1_rec[par] = true;
 	}
-	if (!two_streams) {	/* a later push's front stage must see this channeliser's planes and carry state */
-		HIPCHK(h, hipEventRecord(h->k1_ev, ks));
-		h->k1_ev_rec = true;
-	}
 	/* The output ring of this push: if the push that last used it (the one before last) has not been collected yet,
 	 * collect it now -- the GPU has the previous push's chain and this push's channeliser to work on while this thread
 	 * waits for that push's records and copies them. */
@@ -1564,6 +1563,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			HIPCHK(h, hipGetLastError());
 			if (two_streams)	/* a following push that keeps to the main stream must see the carry */
 				HIPCHK(h, hipEventRecord(h->f_tail, fs));
+			else {	/* ... and a following push's front stage this push's channeliser state and carry, made on the main stream */
+				HIPCHK(h, hipEventRecord(h->k1_ev, fs));
+				h->k1_ev_rec = true;
+			}
 		}
 		h->back.valid = true;
 		h->back.k2 = k2;
