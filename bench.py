@@ -82,6 +82,27 @@ def make_tile(seed: int, fmt: str, rate: int, fos, bursts_per_s: float = 4.0):
     return spec, synth.synth_stream(spec, fmt)
 
 
+def make_variants(seeds, fmt: str, rate: int, fos, bursts_per_s: float = 4.0):
+    """several different recordings of one tile length (numpy releases the GIL: one thread each)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(len(seeds), os.cpu_count() or 1))) as ex:
+        return list(ex.map(lambda sd: make_tile(sd, fmt, rate, fos, bursts_per_s)[1], seeds))
+
+
+def tile_order(i: int, ntiles: int, nbuf: int, nvar: int) -> int:
+    """which of a stream's `nvar` recordings is tile i of the stream: a push is `ntiles` tiles, recordings in turn; the
+    `nbuf` device buffers pushed in turn start one recording apart, so consecutive pushes differ as well"""
+    return ((i % ntiles) + (i // ntiles) % nbuf) % nvar
+
+
+def device_buffers(variants, ntiles, nbuf, dev):
+    """variants[stream][recording] -> nbuf tensors [stream, ntiles * tile] laid out as tile_order() says"""
+    import torch
+    dv = [[torch.from_numpy(v).to(dev) for v in per] for per in variants]
+    return [torch.stack([torch.cat([per[tile_order(b * ntiles + k, ntiles, nbuf, len(per))] for k in range(ntiles)]) for per in dv]).contiguous()
+            for b in range(nbuf)]
+
+
 def cpu_baseline(raw: np.ndarray, fmt: str, fos, rate: int, budget_s: float = 12.0):
     """Oracle ("port" of the reference path) on host cores: one thread per channel, like the reference's one
     rcv_thread per channel (main.c:228-231)."""
@@ -200,8 +221,8 @@ def _reference_run(raw, fmt, fos, rate, budget_s, names, n_tile, reps, tmpdir, h
     return res
 
 
-def oracle_stream(tile: np.ndarray, fmt: str, rate: int, fos, ntiles: int):
-    """The oracle over the very stream the GPU is fed -- `ntiles` repetitions of the tile, from the first sample on
+def oracle_stream(tiles, fmt: str, rate: int, fos, ntiles: int, order=None):
+    """The oracle over the very stream the GPU is fed -- `ntiles` tiles, tile i being recording order(i) of `tiles`, from the first sample on
     (the sync detector's timing class is carried from burst to burst, so what a tile decodes to depends on everything
     before it: there is no shortcut through periodicity).  One thread per channel, like the reference's one rcv_thread
     per channel (main.c:228-231).  Returns (packed records with absolute instants, seconds of wall time)."""
@@ -212,8 +233,8 @@ def oracle_stream(tile: np.ndarray, fmt: str, rate: int, fos, ntiles: int):
 
     def work(c):
         ch = O.OracleChannel(rate, fos[c], FC + fos[c], chn=c)
-        for _ in range(ntiles):
-            ch.feed(tile, fmt)          # ctypes releases the GIL
+        for i in range(ntiles):
+            ch.feed(tiles[order(i)] if order else tiles, fmt)          # ctypes releases the GIL
         out[c] = ch.blocks()
         ch.close()
 
@@ -237,12 +258,12 @@ def canon(recs: np.ndarray) -> bytes:
     return recs[order].tobytes()
 
 
-def oracle_streams(tiles, fmt, rate, fos, ntiles):
+def oracle_streams(tiles, fmt, rate, fos, ntiles, order=None):
     """oracle_stream() for several streams side by side (one thread per channel and stream)"""
     res = [None] * len(tiles)
 
     def work(i):
-        res[i] = oracle_stream(tiles[i], fmt, rate, fos, ntiles)
+        res[i] = oracle_stream(tiles[i], fmt, rate, fos, ntiles, order)
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(len(tiles))]
     for t in th:
@@ -267,9 +288,12 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     sample_bytes = {"cs16": 4, "cu8": 2}[fmt]
     batch = ntiles * TILE
     tile_dec = TILE * 21 // (rate // 4000)
-    tiles_np = [make_tile(seed=seed0 + g, fmt=fmt, rate=rate, fos=fos, bursts_per_s=bursts_per_s)[1] for g in range(nstr)]
     NBUF = 2
-    dbufs = [torch.stack([torch.from_numpy(t).to(dev).repeat(ntiles) for t in tiles_np]).contiguous() for _ in range(NBUF)]
+    nvar = min(16, ntiles) if nstr == 1 else 1        # different recordings in turn (see tile_order): no recording twice in a push
+    flat = make_variants([seed0 + g + 1000 * v for g in range(nstr) for v in range(nvar)], fmt, rate, fos, bursts_per_s)
+    variants = [flat[g * nvar:(g + 1) * nvar] for g in range(nstr)]
+    order = lambda i: tile_order(i, ntiles, NBUF, nvar)
+    dbufs = device_buffers(variants, ntiles, NBUF, dev)
     stride_bytes = dbufs[0].stride(0) * dbufs[0].element_size()
     cap = 1 << 19
     store = (_lib.BurstT * cap)()
@@ -323,7 +347,7 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     tidx = got["trig_dec"] // tile_dec
     t_hi = total_tiles - 1
     ncheck = min(nstr, check_streams)
-    exp, osec = oracle_streams(tiles_np[:ncheck], fmt, rate, fos, total_tiles)
+    exp, osec = oracle_streams(variants[:ncheck], fmt, rate, fos, total_tiles, order)
     nb, bad = 0, 0
     for sidx in range(ncheck):
         e = exp[sidx]
@@ -338,9 +362,9 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     dec_total = st["dec_samples"] * 8 * nstr
     return {"workload": workload, "value": value if equal else None, "unit": "MS/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "warmup": warmup, "fmt": fmt, "sdrinrate": rate, "streams": nstr, "channels": 8 * nstr, "samples_per_step": batch * nstr,
-            "bursts_per_s_per_channel_offered": bursts_per_s, "bursts_per_step": int(round(nrec / max(1, npush))),
+            "bursts_per_s_per_channel_offered": bursts_per_s, "recordings_per_stream": nvar, "bursts_per_step": int(round(nrec / max(1, npush))),
             "first_push_ms": first_ms, "max_push_ms": max(slow),
-            "serial_samples_frac": st["serial_samples"] / max(1, dec_total), "serial_redos": st["serial_redos"], "overflowed": st["overflowed"],
+            "serial_samples_frac": st["serial_samples"] / max(1, dec_total), "repairs": st["repairs"], "serial_redos": st["serial_redos"], "overflowed": st["overflowed"],
             "parity": {"equal": equal, "bursts_checked": nb, "streams_checked": ncheck, "tiles_checked": t_hi, "oracle_seconds": osec,
                        "what": "every burst from the first sample of the run on, vs the oracle over the same stream"}}
 
@@ -452,6 +476,7 @@ def main():
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
     ap.add_argument("--rate", type=int, default=0, help="override the config's SDRINRATE (5000000 / 6000000)")
     ap.add_argument("--streams", type=int, default=0, help="override the config's streams per GPU")
+    ap.add_argument("--recordings", type=int, default=0, help="different synthetic recordings per stream, pushed in turn (0 = 4 for one stream, 2 otherwise)")
     ap.add_argument("--frames", action="store_true",
                     help="also run the block path (RS, HDLC, FCS: SURVEY 8f-1) on every push's bursts and collect the frames")
     ap.add_argument("--no-cpu", action="store_true")
@@ -497,10 +522,17 @@ def main():
     batch = ntiles * TILE
     tile_dec = TILE * 21 // (rate // 4000)
 
-    tiles_np = [make_tile(seed=1234 + g, fmt=args.fmt, rate=rate, fos=fos)[1] for g in mine]
-    # three copies at different addresses, pushed in turn: what a push reads was last touched two pushes ago
+    # Different 2.1 s recordings per stream, in turn (tile_order): a push of 16 tiles is 16 different recordings (33.6 s of air time in
+    # which nothing repeats -- a repeated recording repeats its rare events with it: a noise trigger that exists in one timing class
+    # only, one per ~100 channel-seconds, came back in every tile, each time behind the repair of the one before), and the three
+    # device buffers pushed in turn start one recording apart; what a push reads was last touched two pushes ago.
     NBUF = 3
-    dbufs = [torch.stack([torch.from_numpy(t).to(dev).repeat(ntiles) for t in tiles_np]).contiguous() for _ in range(NBUF)]
+    nvar = max(1, args.recordings or (min(16, ntiles) if nstr == 1 else 2))
+    flat = make_variants([1234 + g + 1000 * v for g in mine for v in range(nvar)], args.fmt, rate, fos)
+    variants = [flat[k * nvar:(k + 1) * nvar] for k in range(len(mine))]
+    tiles_np = [per[0] for per in variants]
+    order = lambda i: tile_order(i, ntiles, NBUF, nvar)
+    dbufs = device_buffers(variants, ntiles, NBUF, dev)
     stride_bytes = dbufs[0].stride(0) * dbufs[0].element_size()
 
     rx = Receiver(rate, [plan_channels(FC, fos)] * nstr, fmt=args.fmt, max_push=batch, device=local, max_bursts=1 << 18,
@@ -628,7 +660,7 @@ def main():
         nb_checked, bad, per_stream = 0, [], []
         oracle_time = 0.0
         for s in range(ncheck_streams):
-            e, dt_o = oracle_stream(tiles_np[s], args.fmt, rate, fos, ncheck_tiles)
+            e, dt_o = oracle_stream(variants[s], args.fmt, rate, fos, ncheck_tiles, order)
             oracle_time += dt_o
             et = e["trig_dec"] // tile_dec
             e = e[(et >= t_lo) & (et < t_hi)]
@@ -702,6 +734,20 @@ def main():
         except (OSError, KeyError, ValueError, IndexError):
             pass
         parity_ok = ok_all or args.no_parity
+        # what actually bounds the channeliser: VALU issue.  The reference's D += x*w is eight separately rounded operations = four
+        # packed FP32 instructions per sample and channel (no FMA: it rounds differently); a SIMD-32 issues a wave's packed
+        # instruction in 4 cycles, a plain one in 2 (MI355X_MICROARCH.md: 157 TFLOP/s FP32 = 64 flop/clk/SIMD).
+        valu = None
+        if kname == "k1_fast" and iso_ms > 0:
+            packed = fast_samples * 8 * 4 / 64.0                    # wave instructions: samples x channels x 4 / 64 lanes
+            other = packed * (41.8 - 33.6) / 33.6                   # conversion, addressing, division (SQ_INSTS_VALU, profiles/r03_bench_pmc_sq.json)
+            cyc = (packed * 4 + other * 2) / (256 * 4)              # per SIMD
+            floor_ms = cyc / 2.4e9 * 1e3
+            valu = {"packed_fp32_wave_insts": packed, "other_valu_wave_insts": other, "simd_cycles": cyc, "floor_ms_at_2400MHz": floor_ms,
+                    "frac_alone": floor_ms / iso_ms, "frac_live": floor_ms / fast_ms if fast_ms > 0 else None,
+                    "note": "share of the launch the SIMDs need for the mixer's instructions alone at the peak clock (the part sustains "
+                            "2.0-2.1 GHz under this load): the kernel is within a third of its instruction-issue bound while it uses a "
+                            "quarter of the HBM bandwidth -- the bound the `roofline` contract asks for (hbm) is not the one that binds"}
         out = {
             "metric": "IQ MS/s demodulated (8 ch, 2 MS/s cs16) + CRC-pass frame parity vs ref",
             "value": value if parity_ok else None, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -714,11 +760,14 @@ def main():
                        "bursts_per_step": total_bursts / max(1, args.steps * world),
                        "x_real_time": value * 1e6 / rate, "parallelism": f"stream-sharded x{world}",
                        "rccl_world_size": dist.get_world_size() if world > 1 else 1,
-                       "input_buffers": NBUF},
+                       "input_buffers": NBUF, "recordings_per_stream": nvar,
+                       "input_note": f"{nvar} different synthetic recordings of {TILE / rate:.1f} s per stream, in turn; the {NBUF} device "
+                                     "buffers pushed in turn start one recording apart (bench.py tile_order)"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
                          "whole_path_frac": (batch * nstr * sample_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                         "valu_issue": valu,
                          "alone": {"avg_launch_ms": iso_ms, "achieved": alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0,
                                    "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else 0.0,
                                    "how": "4 pushes after the timed region, each synchronised before the next: no other kernel on the GPU"},
@@ -736,7 +785,7 @@ def main():
                                    "stage of the one before (clusters, resolver, verify): the intervals overlap and are longer than the "
                                    "kernels alone -- their sum (demod_chain + k1) exceeds ms_per_step, it is not a critical path"},
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
-                                           "candidates", "serial_redos", "serial_samples", "overflowed")},
+                                           "candidates", "repairs", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,
             "host_ms_per_step": {"in_push": host_s[0] / args.steps * 1e3, "in_poll_ready": host_s[1] / args.steps * 1e3,
                                  "note": "wall time of the calling thread inside vdl2gpu_push (enqueues the step's ~20 launches) and inside "

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VDL2GPU_ABI_VERSION 3	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_* */
+#define VDL2GPU_ABI_VERSION 4	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_*; 4: vdl2gpu_stats_t.repairs */
 #define VDL2GPU_MAXCH 8		/* MAXNBCHANNELS vdlm2.h:26 */
 #define VDL2GPU_MAXROWS 8	/* bursts with more rows are rejected, d8psk.c:103 */
 #define VDL2GPU_ROWLEN 255
@@ -136,6 +136,8 @@ typedef struct {
 	uint64_t serial_samples;	/* 84 kS/s samples handled by the serial machine (history-dependent stretches) */
 	uint64_t overflowed;	/* burst records dropped: device ring full, or host queue never drained */
 	uint64_t frames_dropped;	/* VDL2GPU_F_FRAMES: frames dropped (arena full, more than 12 frames in a burst, host queue never drained) */
+	uint64_t repairs;	/* channel-pushes a repair round re-resolved because the verify pass found an unlisted event (cheap; serial_redos
+				 * counts the ones no scheduled round could settle) */
 } vdl2gpu_stats_t;
 
 typedef struct {

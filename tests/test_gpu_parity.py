@@ -352,12 +352,13 @@ def test_silence_between_signals(built, oracle):
     assert _gpu_keys(got) == want and len(want) >= 1
 
 
-def test_verify_pass_catches_incomplete_tables(built, oracle):
+def test_verify_pass_catches_incomplete_tables(built, oracle, monkeypatch):
     """With the region scan switched off the candidate tables lack most trigger classes, so the
-    resolver's chain is wrong after the first burst; K2a-verify must notice and the serial redo must
-    still deliver exactly the oracle's bursts."""
+    resolver's chain is wrong after the first burst; K2a-verify must notice and -- with no repair round
+    scheduled -- the serial redo must still deliver exactly the oracle's bursts."""
     from vdlm2dec_amd import lib
     from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", "0")
     spec = synth.random_scenario(2_000_000, S.FO8[:3], 1 << 21, seed=92, bursts_per_s=10.0, info_max=100)
     raw = synth.synth_stream(spec, "cs16")
     want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
@@ -369,12 +370,12 @@ def test_verify_pass_catches_incomplete_tables(built, oracle):
     assert _gpu_keys(got) == want and len(want) >= 15
 
 
-@pytest.mark.parametrize("rounds", [1, 3])
-def test_repair_rounds_rescan_around_verify_hits(built, oracle, monkeypatch, rounds):
-    """Same handicap, but with repair rounds on from the first push: every event the verify pass finds
-    becomes a seed, its neighbourhood is scanned in all classes and the chain resolved again; the last
-    scheduled round (the only one with rounds = 1) scans the channels that still fail completely, which
-    leaves nothing to verify -- no channel may be left to the serial redo, and the result is the oracle's."""
+@pytest.mark.parametrize("rounds", [2, 3])
+def test_repair_rounds_settle_what_the_verify_pass_finds(built, oracle, monkeypatch, rounds):
+    """Same handicap, with two or three repair rounds from the first push: every event the verify pass finds joins the
+    table as a candidate without a cluster and the resolver runs again (replaying those itself); with most classes
+    missing the new chain fails its own verify pass, and the last scheduled round scans the channels that still fail
+    completely, which leaves nothing to verify -- no channel may be left to the serial redo, and the result is the oracle's."""
     from vdlm2dec_amd import lib
     from vdlm2dec_amd.demod import Receiver, plan_channels
     monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", str(rounds))
@@ -387,6 +388,27 @@ def test_repair_rounds_rescan_around_verify_hits(built, oracle, monkeypatch, rou
         st = rx.stats()
     assert _gpu_keys(got) == want and len(want) >= 15
     assert st["serial_redos"] == 0
+
+
+@pytest.mark.parametrize("seed,bps", [(1077, 4.0), (5077, 4.0), (1077, 15.0)])
+def test_an_event_in_one_class_only_costs_a_resolver_round_not_a_serial_redo(built, oracle, seed, bps):
+    """Recordings of bench.py's generator in which a noise trigger exists in ONE timing class only, far from anything the
+    probe's class sees (scripts/dev/unseeded.py: about one per 100 channel-seconds) -- and the chain happens to idle in
+    that class there.  The verify pass finds it; the one repair round that is always scheduled re-resolves the channel
+    with it (round 3 before this test: a serial redo of the channel's whole push, 8-10 ms for the first push of a handle).
+    Defaults throughout: no environment knobs, no test build.  (The second half of the push is another recording: the same
+    one twice holds the same event twice, the second behind the repair of the first -- two rounds' work.)"""
+    import bench
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec, raw = bench.make_tile(seed, "cs16", 2_000_000, S.FO8, bps)
+    big = np.concatenate([raw, bench.make_tile(2077, "cs16", 2_000_000, S.FO8, bps)[1]])
+    want = sorted(b.key() for b in oracle.run_oracle(big, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=big.size // 2) as rx:
+        rx.push(big)
+        got = rx.poll()
+        st = rx.stats()
+    assert _gpu_keys(got) == want and len(want) >= 60
+    assert st["repairs"] >= 1 and st["serial_redos"] == 0, st
 
 
 @pytest.mark.timeout(300)

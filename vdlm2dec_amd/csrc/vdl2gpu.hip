@@ -111,12 +111,15 @@ struct vdl2gpu {
 	int stage_every = 4;
 	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
 	bool k2_rec[2] = {false, false};
-	hipStream_t pay_stream = nullptr;	/* K2d beside the verify pass (when no repair rounds are scheduled) */
+	hipStream_t pay_stream = nullptr;	/* K2d beside the verify pass; then the push's TAIL (repair rounds, commit, export, counters: see enqueue_back) */
+	hipEvent_t verify_done = nullptr, k2f_done = nullptr;	/* main -> tail: the verify pass has run; tail -> main: the channel states are committed */
+	bool k2f_rec = false;
+	hipStream_t tail_prev = nullptr;	/* the stream the previous push's tail ran on */
 	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
 	unsigned *d_fmask[2] = {nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
 	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
-	int rounds_floor = 0;		/* many channels: one (complete) round is always scheduled, see create */
+	int rounds_floor = 1;		/* one (resolver-only) repair round is always scheduled, see enqueue_back */
 	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked; halved
 					 * whenever a channel's candidate tables overflow */
 	size_t split_default = 0;
@@ -167,6 +170,8 @@ struct vdl2gpu {
 	 * library built with -DVDL2GPU_TESTHOOKS (libvdl2gpu_test.so, which the tests load). */
 	struct {
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
+		bool no_tail = false;		/* VDL2GPU_NO_TAIL: everything behind the verify pass stays on the main stream */
+		bool k2b_front = false;		/* VDL2GPU_K2B_FRONT: the cluster kernel at the end of the front stage instead of the start of the back stage */
 		bool k1_pp = false;		/* VDL2GPU_K1_PP: k1_pp at 2 MS/s as well */
 		bool debug_counters = false;	/* VDL2GPU_DEBUG_COUNTERS: cycle counters of the demodulator kernels */
 		bool split_fixed = false;	/* (test hook) the part length was given: do not adapt it */
@@ -542,6 +547,10 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipEventDestroy(h->k2c_done);
 	if (h->pay_done)
 		(void)hipEventDestroy(h->pay_done);
+	if (h->verify_done)
+		(void)hipEventDestroy(h->verify_done);
+	if (h->k2f_done)
+		(void)hipEventDestroy(h->k2f_done);
 	(void)hipFree(h->d_fmask[0]);
 	(void)hipFree(h->d_fmask[1]);
 	(void)hipFree(h->d_ctl[0]);
@@ -651,6 +660,8 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipStreamCreateWithFlags(&h->pay_stream, hipStreamNonBlocking));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2c_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->pay_done, hipEventDisableTiming));
+	HIPCHK(h, hipEventCreateWithFlags(&h->verify_done, hipEventDisableTiming));
+	HIPCHK(h, hipEventCreateWithFlags(&h->k2f_done, hipEventDisableTiming));
 	for (int r = 0; r < 2; ++r)
 		HIPCHK(h, hipMalloc(&h->d_fmask[r], 16 * sizeof(unsigned)));
 	for (int r = 0; r < 2; ++r)
@@ -695,6 +706,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->stage_every = std::max(1, env_int("VDL2GPU_STAGE_EVERY", h->stage_every));
 	h->k2d_grid = std::max(1, env_int("VDL2GPU_K2D_GRID", h->k2d_grid));
 	h->knob.no_k1_fast = getenv("VDL2GPU_NO_K1_FAST") != nullptr;
+	h->knob.k2b_front = env_int("VDL2GPU_K2B_FRONT", 0) != 0;
+	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
 	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
 	h->knob.k1f_nfam = env_int("VDL2GPU_K1F_NFAM", 0);
@@ -717,7 +730,7 @@ static int create_impl(vdl2gpu_t *h)
 		h->knob.split_fixed = true;
 	}
 #endif
-	h->rounds_floor = (h->S * h->C >= 16) ? 1 : 0;
+	h->rounds_floor = 1;	/* see enqueue_back */
 	h->repair_rounds = env_int("VDL2GPU_REPAIR_ROUNDS", h->rounds_floor);
 	h->force_serial = (cfg.flags & VDL2GPU_F_SERIAL) ? 1 : 0;
 	h->quirk = (cfg.flags & VDL2GPU_F_RTL_QUIRK) ? 1 : 0;
@@ -1034,13 +1047,15 @@ static int enqueue_back(vdl2gpu_t *h)
 	 * balanced with it here: FRONT = channeliser + scan, BACK = clusters + resolver + verify */
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[2], rs));
-	if (!serial)
+	if (!serial && !h->knob.k2b_front)
 		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[3], rs));
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[13], rs));
+	if (h->k2f_rec)		/* the channel states the resolver starts from are committed on the previous push's tail */
+		HIPCHK(h, hipStreamWaitEvent(rs, h->k2f_done, 0));
 	hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
@@ -1063,48 +1078,73 @@ static int enqueue_back(vdl2gpu_t *h)
 	if (!serial)
 		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
 	HIPCHK(h, hipGetLastError());
+	/* ---- the TAIL: everything behind the verify pass -- repair rounds, commit, the payloads a round re-resolved, block path,
+	 * export, counters: a chain of one-workgroup-per-channel kernels and a PCIe copy, 0.1 ms while nothing fails and 0.3 ms when
+	 * a channel is repaired (most pushes of ordinary traffic).  On the main stream it stood between this push's verify pass and
+	 * the NEXT push's cluster kernel, which needs none of it; it runs on the payload stream instead (behind the payload decode
+	 * it would have had to wait for anyway), the main stream goes on with the next push, and only that push's resolver waits --
+	 * for the commit (k2f_done), which the cluster kernel in front of it covers.  k2_done, which frees the plane and table sets
+	 * and tells the host the ring is complete, is recorded at the tail's end. */
+	hipStream_t ts = (spec && h->back.two_streams && !h->knob.no_tail) ? h->pay_stream : h->stream;
+	if (ts != h->stream) {
+		HIPCHK(h, hipEventRecord(h->verify_done, h->stream));
+		HIPCHK(h, hipStreamWaitEvent(ts, h->verify_done, 0));
+	}
+	if (h->tail_prev && h->tail_prev != ts && h->k2_rec[par ^ 1])	/* tails follow each other (running totals, StreamState) */
+		HIPCHK(h, hipStreamWaitEvent(ts, h->k2_done[par ^ 1], 0));
+	h->tail_prev = ts;
 	if (!h->full_scan && !serial) {
-		/* repair round: channels whose verify found an unlisted hit are re-sorted, re-clustered,
-		 * re-resolved and re-verified with that hit in their table; every other channel's
-		 * workgroups exit at once.  What still fails is redone serially by K2f. */
+		/* Repair rounds.  The verify pass has appended what it found to the failing channel's table (candidates without
+		 * clusters): a round re-sorts the table, re-resolves the channel -- the resolver replays the new candidates with the
+		 * serial machine and returns to the tables behind each -- and verifies the stretches the new chain idles through
+		 * (other classes than before from the first new event on).  Every other channel's workgroups exit at once: three
+		 * launches, ~12 us, when nothing failed -- which is why one round is ALWAYS scheduled: an unlisted event (a noise
+		 * trigger that exists in one class only) turns up about once per 100 channel-seconds of ordinary traffic, and without
+		 * a round it costs a serial redo of the channel's whole push (K2f: 8 ms at 33 s of air time).  If more than one round
+		 * is scheduled (after a serial redo: adapted below), the LAST one does not repair, it starts over: the channels that
+		 * still fail are scanned completely -- every class at every instant, like VDL2GPU_F_FULLSCAN but for them alone
+		 * (~0.1 ms for a channel of a 67 MS push) -- their tables rebuilt from nothing, which leaves nothing to verify and
+		 * nothing to cascade.  What still fails after the last round is redone serially by K2f. */
 		K2Params k2r = k2;
-		if (spec && h->repair_rounds > 0)	/* a repair round rewrites the selection K2d is reading */
+		if (spec && h->repair_rounds > 0 && ts == h->stream)	/* a repair round rewrites the selection K2d is reading (on the payload stream the tail is behind it anyway) */
 			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));
+		const dim3 vgrid((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S);
 		for (int rr = 1; rr <= h->repair_rounds; ++rr) {
 			k2r.round = rr;
-			/* The LAST scheduled round does not repair, it starts over: the channels that still fail are scanned
-			 * completely -- every class at every instant, like VDL2GPU_F_FULLSCAN but for them alone (≈ 0.1 ms for
-			 * a channel of a 67 MS push) --, which leaves nothing to verify and nothing to cascade; before it,
-			 * rounds that only scan around what the verify pass found (cheaper when they suffice). */
-			k2r.full_round = (rr == h->repair_rounds) ? 1 : 0;
-			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, h->stream, k2r);
+			k2r.full_round = (rr == h->repair_rounds && h->repair_rounds >= 2) ? 1 : 0;
+			k2r.mini_round = k2r.full_round ? 0 : 1;
 			if (k2r.full_round) {
+				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, ts, k2r);	/* (resets the channel's tables) */
 				const unsigned want = tiles;
 				unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
 				per = per > want ? want : per;
-				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
-			} else
-			hipLaunchKernelGGL(k2a_region, dim3(32, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
-			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, h->stream, k2r);
-			hipLaunchKernelGGL(k2b_clusters, dim3(k2r.full_round ? (unsigned)(h->n_cu * 4 * K2B_WAVES) : 256u, (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, h->stream, k2r);
-			hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, h->stream, k2r);
-			if (!k2r.full_round)	/* (complete tables leave nothing to verify) */
-				hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2r);
+				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, ts, k2r);
+				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, ts, k2r);
+				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
+				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
+			} else {
+				hipLaunchKernelGGL(k2s_merge, gch, dim3(K2M_NT), 0, ts, k2r);
+				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
+				hipLaunchKernelGGL(k2a_verify, vgrid, dim3(K2A_THREADS), 0, ts, k2r);
+			}
 		}
 		HIPCHK(h, hipGetLastError());
 	}
 	if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[5], h->stream));
-	hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, h->stream, k2);
+		HIPCHK(h, hipEventRecord(pt.e[5], ts));
+	hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, ts, k2);
+	HIPCHK(h, hipEventRecord(h->k2f_done, ts));
+	h->k2f_rec = true;
 	if (h->ring_spec[ring]) {
-		HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
+		if (ts == h->stream)
+			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
 		if (h->repair_rounds > 0 && !h->full_scan && !serial) {
 			K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
 			k2p.pay_final = 1;
-			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2p);
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2p);
 		}
 	} else
-		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, h->stream, k2);
+		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2);
 	HIPCHK(h, hipGetLastError());
 	if (h->frames_on) {
 		/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
@@ -1121,11 +1161,11 @@ static int enqueue_back(vdl2gpu_t *h)
 		k4.tabs = h->d_k4tab;
 		k4.fmask = h->ring_spec[ring] ? h->d_fmask[par] : nullptr;
 		k4.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
-		hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 16), dim3(K4_NT), 0, h->stream, k4);
+		hipLaunchKernelGGL(k4_frames, dim3((unsigned)h->n_cu * 16), dim3(K4_NT), 0, ts, k4);
 		HIPCHK(h, hipGetLastError());
 	}
 	if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[6], h->stream));
+		HIPCHK(h, hipEventRecord(pt.e[6], ts));
 	{
 		K3Params k3{};
 		k3.src = h->d_dec[par];
@@ -1149,15 +1189,15 @@ static int enqueue_back(vdl2gpu_t *h)
 			ke.count = h->d_outc + 2 * ring;
 			ke.dst = h->d_slab[ring];
 			ke.cap = std::min(h->slab_cap, h->rec_cap);
-			hipLaunchKernelGGL(k_export_records, dim3((unsigned)h->n_cu), dim3(256), 0, h->stream, ke);
+			hipLaunchKernelGGL(k_export_records, dim3((unsigned)h->n_cu), dim3(256), 0, ts, ke);
 			HIPCHK(h, hipGetLastError());
 		}
-		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, h->stream, k3);
+		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, ts, k3);
 		HIPCHK(h, hipGetLastError());
 	}
 	if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[7], h->stream));
-	HIPCHK(h, hipEventRecord(h->k2_done[par], h->stream));
+		HIPCHK(h, hipEventRecord(pt.e[7], ts));
+	HIPCHK(h, hipEventRecord(h->k2_done[par], ts));
 	h->k2_rec[par] = true;
 	/* (the same event tells the host that this push's output ring is complete: ring == par) */
 	return VDL2GPU_OK;
@@ -1181,6 +1221,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	if (h->pending.size() >= 256) {	/* bound the event backlog */
 		HIPCHK(h, hipStreamSynchronize(h->fstream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->pay_stream));
 		int rc = harvest_timing(h);
 		if (rc)
 			return rc;
@@ -1201,6 +1242,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (need > h->raw_bytes[stg]) {
 			HIPCHK(h, hipStreamSynchronize(h->fstream));
 			HIPCHK(h, hipStreamSynchronize(h->stream));
+			HIPCHK(h, hipStreamSynchronize(h->pay_stream));
 			HIPCHK(h, hipStreamSynchronize(h->in_stream));
 			(void)hipFree(h->d_raw[stg]);
 			h->d_raw[stg] = nullptr;
@@ -1270,6 +1312,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	hipStream_t ks = fs;
 	if (!two_streams && h->last_two_streams)	/* the previous push's channeliser state and carry were written on the front stream */
 		HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
+	if (!two_streams && h->k2_rec[par ^ 1])	/* ... and its tail may have run on the payload stream */
+		HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par ^ 1], 0));
 	if (two_streams) {
 		/* the plane set and the table set of this parity were last used by the push before last */
 		if (h->k2_rec[par])
@@ -1538,6 +1582,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		}
 		if (!serial)
 			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs, k2);
+		if (!serial && h->knob.k2b_front)
+			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs, k2);
 		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[4], fs));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
 		HIPCHK(h, hipGetLastError());
@@ -1603,6 +1649,7 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	HIPCHK(h, hipStreamSynchronize(h->fstream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->pay_stream));
 	return harvest_timing(h);
 }
 
@@ -1669,16 +1716,14 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			h->last_ovf_push = h->ring_push[ring];
 	}
 	{
-		/* repair rounds only cost launches while nothing fails, so: none until the first verify
-		 * failure shows up (as a serial redo), then as many as it takes to get rid of the serial
-		 * redos, and back down one at a time after long quiet stretches */
+		/* one round always (enqueue_back); one more after every serial redo -- a repaired chain failed its own verify pass
+		 * as often as rounds were scheduled --, and back down one at a time after 256 pushes without a serial redo (what
+		 * the first round repairs does not count: it is always there) */
 		const unsigned redos = h->h_pin_cnt[32 * ring + 2], repairs = h->h_pin_cnt[32 * ring + 3];
 		if (redos != h->redos_seen) {
 			h->redos_seen = redos;
 			h->last_redo_push = h->ring_push[ring];
 			h->repair_rounds = std::min(4, h->repair_rounds + 1);
-		} else if (repairs != h->repairs_seen) {
-			h->last_redo_push = h->ring_push[ring];	/* the rounds are earning their keep */
 		} else if (h->repair_rounds > h->rounds_floor && h->ring_push[ring] > h->last_redo_push + 256) {
 			h->repair_rounds--;
 			h->last_redo_push = h->ring_push[ring];
@@ -2031,6 +2076,7 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 		}
 	out->overflowed = h->overflowed;
 	out->frames_dropped = h->frames_dropped;
+	out->repairs = h->repairs_seen;
 	return VDL2GPU_OK;
 }
 

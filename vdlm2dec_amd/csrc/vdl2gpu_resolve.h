@@ -10,6 +10,7 @@
  * when it ever needs one (status CL_INVALID), so this is a cost decision, never a correctness one.
  */
 #define K2S_NT 1024
+#define K2S_MERGE 256		/* candidates a repair round merges into the sorted table instead of sorting again */
 #define K2S_LOOKBACK 72		/* a triggered detector is busy for at least 9 symbols = 72 samples */
 __global__ __launch_bounds__(K2S_NT)
 void k2s_sort(K2Params p)
@@ -28,15 +29,15 @@ void k2s_sort(K2Params p)
 	if (ncand > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] != 0)
 		return;		/* tables unusable: the resolver runs serially */
 	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
 	for (int i = tid; i < ncand; i += K2S_NT)
 		sbuf[i] = (((unsigned long long)(unsigned)(cands[i].nrel * 4 + cands[i].r)) << 16) | (unsigned)i;
 	if (tid == 0)
 		s_np = 0;
 	__syncthreads();
 	wg_sort_u64<K2S_NT>(sbuf, ws, ncand, 18, (unsigned)(VDL2_CARRY_FRAMES + p.J));
-	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
-	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
-	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
 	/* repair round: candidates are only ever appended and a cluster depends on nothing but its own
 	 * candidate and the samples, so the clusters of the earlier rounds stand -- only primaries that are new
 	 * (or were not primary before) go to K2b */
@@ -73,6 +74,93 @@ void k2s_sort(K2Params p)
 		p.ctl[CTL_NCLUST0 + sc] = (unsigned)ncand;
 	}
 }
+
+/* K2s for a repair round that only re-resolves (K2Params.mini_round): the table is sorted but for the handful of candidates
+ * the verify pass appended -- merge them in.  Every old entry moves up by the number of new keys below it, every new one goes
+ * where a binary search of the old list plus its rank among the new ones puts it (keys are unique: what the verify pass lists
+ * was not in the table).  Nothing else changes: the old clusters stand, the new candidates have none (their heads say so), no
+ * primaries are chosen.  A kernel of its own because of its footprint: 2 KB of LDS where k2s_sort has 84 -- one workgroup per
+ * channel that wants half a CU's LDS waits for the other stage's wide kernel to drain before it gets it. */
+#define K2M_NT 256	/* four wavefronts of 40 registers fit beside anything */
+__global__ __launch_bounds__(K2M_NT)
+void k2s_merge(K2Params p)
+{
+	__shared__ unsigned long long knew[K2S_MERGE];
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial || p.fail[sc] >= VDL2_VERIFIED)
+		return;
+	const int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
+	if (ncand > VDL2_CAND_CAP || *ovf != 0)
+		return;		/* tables unusable: the resolver runs serially */
+	const int nold = (int)p.ctl[CTL_NCLUST0 + sc], nnew = ncand - nold;
+	if (nnew <= 0)
+		return;		/* (a channel that failed for another reason than an unlisted event: the resolver will find nothing new) */
+	if (nnew > K2S_MERGE) {	/* a handicapped test build, a pathological input: not worth a sort kernel's footprint in every push */
+		if (tid == 0)
+			*ovf = 1u;	/* the resolver takes the channel through the serial machine (a complete round resets this) */
+		return;
+	}
+	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
+	unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
+	if (tid < nnew)
+		knew[tid] = (((unsigned long long)(unsigned)(cands[nold + tid].nrel * 4 + cands[nold + tid].r)) << 16) | (unsigned)(nold + tid);
+	__syncthreads();
+	/* everything is read before anything is written: a thread's share of the old list into registers, the new keys' places by
+	 * binary search of the old list */
+	constexpr int PER = VDL2_CAND_CAP / K2M_NT;
+	unsigned long long v[PER];
+	int up[PER];
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		const int j = tid + k * K2M_NT;
+		v[k] = j < nold ? (((unsigned long long)(unsigned)skey[j] << 16) | sidx[j]) : ~0ull;
+	}
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		up[k] = 0;
+		for (int i = 0; i < nnew; ++i)
+			up[k] += (knew[i] < v[k]) ? 1 : 0;
+	}
+	int at = 0;
+	unsigned long long vn = 0;
+	if (tid < nnew) {
+		vn = knew[tid];
+		const int kn = (int)(vn >> 16);
+		int a = 0, b = nold;	/* old entries below vn */
+		while (a < b) {
+			const int m = (a + b) >> 1;
+			if (skey[m] < kn)
+				a = m + 1;
+			else
+				b = m;
+		}
+		at = a;
+		for (int i = 0; i < nnew; ++i)
+			at += (knew[i] < vn) ? 1 : 0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		const int j = tid + k * K2M_NT;
+		if (j < nold) {
+			skey[j + up[k]] = (int)(v[k] >> 16);
+			sidx[j + up[k]] = (unsigned short)(v[k] & 0xffffu);
+		}
+	}
+	if (tid < nnew) {
+		skey[at] = (int)(vn >> 16);
+		sidx[at] = (unsigned short)(vn & 0xffffu);
+	}
+	if (tid == 0) {
+		p.ctl[CTL_NPRIM0 + sc] = 0u;
+		p.ctl[CTL_NCLUST0 + sc] = (unsigned)ncand;
+	}
+}
+static_assert(VDL2_CAND_CAP % K2M_NT == 0 && K2S_MERGE <= K2M_NT, "k2s_merge");
 
 /* ====================================================================== K2b
  * One wavefront per primary trigger candidate (persistent workgroups pull tickets):
@@ -277,9 +365,13 @@ void k2c_resolve(K2Params p)
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
+	int seg_from = -0x7fffffff;	/* repair round: stretches that end at or before the earliest event the verify pass found lie on the unchanged
+					 * part of the chain and have been verified -- only what lies behind is listed again */
 	if (p.round > 0) {
-		if (p.fail[sc] >= VDL2_VERIFIED)
+		const int fail_in = p.fail[sc];
+		if (fail_in >= VDL2_VERIFIED)
 			return;		/* verified in the first pass: nothing to repair */
+		seg_from = fail_in;
 		__syncthreads();
 		if (tid == 0) {
 			p.redo[sc] = 1;
@@ -464,16 +556,19 @@ void k2c_resolve(K2Params p)
 			if (lazy && (st.r != r_probe || (int)(st.pos & 1) != par_probe)) {
 				/* the chain idles from here to the next candidate in a class the probe did not
 				 * scan: K2a-verify must confirm there really is nothing in between */
-				const unsigned q = atomicAdd(nseg, 1u);
-				if (q < VDL2_SEG_CAP) {
-					Seg g;
-					g.lo = (int)(st.pos - cx.dec_base);
-					g.hi = (cur >= 0) ? (skey[cur] >> 2) : t_end;
-					g.r = st.r;
-					g.pad = 0;
-					segs[q] = g;
-				} else
-					atomicMin(p.fail + sc, 0);
+				const int g_hi = (cur >= 0) ? (skey[cur] >> 2) : t_end;
+				if (g_hi > seg_from) {
+					const unsigned q = atomicAdd(nseg, 1u);
+					if (q < VDL2_SEG_CAP) {
+						Seg g;
+						g.lo = (int)(st.pos - cx.dec_base);
+						g.hi = g_hi;
+						g.r = st.r;
+						g.pad = 0;
+						segs[q] = g;
+					} else
+						atomicMin(p.fail + sc, 0);
+				}
 			}
 			if (cur >= 0 && sstat[cur] != CL_STEADY)
 				why = 1;
@@ -600,7 +695,8 @@ void k2c_resolve(K2Params p)
 				d += (hd.y >> 24) & 255;
 				const int r_s = (hd.y >> 2) & 3;
 				const long long n_s = cx.dec_base + hd.x;
-				if (lazy && sstat[j] == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe)) {
+				if (lazy && sstat[j] == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe) &&
+				    ((snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2)) > seg_from) {
 					/* after this cluster the chain idles in class (r_s, parity of n_s) until
 					 * the successor's trigger (or the end of the data) */
 					const unsigned q = (unsigned)atomicAdd(&s_walk[1], 1);

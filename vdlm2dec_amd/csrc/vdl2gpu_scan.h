@@ -131,13 +131,24 @@ __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long de
 	} else {
 		if (n < chk_lo || n >= chk_hi)
 			return;
-		/* a detector hit the tables did not list: remember where, and make it a seed so that the
-		 * repair round scans its neighbourhood in every class (that finds this hit again, and
-		 * whatever else the detector does around it) */
+		/* a detector hit the tables did not list: remember where, and list it -- a candidate without a cluster: the repair
+		 * round is the resolver alone, over the tables plus these (it replays a candidate that has no cluster with the
+		 * serial machine and is back on the tables behind it).  Not a duplicate: the chain idled through this instant in
+		 * this class, so the table had nothing here. */
 		atomicMin(fail, (int)(n - dec_base));
-		const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
-		if (kk < VDL2_CAND_CAP)
-			p.seeds[(size_t)sc * VDL2_CAND_CAP + kk] = (int)(n - dec_base);
+		const unsigned kc = atomicAdd(cntp, 1u);
+		if (kc < VDL2_CAND_CAP) {
+			Cand cd;
+			cd.nrel = (int)(n - dec_base);
+			cd.r = r;
+			cd.p2err = p2err;
+			cd.perr = perr;
+			cd.err = err;
+			cd.pfr = pfr;
+			cl[kc] = cd;
+			p.clhead[(size_t)sc * VDL2_CAND_CAP + kc] = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
+		} else
+			*ovf = 1u;
 		return;
 	}
 	const unsigned kk = atomicAdd(cntp, 1u);

@@ -157,6 +157,8 @@ struct K2Params {
 	unsigned *outc_total_redo;	/* running count of serial redos (host adapts the number of repair rounds) */
 	unsigned *fmask;	/* [16] bit per (stream, channel slot) that a repair round re-resolved or K2f redid serially in this push */
 	int full_round;		/* this repair round scans the failing channels completely (all classes, every instant): no regions, no verify */
+	int mini_round;		/* this repair round re-resolves with what the verify pass found and appended to the tables, nothing else: no scan, no
+				 * clusters (the resolver replays the few new candidates itself) */
 	int pay_final;		/* K2d: second pass, behind the repair rounds (only masked channels, records tagged final) */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */

@@ -63,7 +63,7 @@ class FrameT(C.Structure):
 class StatsT(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples_in", "dec_samples", "sync_evals", "triggers",
                                           "header_rejects", "bursts", "deferrals", "candidates", "serial_redos", "serial_samples", "overflowed",
-                                          "frames_dropped")]
+                                          "frames_dropped", "repairs")]
 
 
 class TimingT(C.Structure):
