@@ -29,3 +29,10 @@ for _ in range(N):
 rx.poll_raw(buf, 16384); rx.sync()
 dt = time.perf_counter() - t0
 print("per step: total %.3f ms, push call %.3f ms, poll_ready call %.3f ms" % (dt / N * 1e3, tp / N * 1e3, tq / N * 1e3))
+# the enqueue cost alone: the GPU idle before every push (nothing to wait for inside the call)
+tp = 0.0
+for _ in range(N):
+    rx.sync()
+    a = time.perf_counter(); rx.push_device(dbatch.data_ptr(), batch, 0); tp += time.perf_counter() - a
+    rx.poll_raw(buf, 16384)
+print("push call with an idle GPU (enqueue cost only): %.3f ms" % (tp / N * 1e3))

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -72,15 +73,21 @@ struct vdl2gpu {
 	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
 	unsigned k1_tbase[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* what they hold, per XCD (the same for every role and stream) */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
-	float2 *d_dec[2] = { nullptr, nullptr };
+	float2 *d_dec[3] = { nullptr, nullptr, nullptr };	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
+							 * reader, the back stage's tail, was ENQUEUED -- with two sets the channeliser had to wait for that tail */
 	StreamState *d_ss = nullptr;
 	ChanState *d_cs = nullptr;
 	ChanCfg *d_cfg = nullptr;
 	uint8_t *d_pn = nullptr;
-	vdl2gpu_burst_t *d_recs[2] = { nullptr, nullptr };	/* output rings, alternating per push */
-	unsigned *d_outc = nullptr;	/* [ring][2] = records written, dropped */
-	bool ring_busy[2] = { false, false };
-	uint64_t ring_push[2] = { 0, 0 };	/* which push filled the ring */
+	vdl2gpu_burst_t *d_recs[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* output rings, used in turn (push % 3): the calling thread waits for the
+									 * ring's previous push only three pushes later -- with two rings it waited for the tail of the push
+									 * before last in every call, and the GPU's front stream waited for the calling thread */
+	unsigned *d_outc = nullptr;	/* [2*ring + {0,1}] = records written, dropped; [8], [9] running totals: serial redos, repairs */
+	bool ring_busy[VDL2_NRING] = { false, false, false };
+	hipEvent_t ring_done[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* the end of the push's tail: its records and counters are on the host */
+	hipEvent_t in_read[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* its channeliser has read the caller's device buffer */
+	bool in_rec[VDL2_NRING] = { false, false, false };
+	uint64_t ring_push[VDL2_NRING] = { 0, 0, 0 };	/* which push filled the ring */
 	hipStream_t copy_stream = nullptr;
 	unsigned *d_ctl[2] = {nullptr, nullptr};	/* control words, see CTL_* in vdl2gpu_kernels.h */
 	size_t ctl_words = 0;
@@ -117,14 +124,14 @@ struct vdl2gpu {
 	hipStream_t tail_prev = nullptr;	/* the stream the previous push's tail ran on */
 	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
 	unsigned *d_fmask[2] = {nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
-	bool ring_spec[2] = {false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
+	bool ring_spec[VDL2_NRING] = {false, false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
 	int rounds_floor = 1;		/* one (resolver-only) repair round is always scheduled, see enqueue_back */
 	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked; halved
 					 * whenever a channel's candidate tables overflow */
 	size_t split_default = 0;
 	unsigned long long last_ovf_push = 0;
-	size_t ring_samples[2] = {0, 0};	/* samples (per stream) of the push that filled each output ring */
+	size_t ring_samples[VDL2_NRING] = {0, 0, 0};	/* samples (per stream) of the push that filled each output ring */
 	double cand_dens[4] = {0, 0, 0, 0};	/* candidates per input sample of the busiest channel, last four parts collected */
 	unsigned cand_dens_n = 0;
 	size_t split_unit = 32768;	/* parts are multiples of this (k1_fast takes whole superperiods; the RTL quirk needs whole blocks) */
@@ -145,12 +152,15 @@ struct vdl2gpu {
 	 * page-locked host memory, which the GPU itself fills at the end of the push -- k_export_records -- so that collecting a
 	 * push's bursts is an index sort and ONE copy per record, into the caller's buffer), bits 0-31 = index there */
 	std::vector<uint64_t> ready_idx;
-	vdl2gpu_burst_t *h_slab[2] = {nullptr, nullptr}, *d_slab[2] = {nullptr, nullptr};	/* the slabs and their device addresses */
+	vdl2gpu_burst_t *h_slab[VDL2_NSLAB] = {nullptr, nullptr, nullptr, nullptr}, *d_slab[VDL2_NSLAB] = {nullptr, nullptr, nullptr, nullptr};	/* the slabs (push % 4) and their device addresses:
+									 * one more than rings, so that a ring collected at the last moment -- by the call that is about to reuse it -- still lies
+									 * untouched in its slab while the caller polls once more, instead of being copied aside at once */
+	int ring_slab[VDL2_NRING] = {0, 0, 0};	/* the slab of the push that filled the ring */
 	unsigned slab_cap = 0;
 	size_t ready_pos = 0;
 	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
 	bool frames_on = false;
-	vdl2gpu_frame_t *d_frames[2] = {nullptr, nullptr};	/* byte buffers of compact entries */
+	vdl2gpu_frame_t *d_frames[VDL2_NRING] = {nullptr, nullptr, nullptr};	/* byte buffers of compact entries */
 	unsigned *d_k4tab = nullptr;	/* GF(256) and FCS tables of the block path */
 	unsigned *d_fcnt = nullptr;	/* [4*ring] frames written, [4*ring+1] dropped, [4*ring+2] bytes used */
 	unsigned frame_cap = 0;	/* bytes of a frame buffer (slots + arena) */
@@ -165,6 +175,8 @@ struct vdl2gpu {
 	unsigned pin_recs = 0;
 	bool failed = false;	/* a HIP call failed while work was being enqueued: device and host state no longer agree */
 	std::string err;
+	double hprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* VDL2GPU_HOST_PROF: seconds of the calling thread in the segments of push_impl (printed at destroy) */
+	bool hprof_on = false;
 	/* Environment knobs, read ONCE in create_impl (INTEGRATION.md lists them): push_impl never calls getenv.
 	 * The test handicaps (VDL2GPU_PRIM_DROP, VDL2GPU_SPLIT_SAMPLES, VDL2GPU_F_TEST_NOREGION) exist only in the
 	 * library built with -DVDL2GPU_TESTHOOKS (libvdl2gpu_test.so, which the tests load). */
@@ -194,7 +206,7 @@ struct vdl2gpu {
 		bool valid = false;
 		K2Params k2{};
 		int64_t J = 0;
-		int par = 0, ring = 0;
+		int par = 0, ring = 0, slab = 0;
 		bool staged = false, serial = false, two_streams = false;
 		unsigned tiles = 0;
 		size_t pt_index = 0;	/* its PushTiming in `pending` */
@@ -411,6 +423,11 @@ static size_t fmt_bytes(int fmt)
 
 extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 {
+	if (h && h->hprof_on && h->pushes)
+		fprintf(stderr, "vdl2gpu host profile, ms per push over %llu pushes: wait for the buffer of the push before last %.3f, channeliser enqueue %.3f, "
+				"collect the ring %.3f, front stage enqueue %.3f, spill %.3f, back stage enqueue %.3f\n", (unsigned long long)h->pushes,
+			h->hprof[0] / h->pushes * 1e3, h->hprof[1] / h->pushes * 1e3, h->hprof[2] / h->pushes * 1e3, h->hprof[3] / h->pushes * 1e3,
+			h->hprof[4] / h->pushes * 1e3, h->hprof[5] / h->pushes * 1e3);
 #ifdef K1F_PROF
 	{
 		static unsigned raw[K1F_PROF_SLOTS][12];
@@ -509,14 +526,17 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_k1_tickets);
 	(void)hipFree(h->d_dec[0]);
 	(void)hipFree(h->d_dec[1]);
+	(void)hipFree(h->d_dec[2]);
 	(void)hipFree(h->d_ss);
 	(void)hipFree(h->d_cs);
 	(void)hipFree(h->d_cfg);
 	(void)hipFree(h->d_pn);
 	(void)hipFree(h->d_recs[0]);
 	(void)hipFree(h->d_recs[1]);
+	(void)hipFree(h->d_recs[2]);
 	(void)hipFree(h->d_frames[0]);
 	(void)hipFree(h->d_frames[1]);
+	(void)hipFree(h->d_frames[2]);
 	(void)hipFree(h->d_fcnt);
 	(void)hipFree(h->d_k4tab);
 	(void)hipFree(h->d_outc);
@@ -527,6 +547,12 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 			(void)hipEventDestroy(h->k1_done[r]);
 		if (h->k2_done[r])
 			(void)hipEventDestroy(h->k2_done[r]);
+	}
+	for (int r = 0; r < VDL2_NRING; ++r) {
+		if (h->ring_done[r])
+			(void)hipEventDestroy(h->ring_done[r]);
+		if (h->in_read[r])
+			(void)hipEventDestroy(h->in_read[r]);
 	}
 	if (h->fstream) {
 		(void)hipStreamSynchronize(h->fstream);
@@ -588,7 +614,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_headtap_n);
 	if (h->h_pin)
 		(void)hipHostFree(h->h_pin);
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSLAB; ++r)
 		if (h->h_slab[r])
 			(void)hipHostFree(h->h_slab[r]);
 	if (h->h_pin_cnt)
@@ -626,6 +652,7 @@ static int create_impl(vdl2gpu_t *h)
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
 	HIPCHK(h, hipMalloc(&h->d_dec[0], dec_bytes));
 	HIPCHK(h, hipMalloc(&h->d_dec[1], dec_bytes));
+	HIPCHK(h, hipMalloc(&h->d_dec[2], dec_bytes));
 	HIPCHK(h, hipMemsetAsync(h->d_dec[0], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_lo_ext, (size_t)S * VDL2_CS * (L + 48) * sizeof(float2)));
@@ -635,11 +662,11 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_cs, (size_t)S * VDL2_CS * sizeof(ChanState)));
 	HIPCHK(h, hipMalloc(&h->d_cfg, (size_t)S * VDL2_CS * sizeof(ChanCfg)));
 	HIPCHK(h, hipMalloc(&h->d_pn, VDL2_PN_BITS));
-	for (int r = 0; r < 2; ++r) {
+	for (int r = 0; r < VDL2_NRING; ++r) {
 		HIPCHK(h, hipMalloc(&h->d_recs[r], (size_t)h->rec_cap * sizeof(vdl2gpu_burst_t)));
 	}
-	HIPCHK(h, hipMalloc(&h->d_outc, 8 * sizeof(unsigned)));
-	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 8 * sizeof(unsigned), h->stream));
+	HIPCHK(h, hipMalloc(&h->d_outc, 16 * sizeof(unsigned)));
+	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 16 * sizeof(unsigned), h->stream));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 	/* (HIP multiplexes its streams onto four hardware queues: a fifth stream shares one with another, and kernels that
 	 * were meant to run side by side then run one behind the other -- this handle makes exactly main, copy, resolver, payload;
@@ -647,6 +674,10 @@ static int create_impl(vdl2gpu_t *h)
 	for (int r = 0; r < 2; ++r) {
 		HIPCHK(h, hipEventCreateWithFlags(&h->k1_done[r], hipEventDisableTiming));
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
+	}
+	for (int r = 0; r < VDL2_NRING; ++r) {
+		HIPCHK(h, hipEventCreateWithFlags(&h->ring_done[r], hipEventDisableTiming));
+		HIPCHK(h, hipEventCreateWithFlags(&h->in_read[r], hipEventDisableTiming));
 	}
 	{
 		int prio_lo = 0, prio_hi = 0;
@@ -706,6 +737,7 @@ static int create_impl(vdl2gpu_t *h)
 	h->stage_every = std::max(1, env_int("VDL2GPU_STAGE_EVERY", h->stage_every));
 	h->k2d_grid = std::max(1, env_int("VDL2GPU_K2D_GRID", h->k2d_grid));
 	h->knob.no_k1_fast = getenv("VDL2GPU_NO_K1_FAST") != nullptr;
+	h->hprof_on = getenv("VDL2GPU_HOST_PROF") != nullptr;
 	h->knob.k2b_front = env_int("VDL2GPU_K2B_FRONT", 0) != 0;
 	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
@@ -736,26 +768,26 @@ static int create_impl(vdl2gpu_t *h)
 	h->quirk = (cfg.flags & VDL2GPU_F_RTL_QUIRK) ? 1 : 0;
 	h->pin_recs = std::min<unsigned>(h->rec_cap, 8192u);
 	HIPCHK(h, hipHostMalloc(&h->h_pin, (size_t)h->pin_recs * sizeof(vdl2gpu_burst_t), hipHostMallocDefault));
-	h->slab_cap = std::min<unsigned>(h->rec_cap, 65536u);	/* 138 MB of page-locked memory per ring at most; a push with more bursts takes the bounce buffer for the rest */
+	h->slab_cap = std::min<unsigned>(h->rec_cap, 16384u);	/* 34 MB of page-locked memory per slab at most (four slabs); a push with more bursts takes the bounce buffer for the rest */
 #ifdef VDL2GPU_TESTHOOKS
 	h->slab_cap = std::max(1u, std::min<unsigned>(h->slab_cap, (unsigned)env_int("VDL2GPU_SLAB_CAP", (int)h->slab_cap)));	/* (tests: force the bounce path) */
 #endif
-	for (int r = 0; r < 2; ++r) {
+	for (int r = 0; r < VDL2_NSLAB; ++r) {
 		HIPCHK(h, hipHostMalloc(&h->h_slab[r], (size_t)h->slab_cap * sizeof(vdl2gpu_burst_t), hipHostMallocMapped));
 		HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_slab[r], h->h_slab[r], 0));
 	}
-	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 64 * sizeof(unsigned), hipHostMallocMapped));
-	memset(h->h_pin_cnt, 0, 64 * sizeof(unsigned));
+	HIPCHK(h, hipHostMalloc(&h->h_pin_cnt, 32 * VDL2_NRING * sizeof(unsigned), hipHostMallocMapped));
+	memset(h->h_pin_cnt, 0, 32 * VDL2_NRING * sizeof(unsigned));
 	h->frames_on = (cfg.flags & VDL2GPU_F_FRAMES) != 0;
 	HIPCHK(h, hipMalloc(&h->d_k4tab, K4_TABW * sizeof(unsigned)));
 	hipLaunchKernelGGL(k4_tables, dim3(1), dim3(64), 0, h->stream, h->d_k4tab);
 	HIPCHK(h, hipGetLastError());
 	if (h->frames_on) {
 		h->frame_cap = h->rec_cap * K4_SLOT + (4u << 20);	/* bytes: a slot per record, and the arena (see K4Params) */
-		for (int r = 0; r < 2; ++r)
+		for (int r = 0; r < VDL2_NRING; ++r)
 			HIPCHK(h, hipMalloc((void **)&h->d_frames[r], (size_t)h->frame_cap));
-		HIPCHK(h, hipMalloc(&h->d_fcnt, 8 * sizeof(unsigned)));
-		HIPCHK(h, hipMemsetAsync(h->d_fcnt, 0, 8 * sizeof(unsigned), h->stream));
+		HIPCHK(h, hipMalloc(&h->d_fcnt, 4 * VDL2_NRING * sizeof(unsigned)));
+		HIPCHK(h, hipMemsetAsync(h->d_fcnt, 0, 4 * VDL2_NRING * sizeof(unsigned), h->stream));
 	}
 	HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pin_cnt, h->h_pin_cnt, 0));
 	HIPCHK(h, hipMalloc(&h->d_dbg, 64 * sizeof(unsigned long long)));
@@ -917,7 +949,7 @@ static int harvest_timing(vdl2gpu_t *h)
 
 static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking);
 static int enqueue_back(vdl2gpu_t *h);
-static void spill_slab(vdl2gpu_t *h, int ring);
+static void spill_slab(vdl2gpu_t *h, int slab);
 
 template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
 {
@@ -1168,8 +1200,8 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(pt.e[6], ts));
 	{
 		K3Params k3{};
-		k3.src = h->d_dec[par];
-		k3.dst = h->d_dec[par ^ 1];
+		k3.src = nullptr;	/* (the counters kernel copies nothing) */
+		k3.dst = nullptr;
 		k3.cap = h->cap;
 		k3.nbch = h->C;
 		k3.J = J;
@@ -1187,7 +1219,7 @@ static int enqueue_back(vdl2gpu_t *h)
 			KExportParams ke{};
 			ke.recs = h->d_recs[ring];
 			ke.count = h->d_outc + 2 * ring;
-			ke.dst = h->d_slab[ring];
+			ke.dst = h->d_slab[h->back.slab];
 			ke.cap = std::min(h->slab_cap, h->rec_cap);
 			hipLaunchKernelGGL(k_export_records, dim3((unsigned)h->n_cu), dim3(256), 0, ts, ke);
 			HIPCHK(h, hipGetLastError());
@@ -1199,7 +1231,7 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(pt.e[7], ts));
 	HIPCHK(h, hipEventRecord(h->k2_done[par], ts));
 	h->k2_rec[par] = true;
-	/* (the same event tells the host that this push's output ring is complete: ring == par) */
+	HIPCHK(h, hipEventRecord(h->ring_done[ring], ts));
 	return VDL2GPU_OK;
 }
 
@@ -1226,7 +1258,16 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (rc)
 			return rc;
 	}
-	const int ring = (int)(h->pushes & 1);	/* output ring of this push (collected below, once the GPU has been given work to do meanwhile) */
+	/* include/vdl2gpu.h: a device buffer must stay unchanged "until the second push after this one has been issued": that push
+	 * is this call, for the buffer of the push before last (with two output rings the wait for that push's ring implied it) */
+	auto hnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double hp_t = h->hprof_on ? hnow() : 0.0;
+	auto hp = [&](int k) { if (h->hprof_on) { const double t = hnow(); h->hprof[k] += t - hp_t; hp_t = t; } };
+	if (h->in_rec[(h->pushes + 1) % VDL2_NRING])
+		HIPCHK(h, hipEventSynchronize(h->in_read[(h->pushes + 1) % VDL2_NRING]));
+	hp(0);
+	const int slab = (int)(h->pushes % VDL2_NSLAB);	/* page-locked slab this push's records are exported to */
+	const int ring = (int)(h->pushes % VDL2_NRING);	/* output ring of this push (collected below, once the GPU has been given work to do meanwhile) */
 	const void *src = iq;
 	size_t stride = stream_stride_bytes;
 	bool staged_in = false;
@@ -1270,6 +1311,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	int64_t J = 0;
 	vdl2gpu_plan(h->total_in, nsamples, (unsigned)h->sdrclk, (unsigned)h->L, &k1.c0, &k1.no0, &k1.nf0, &J);
 	const int par = (int)(h->pushes & 1);
+	const int pset = (int)(h->pushes % 3);	/* plane set of this push */
 	k1.raw = src;
 	k1.stream_stride = stride;
 	k1.fmt = h->cfg.fmt;
@@ -1282,7 +1324,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	k1.N = (long long)nsamples;
 	k1.J = J;
 	k1.lo = h->d_lo;
-	k1.dec = h->d_dec[par];
+	k1.dec = h->d_dec[pset];
 	k1.cap = h->cap;
 	k1.ss = h->d_ss;
 	/* A short push (a live SDR block is 1376 frames per channel) is cheaper on the serial machine alone
@@ -1315,9 +1357,9 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	if (!two_streams && h->k2_rec[par ^ 1])	/* ... and its tail may have run on the payload stream */
 		HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par ^ 1], 0));
 	if (two_streams) {
-		/* the plane set and the table set of this parity were last used by the push before last */
-		if (h->k2_rec[par])
-			HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par], 0));
+		/* (the plane set this push's channeliser writes was last read by the push three back, whose end the front stage of
+		 * the push before this one has waited for; the TABLE set of this parity was last used by the push before last:
+		 * the wait for that is in front of k_push_init, behind the channeliser) */
 		if (h->k1_ev_rec && !h->last_two_streams)	/* the previous push's channeliser ran on the main stream */
 			HIPCHK(h, hipStreamWaitEvent(fs, h->k1_ev, 0));
 	}
@@ -1493,6 +1535,11 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[1], ks));
+	if (memkind != VDL2GPU_MEM_HOST) {	/* the caller's device buffer has been read: see the wait at the top */
+		HIPCHK(h, hipEventRecord(h->in_read[ring], ks));
+		h->in_rec[ring] = true;
+	} else
+		h->in_rec[ring] = false;
 	if (staged_in) {	/* (only the staging copy of the push after next waits for it) */
 		HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
 		h->k1_rec[par] = true;
@@ -1500,11 +1547,15 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	/* The output ring of this push: if the push that last used it (the one before last) has not been collected yet,
 	 * collect it now -- the GPU has the previous push's chain and this push's channeliser to work on while this thread
 	 * waits for that push's records and copies them. */
+	hp(1);	/* channeliser enqueued */
 	if (h->ring_busy[ring]) {
 		const int rch = harvest_ring(h, ring, true);
 		if (rch < 0)
 			return rch;
 	}
+	hp(2);	/* ring collected */
+	if (two_streams && h->k2_rec[par])	/* the table set of this parity, and the output ring, were last used by the push before last */
+		HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par], 0));
 	{
 		KInitParams ki{};
 		ki.ctl = h->d_ctl[par] + CTL_STAGE;
@@ -1521,7 +1572,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(pt.e[10], fs));
 	{
 		K2Params k2{};
-		k2.dec = h->d_dec[par];
+		k2.dec = h->d_dec[pset];
 		k2.cap = h->cap;
 		k2.nbch = h->C;
 		k2.nstreams = h->S;
@@ -1539,7 +1590,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.stage_cap = h->stage_cap;
 		k2.recs = h->d_recs[ring];
 		k2.outc = h->d_outc + 2 * ring;
-		k2.outc_total_redo = h->d_outc + 4;
+		k2.outc_total_redo = h->d_outc + 8;
 		k2.fmask = h->d_fmask[par];
 		k2.rec_cap = h->rec_cap;
 		k2.dec_base = dec_base;
@@ -1595,13 +1646,11 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			 * shorter) go in front of where the next push's output will start, in the other plane set -- a fixed amount,
 			 * so that it does not wait for the resolver to say how much is still unconsumed (3 MB per stream).  Behind
 			 * this push's scan rather than in front of the next push's channeliser: there the copy sat for 100 us
-			 * behind the cluster kernel, which has the higher priority.  The other plane set was last read by the
-			 * previous push's back stage. */
-			if (two_streams && h->k2_rec[par ^ 1])
-				HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par ^ 1], 0));
+			 * behind the cluster kernel, which has the higher priority.  The next plane set (of three) was last read by the
+			 * back stage of the push before last, which this push's front stage waited for before its scan. */
 			K3Params k3{};
-			k3.src = h->d_dec[par];
-			k3.dst = h->d_dec[par ^ 1];
+			k3.src = h->d_dec[pset];
+			k3.dst = h->d_dec[(pset + 1) % 3];
 			k3.cap = h->cap;
 			k3.nbch = h->C;
 			k3.J = J;
@@ -1619,6 +1668,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		h->back.J = J;
 		h->back.par = par;
 		h->back.ring = ring;
+		h->back.slab = slab;
 		h->back.staged = staged;
 		h->back.serial = serial;
 		h->back.two_streams = two_streams;
@@ -1626,15 +1676,19 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		h->back.pt_index = h->pending.size();
 	}
 	h->pending.push_back(pt);
-	spill_slab(h, ring);	/* (the ring was collected above: whatever of it the caller has not taken yet) */
+	hp(3);	/* rest of the front stage enqueued */
+	spill_slab(h, slab);	/* (this push's export will write the slab of the push four back: whatever of it the caller has not taken yet moves aside) */
+	hp(4);
 	{
 		const int rcb = enqueue_back(h);
 		if (rcb)
 			return rcb;
 	}
+	hp(5);	/* back stage enqueued */
 	h->last_J = J;
 	h->last_two_streams = two_streams;
 	h->ring_busy[ring] = true;
+	h->ring_slab[ring] = slab;
 	h->ring_push[ring] = h->pushes;
 	h->ring_samples[ring] = nsamples;
 	h->total_in += nsamples;
@@ -1653,19 +1707,34 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 	return harvest_timing(h);
 }
 
+/* A record in a slab holds what k_export_records sent: the header and the rows the burst uses; everything behind is zero by
+ * definition (burst_payload clears a record before it fills it) and is not read from the slab. */
+static inline void rec_copy(vdl2gpu_burst_t *dst, const vdl2gpu_burst_t *src, bool from_slab)
+{
+	if (!from_slab) {
+		*dst = *src;
+		return;
+	}
+	const int nb = std::min(std::max(src->nbrow, 0), (int)VDL2GPU_MAXROWS);
+	const size_t used = offsetof(vdl2gpu_burst_t, data) + (size_t)nb * VDL2GPU_ROWLEN;
+	memcpy(dst, src, used);
+	memset(reinterpret_cast<char *>(dst) + used, 0, sizeof *dst - used);
+}
+
 static inline vdl2gpu_burst_t *rec_of(vdl2gpu_t *h, uint64_t hd)
 {
-	const unsigned src = (unsigned)(hd >> 32) & 3u;
+	const unsigned src = (unsigned)(hd >> 32) & 7u;
 	return (src ? h->h_slab[src - 1] : h->ready.data()) + (uint32_t)hd;
 }
 
 /* A ring's slab is about to be written again (its push's back stage is being enqueued): whatever of it has not been
  * handed out yet moves to the pageable queue.  A consumer that polls after every push never gets here with anything. */
-static void spill_slab(vdl2gpu_t *h, int ring)
+static void spill_slab(vdl2gpu_t *h, int slab)
 {
 	for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
-		if (((h->ready_idx[i] >> 32) & 3u) == (unsigned)(1 + ring)) {
-			h->ready.push_back(h->h_slab[ring][(uint32_t)h->ready_idx[i]]);
+		if (((h->ready_idx[i] >> 32) & 7u) == (unsigned)(1 + slab)) {
+			h->ready.emplace_back();
+			rec_copy(&h->ready.back(), &h->h_slab[slab][(uint32_t)h->ready_idx[i]], true);
 			h->ready_idx[i] = (uint64_t)(h->ready.size() - 1);
 		}
 }
@@ -1678,7 +1747,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	if (!h->ring_busy[ring])
 		return 0;
 	if (!blocking) {
-		const hipError_t q = hipEventQuery(h->k2_done[ring]);
+		const hipError_t q = hipEventQuery(h->ring_done[ring]);
 		if (q == hipErrorNotReady)
 			return 1;
 		if (q != hipSuccess) {
@@ -1686,7 +1755,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			return VDL2GPU_EHIP;
 		}
 	}
-	HIPCHK(h, hipEventSynchronize(h->k2_done[ring]));
+	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
 	const unsigned c0 = h->h_pin_cnt[32 * ring], c1 = h->h_pin_cnt[32 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
@@ -1746,8 +1815,10 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 											 * (so the storage never exceeds 2 x the unread records + one push: <= (8 + 1) x max_bursts records) */
 			std::vector<vdl2gpu_burst_t> keep;
 			keep.reserve(h->ready_idx.size() - h->ready_pos);
-			for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
-				keep.push_back(*rec_of(h, h->ready_idx[i]));
+			for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i) {
+				keep.emplace_back();
+				rec_copy(&keep.back(), rec_of(h, h->ready_idx[i]), ((h->ready_idx[i] >> 32) & 7u) != 0);
+			}
 			h->ready.swap(keep);
 			h->ready_idx.resize(h->ready.size());
 			for (size_t i = 0; i < h->ready_idx.size(); ++i)
@@ -1785,7 +1856,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			h->ready_idx.push_back(handle);
 		};
 		for (unsigned i = 0; i < ns; ++i)
-			take(h->h_slab[ring][i], ((uint64_t)(1 + ring) << 32) | i);
+			take(h->h_slab[h->ring_slab[ring]][i], ((uint64_t)(1 + h->ring_slab[ring]) << 32) | i);
 		for (size_t i = old; i < h->ready.size(); ++i)
 			take(h->ready[i], (uint64_t)i);
 		std::sort(h->ready_idx.begin() + iold, h->ready_idx.end(), [h](uint64_t x, uint64_t y) {
@@ -1889,10 +1960,13 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 static int harvest_all(vdl2gpu_t *h, bool blocking)
 {
 	/* oldest push first */
-	const int first = (h->ring_busy[0] && h->ring_busy[1] && h->ring_push[1] < h->ring_push[0]) ? 1 : 0;
-	for (int k = 0; k < 2; ++k) {
-		const int ring = first ^ k;
-		const int rc = harvest_ring(h, ring, blocking);
+	int order[VDL2_NRING], n = 0;
+	for (int r = 0; r < VDL2_NRING; ++r)
+		if (h->ring_busy[r])
+			order[n++] = r;
+	std::sort(order, order + n, [&](int a, int b) { return h->ring_push[a] < h->ring_push[b]; });
+	for (int k = 0; k < n; ++k) {
+		const int rc = harvest_ring(h, order[k], blocking);
 		if (rc < 0)
 			return rc;
 		if (rc == 1)
@@ -1904,8 +1978,10 @@ static int harvest_all(vdl2gpu_t *h, bool blocking)
 static int hand_out(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	const int n = std::min<int>(max, (int)(h->ready_idx.size() - h->ready_pos));
-	for (int i = 0; i < n; ++i)
-		out[i] = *rec_of(h, h->ready_idx[h->ready_pos + i]);
+	for (int i = 0; i < n; ++i) {
+		const uint64_t hd = h->ready_idx[h->ready_pos + i];
+		rec_copy(out + i, rec_of(h, hd), ((hd >> 32) & 7u) != 0);
+	}
 	h->ready_pos += (size_t)n;
 	return n;
 }
@@ -2117,7 +2193,7 @@ extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *ou
 		return rc;
 	StreamState ss;
 	HIPCHK(h, hipMemcpy(&ss, h->d_ss + stream, sizeof ss, hipMemcpyDeviceToHost));
-	const int par = (int)((h->pushes - 1) & 1);
+	const int par = (int)((h->pushes - 1) % 3);
 	const int64_t n = std::min<int64_t>(ss.last_J, max_complex);
 	if (n <= 0)
 		return 0;

@@ -71,8 +71,8 @@ __global__ void k3_rebase(K3Params p)
 	if (s == 0) {
 		p.host_cnt[0] = p.outc[2 * p.ring];
 		p.host_cnt[1] = p.outc[2 * p.ring + 1];
-		p.host_cnt[2] = p.outc[4];
-		p.host_cnt[3] = p.outc[5];
+		p.host_cnt[2] = p.outc[8];	/* running totals: serial redos, repairs */
+		p.host_cnt[3] = p.outc[9];
 		for (int i = 0; i < 3; ++i)
 			p.host_cnt[4 + i] = p.fcnt ? p.fcnt[i] : 0u;
 		for (int i = 0; i < 16; ++i)
@@ -95,17 +95,25 @@ struct KExportParams {
 	vdl2gpu_burst_t *dst;	/* device address of the ring's slab */
 	unsigned cap;		/* records the slab holds */
 };
+/* Only what a record uses travels: the header and the rows of the burst (a record is eight rows of 255 bytes; a typical
+ * burst fills one or two) -- a sixth of the PCIe traffic and of what the collecting thread reads; the host zero-fills the
+ * rest when it hands the record out (vdl2gpu.hip: rec_copy).  One wavefront per record. */
 __global__ __launch_bounds__(256)
 void k_export_records(KExportParams p)
 {
-	static_assert(sizeof(vdl2gpu_burst_t) % 8 == 0, "records are copied as 8-byte words");
+	static_assert(sizeof(vdl2gpu_burst_t) % 8 == 0 && offsetof(vdl2gpu_burst_t, data) % 8 == 0, "records are copied as 8-byte words");
 	unsigned n = *p.count;
 	n = n < p.cap ? n : p.cap;
-	const size_t words = (size_t)n * (sizeof(vdl2gpu_burst_t) / 8);
-	const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recs);
-	unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.dst);
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
-		dst[i] = src[i];
+	const unsigned lane = threadIdx.x & 63u;
+	for (unsigned r = blockIdx.x * 4u + (threadIdx.x >> 6); r < n; r += gridDim.x * 4u) {
+		int nb = p.recs[r].nbrow;
+		nb = nb < 0 ? 0 : (nb > VDL2GPU_MAXROWS ? VDL2GPU_MAXROWS : nb);
+		const unsigned words = (unsigned)((offsetof(vdl2gpu_burst_t, data) + (size_t)nb * VDL2GPU_ROWLEN + 7) / 8);
+		const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recs + r);
+		unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.dst + r);
+		for (unsigned i = lane; i < words; i += 64u)
+			dst[i] = src[i];
+	}
 }
 
 /* test hook: both device forms of atan2f; a disagreement between them comes back as NaN */
