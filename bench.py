@@ -348,7 +348,7 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     t_hi = total_tiles - 1
     ncheck = min(nstr, check_streams)
     exp, osec = oracle_streams(variants[:ncheck], fmt, rate, fos, total_tiles, order)
-    nb, bad = 0, 0
+    nb, bad, first_bad = 0, 0, None
     for sidx in range(ncheck):
         e = exp[sidx]
         e = e[(e["trig_dec"] // tile_dec) < t_hi]
@@ -357,6 +357,16 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
         nb += len(g)
         if canon(g) != canon(e):
             bad += 1
+            if first_bad is None:       # what differs, for whoever reads the line: records only one side has, the first few by (channel, instant)
+                gk = {(int(r["chn"]), int(r["trig_dec"])): r.tobytes() for r in g}
+                ek = {(int(r["chn"]), int(r["trig_dec"])): r.tobytes() for r in e}
+                first_bad = {"stream": sidx, "gpu_only": sorted(set(gk) - set(ek))[:6], "oracle_only": sorted(set(ek) - set(gk))[:6],
+                             "different": sorted(k for k in set(gk) & set(ek) if gk[k] != ek[k])[:6],
+                             "counts": [len(gk), len(ek)], "tile_dec": tile_dec}
+                for k in first_bad["different"][:1]:
+                    a, b = g[(g["chn"] == k[0]) & (g["trig_dec"] == k[1])][0], e[(e["chn"] == k[0]) & (e["trig_dec"] == k[1])][0]
+                    first_bad["fields"] = {n: ([int(x) for x in np.flatnonzero(np.asarray(a[n]) != np.asarray(b[n]))[:8]] if np.ndim(a[n]) else [int(a[n]), int(b[n])])
+                                           for n in g.dtype.names if not np.array_equal(a[n], b[n])}
     equal = bad == 0 and nb > 0
     value = nstr * batch * steps / dt / 1e6
     dec_total = st["dec_samples"] * 8 * nstr
@@ -366,7 +376,8 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
             "first_push_ms": first_ms, "max_push_ms": max(slow),
             "serial_samples_frac": st["serial_samples"] / max(1, dec_total), "repairs": st["repairs"], "serial_redos": st["serial_redos"], "overflowed": st["overflowed"],
             "parity": {"equal": equal, "bursts_checked": nb, "streams_checked": ncheck, "tiles_checked": t_hi, "oracle_seconds": osec,
-                       "what": "every burst from the first sample of the run on, vs the oracle over the same stream"}}
+                       "what": "every burst from the first sample of the run on, vs the oracle over the same stream",
+                       **({"mismatch": first_bad} if first_bad else {})}}
 
 
 def live_leg(local=0, nblocks=300, paced=True, nslots=8, bursts_per_s=8.0, seed=77):

@@ -73,7 +73,7 @@ struct vdl2gpu {
 	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
 	unsigned k1_tbase[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* what they hold, per XCD (the same for every role and stream) */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
-	float2 *d_dec[3] = { nullptr, nullptr, nullptr };	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
+	float2 *d_dec[VDL2_NSET] = { nullptr, nullptr, nullptr };	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
 							 * reader, the back stage's tail, was ENQUEUED -- with two sets the channeliser had to wait for that tail */
 	StreamState *d_ss = nullptr;
 	ChanState *d_cs = nullptr;
@@ -89,22 +89,22 @@ struct vdl2gpu {
 	bool in_rec[VDL2_NRING] = { false, false, false };
 	uint64_t ring_push[VDL2_NRING] = { 0, 0, 0 };	/* which push filled the ring */
 	hipStream_t copy_stream = nullptr;
-	unsigned *d_ctl[2] = {nullptr, nullptr};	/* control words, see CTL_* in vdl2gpu_kernels.h */
+	unsigned *d_ctl[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* control words, see CTL_* in vdl2gpu_kernels.h */
 	size_t ctl_words = 0;
 	unsigned rec_cap = 0;
-	Cand *d_cands[2] = {nullptr, nullptr};
-	Cluster *d_clusters[2] = {nullptr, nullptr};
-	int2 *d_clhead[2] = {nullptr, nullptr};
-	BurstDesc *d_stage[2] = {nullptr, nullptr};
-	unsigned *d_sel_list[2] = {nullptr, nullptr};
-	int2 *d_regs[2] = {nullptr, nullptr};
-	Seg *d_segs[2] = {nullptr, nullptr};
-	int *d_fail[2] = {nullptr, nullptr};
-	int *d_redo[2] = {nullptr, nullptr};
-	ChanState *d_cs_out[2] = {nullptr, nullptr};
-	int *d_skey[2] = {nullptr, nullptr};
-	unsigned short *d_sidx[2] = {nullptr, nullptr}, *d_prim[2] = {nullptr, nullptr};
-	int *d_seeds[2] = {nullptr, nullptr};
+	Cand *d_cands[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	Cluster *d_clusters[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	int2 *d_clhead[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	BurstDesc *d_stage[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	unsigned *d_sel_list[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	int2 *d_regs[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	Seg *d_segs[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	int *d_fail[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	int *d_redo[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	ChanState *d_cs_out[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	int *d_skey[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	unsigned short *d_sidx[VDL2_NSET] = {nullptr, nullptr, nullptr}, *d_prim[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	int *d_seeds[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
@@ -116,14 +116,15 @@ struct vdl2gpu {
 	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown): an event record between two kernels of the chain
 					 * costs ~3 us, so only every stage_every-th push carries them (the sums are scaled up in harvest) */
 	int stage_every = 4;
-	hipEvent_t k1_done[2] = {nullptr, nullptr}, k2_done[2] = {nullptr, nullptr};	/* per plane set */
-	bool k2_rec[2] = {false, false};
+	hipEvent_t k1_done[2] = {nullptr, nullptr};	/* per staging buffer (host input) */
+	hipEvent_t k2_done[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* per table set: the end of the tail of the push that used it */
+	bool k2_rec[VDL2_NSET] = {false, false, false};
 	hipStream_t pay_stream = nullptr;	/* K2d beside the verify pass; then the push's TAIL (repair rounds, commit, export, counters: see enqueue_back) */
 	hipEvent_t verify_done = nullptr, k2f_done = nullptr;	/* main -> tail: the verify pass has run; tail -> main: the channel states are committed */
 	bool k2f_rec = false;
 	hipStream_t tail_prev = nullptr;	/* the stream the previous push's tail ran on */
 	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
-	unsigned *d_fmask[2] = {nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
+	unsigned *d_fmask[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
 	bool ring_spec[VDL2_NRING] = {false, false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
 	int rounds_floor = 1;		/* one (resolver-only) repair round is always scheduled, see enqueue_back */
@@ -212,7 +213,7 @@ struct vdl2gpu {
 		size_t pt_index = 0;	/* its PushTiming in `pending` */
 	} back;
 	hipStream_t fstream = nullptr;
-	hipEvent_t f_done[2] = {nullptr, nullptr};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
+	hipEvent_t f_done[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
 	hipEvent_t k1_ev = nullptr;	/* channeliser + carry copy of the latest push that kept to the main stream */
 	hipEvent_t f_tail = nullptr;	/* the end of the latest front stage on fstream (carry copy included) */
 	bool k1_ev_rec = false, last_two_streams = false;
@@ -425,9 +426,9 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 {
 	if (h && h->hprof_on && h->pushes)
 		fprintf(stderr, "vdl2gpu host profile, ms per push over %llu pushes: wait for the buffer of the push before last %.3f, channeliser enqueue %.3f, "
-				"collect the ring %.3f, front stage enqueue %.3f, spill %.3f, back stage enqueue %.3f\n", (unsigned long long)h->pushes,
+				"collect the ring %.3f, front stage enqueue %.3f, spill %.3f, back stage enqueue %.3f; waiting for rings' events (push and poll calls) %.3f\n", (unsigned long long)h->pushes,
 			h->hprof[0] / h->pushes * 1e3, h->hprof[1] / h->pushes * 1e3, h->hprof[2] / h->pushes * 1e3, h->hprof[3] / h->pushes * 1e3,
-			h->hprof[4] / h->pushes * 1e3, h->hprof[5] / h->pushes * 1e3);
+			h->hprof[4] / h->pushes * 1e3, h->hprof[5] / h->pushes * 1e3, h->hprof[6] / h->pushes * 1e3);
 #ifdef K1F_PROF
 	{
 		static unsigned raw[K1F_PROF_SLOTS][12];
@@ -542,12 +543,12 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_outc);
 	if (h->copy_stream)
 		(void)hipStreamDestroy(h->copy_stream);
-	for (int r = 0; r < 2; ++r) {
+	for (int r = 0; r < 2; ++r)
 		if (h->k1_done[r])
 			(void)hipEventDestroy(h->k1_done[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
 		if (h->k2_done[r])
 			(void)hipEventDestroy(h->k2_done[r]);
-	}
 	for (int r = 0; r < VDL2_NRING; ++r) {
 		if (h->ring_done[r])
 			(void)hipEventDestroy(h->ring_done[r]);
@@ -558,7 +559,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipStreamSynchronize(h->fstream);
 		(void)hipStreamDestroy(h->fstream);
 	}
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		if (h->f_done[r])
 			(void)hipEventDestroy(h->f_done[r]);
 	if (h->k1_ev)
@@ -577,38 +578,38 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipEventDestroy(h->verify_done);
 	if (h->k2f_done)
 		(void)hipEventDestroy(h->k2f_done);
-	(void)hipFree(h->d_fmask[0]);
-	(void)hipFree(h->d_fmask[1]);
-	(void)hipFree(h->d_ctl[0]);
-	(void)hipFree(h->d_ctl[1]);
-	(void)hipFree(h->d_cands[0]);
-	(void)hipFree(h->d_cands[1]);
-	(void)hipFree(h->d_clusters[0]);
-	(void)hipFree(h->d_clusters[1]);
-	(void)hipFree(h->d_clhead[0]);
-	(void)hipFree(h->d_clhead[1]);
-	(void)hipFree(h->d_stage[0]);
-	(void)hipFree(h->d_stage[1]);
-	(void)hipFree(h->d_sel_list[0]);
-	(void)hipFree(h->d_sel_list[1]);
-	(void)hipFree(h->d_regs[0]);
-	(void)hipFree(h->d_regs[1]);
-	(void)hipFree(h->d_segs[0]);
-	(void)hipFree(h->d_segs[1]);
-	(void)hipFree(h->d_fail[0]);
-	(void)hipFree(h->d_fail[1]);
-	(void)hipFree(h->d_redo[0]);
-	(void)hipFree(h->d_redo[1]);
-	(void)hipFree(h->d_cs_out[0]);
-	(void)hipFree(h->d_cs_out[1]);
-	(void)hipFree(h->d_skey[0]);
-	(void)hipFree(h->d_skey[1]);
-	(void)hipFree(h->d_sidx[0]);
-	(void)hipFree(h->d_sidx[1]);
-	(void)hipFree(h->d_prim[0]);
-	(void)hipFree(h->d_prim[1]);
-	(void)hipFree(h->d_seeds[0]);
-	(void)hipFree(h->d_seeds[1]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_fmask[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_ctl[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_cands[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_clusters[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_clhead[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_stage[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_sel_list[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_regs[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_segs[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_fail[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_redo[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_cs_out[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_skey[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_sidx[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_prim[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_seeds[r]);
 	(void)hipFree(h->d_dbg);
 	(void)hipFree(h->d_headtap);
 	(void)hipFree(h->d_headtap_n);
@@ -653,7 +654,8 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipMalloc(&h->d_dec[0], dec_bytes));
 	HIPCHK(h, hipMalloc(&h->d_dec[1], dec_bytes));
 	HIPCHK(h, hipMalloc(&h->d_dec[2], dec_bytes));
-	HIPCHK(h, hipMemsetAsync(h->d_dec[0], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
+	for (int r = 0; r < VDL2_NSET; ++r)
+		HIPCHK(h, hipMemsetAsync(h->d_dec[r], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
 	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_lo_ext, (size_t)S * VDL2_CS * (L + 48) * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_k1_tickets, (size_t)S * 21 * 8 * sizeof(unsigned)));
@@ -671,10 +673,10 @@ static int create_impl(vdl2gpu_t *h)
 	/* (HIP multiplexes its streams onto four hardware queues: a fifth stream shares one with another, and kernels that
 	 * were meant to run side by side then run one behind the other -- this handle makes exactly main, copy, resolver, payload;
 	 * host input adds one for its copies, which may share a queue with the record read-back) */
-	for (int r = 0; r < 2; ++r) {
+	for (int r = 0; r < 2; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->k1_done[r], hipEventDisableTiming));
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
-	}
 	for (int r = 0; r < VDL2_NRING; ++r) {
 		HIPCHK(h, hipEventCreateWithFlags(&h->ring_done[r], hipEventDisableTiming));
 		HIPCHK(h, hipEventCreateWithFlags(&h->in_read[r], hipEventDisableTiming));
@@ -684,7 +686,7 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
 		HIPCHK(h, hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, prio_lo));	/* the back stage (main stream, high priority) is the shorter one: it goes first */
 	}
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->f_done[r], hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k1_ev, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->f_tail, hipEventDisableTiming));
@@ -693,43 +695,43 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipEventCreateWithFlags(&h->pay_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->verify_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2f_done, hipEventDisableTiming));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_fmask[r], 16 * sizeof(unsigned)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMemsetAsync(h->d_fmask[r], 0, 16 * sizeof(unsigned), h->stream));
 	h->ctl_words = CTL_CAND0 + 8 * (size_t)S * VDL2_CS;
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_ctl[r], h->ctl_words * sizeof(unsigned)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMemsetAsync(h->d_ctl[r], 0, h->ctl_words * sizeof(unsigned), h->stream));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_cands[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cand)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_clusters[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(Cluster)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_clhead[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int2)));
 	h->stage_cap = (unsigned)S * VDL2_CS * VDL2_CAND_CAP * VDL2_CL_MAXB + 65536u;	/* static slots + dynamic tail */
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_stage[r], (size_t)h->stage_cap * sizeof(BurstDesc)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_sel_list[r], (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_regs[r], (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_segs[r], (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_fail[r], (size_t)S * VDL2_CS * sizeof(int)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_redo[r], (size_t)S * VDL2_CS * sizeof(int)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_cs_out[r], (size_t)S * VDL2_CS * sizeof(ChanState)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_skey[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_sidx[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_prim[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
@@ -1122,8 +1124,8 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(h->verify_done, h->stream));
 		HIPCHK(h, hipStreamWaitEvent(ts, h->verify_done, 0));
 	}
-	if (h->tail_prev && h->tail_prev != ts && h->k2_rec[par ^ 1])	/* tails follow each other (running totals, StreamState) */
-		HIPCHK(h, hipStreamWaitEvent(ts, h->k2_done[par ^ 1], 0));
+	if (h->tail_prev && h->tail_prev != ts && h->k2_rec[(par + VDL2_NSET - 1) % VDL2_NSET])	/* tails follow each other (running totals, StreamState) */
+		HIPCHK(h, hipStreamWaitEvent(ts, h->k2_done[(par + VDL2_NSET - 1) % VDL2_NSET], 0));
 	h->tail_prev = ts;
 	if (!h->full_scan && !serial) {
 		/* Repair rounds.  The verify pass has appended what it found to the failing channel's table (candidates without
@@ -1310,8 +1312,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	K1Params k1{};
 	int64_t J = 0;
 	vdl2gpu_plan(h->total_in, nsamples, (unsigned)h->sdrclk, (unsigned)h->L, &k1.c0, &k1.no0, &k1.nf0, &J);
-	const int par = (int)(h->pushes & 1);
-	const int pset = (int)(h->pushes % 3);	/* plane set of this push */
+	const int par = (int)(h->pushes % VDL2_NSET);	/* table set, plane set and output ring of this push */
+	const int pset = par;
 	k1.raw = src;
 	k1.stream_stride = stride;
 	k1.fmt = h->cfg.fmt;
@@ -1319,7 +1321,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	k1.sdrclk = h->sdrclk;
 	k1.L = h->L;
 	k1.maxwin = h->maxwin;
-	k1.parity = par;
+	k1.parity = (int)(h->pushes & 1);	/* the carried partial window is double-buffered in StreamState.acc: read [parity], written [parity ^ 1] */
 	k1.quirk = h->quirk;
 	k1.N = (long long)nsamples;
 	k1.J = J;
@@ -1354,12 +1356,13 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	hipStream_t ks = fs;
 	if (!two_streams && h->last_two_streams)	/* the previous push's channeliser state and carry were written on the front stream */
 		HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
-	if (!two_streams && h->k2_rec[par ^ 1])	/* ... and its tail may have run on the payload stream */
-		HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par ^ 1], 0));
+	if (!two_streams && h->k2_rec[(par + VDL2_NSET - 1) % VDL2_NSET])	/* ... and its tail may have run on the payload stream */
+		HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[(par + VDL2_NSET - 1) % VDL2_NSET], 0));
 	if (two_streams) {
-		/* (the plane set this push's channeliser writes was last read by the push three back, whose end the front stage of
-		 * the push before this one has waited for; the TABLE set of this parity was last used by the push before last:
-		 * the wait for that is in front of k_push_init, behind the channeliser) */
+		/* the plane set this push's channeliser writes, the table set and the output ring were last used by the push three
+		 * back: by its tail (the payload decode of a repaired channel reads the planes to the very end of it) */
+		if (h->k2_rec[par])
+			HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par], 0));
 		if (h->k1_ev_rec && !h->last_two_streams)	/* the previous push's channeliser ran on the main stream */
 			HIPCHK(h, hipStreamWaitEvent(fs, h->k1_ev, 0));
 	}
@@ -1541,8 +1544,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	} else
 		h->in_rec[ring] = false;
 	if (staged_in) {	/* (only the staging copy of the push after next waits for it) */
-		HIPCHK(h, hipEventRecord(h->k1_done[par], ks));
-		h->k1_rec[par] = true;
+		HIPCHK(h, hipEventRecord(h->k1_done[stg], ks));
+		h->k1_rec[stg] = true;
 	}
 	/* The output ring of this push: if the push that last used it (the one before last) has not been collected yet,
 	 * collect it now -- the GPU has the previous push's chain and this push's channeliser to work on while this thread
@@ -1554,8 +1557,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			return rch;
 	}
 	hp(2);	/* ring collected */
-	if (two_streams && h->k2_rec[par])	/* the table set of this parity, and the output ring, were last used by the push before last */
-		HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[par], 0));
 	{
 		KInitParams ki{};
 		ki.ctl = h->d_ctl[par] + CTL_STAGE;
@@ -1650,7 +1651,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			 * back stage of the push before last, which this push's front stage waited for before its scan. */
 			K3Params k3{};
 			k3.src = h->d_dec[pset];
-			k3.dst = h->d_dec[(pset + 1) % 3];
+			k3.dst = h->d_dec[(pset + 1) % VDL2_NSET];
 			k3.cap = h->cap;
 			k3.nbch = h->C;
 			k3.J = J;
@@ -1755,7 +1756,10 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			return VDL2GPU_EHIP;
 		}
 	}
+	const double hq0 = h->hprof_on ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
 	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
+	if (h->hprof_on)
+		h->hprof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - hq0;
 	const unsigned c0 = h->h_pin_cnt[32 * ring], c1 = h->h_pin_cnt[32 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
@@ -2193,7 +2197,7 @@ extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *ou
 		return rc;
 	StreamState ss;
 	HIPCHK(h, hipMemcpy(&ss, h->d_ss + stream, sizeof ss, hipMemcpyDeviceToHost));
-	const int par = (int)((h->pushes - 1) % 3);
+	const int par = (int)((h->pushes - 1) % VDL2_NSET);
 	const int64_t n = std::min<int64_t>(ss.last_J, max_complex);
 	if (n <= 0)
 		return 0;
@@ -2264,11 +2268,11 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) & 1] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) % VDL2_NSET] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, VDL2_CAND_CAP);
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_cands[(h->pushes - 1) & 1] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_cands[(h->pushes - 1) % VDL2_NSET] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -2281,7 +2285,7 @@ extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
-	HIPCHK(h, hipMemcpy(out, h->d_fail[(h->pushes - 1) & 1], (size_t)h->S * VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(out, h->d_fail[(h->pushes - 1) % VDL2_NSET], (size_t)h->S * VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
 	return h->S * VDL2_CS;
 }
 
@@ -2294,10 +2298,10 @@ extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, in
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) & 1] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) % VDL2_NSET] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, (unsigned)std::min(max_segs, VDL2_SEG_CAP));
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_segs[(h->pushes - 1) & 1] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_segs[(h->pushes - 1) % VDL2_NSET] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 

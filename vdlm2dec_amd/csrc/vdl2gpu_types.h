@@ -9,7 +9,8 @@
 #include "../../include/vdl2gpu.h"
 
 #define VDL2_CS 8		/* channel planes per stream */
-#define VDL2_NRING 3		/* output rings (records, frames, counters), used in turn */
+#define VDL2_NSET 3		/* plane sets, table sets and output rings, used in turn (push % 3): three pushes in the pipeline, the oldest in its tail */
+#define VDL2_NRING VDL2_NSET	/* output rings (records, frames, counters) */
 #define VDL2_NSLAB 4		/* page-locked slabs the records are exported to, used in turn */
 #define VDL2_HIST 160		/* frames of history kept: 17-tap FIR + 17 symbols x 8 + slack */
 #define VDL2_NPH 68		/* NBPH*D8DWN, vdlm2.h:54-55 */
