@@ -167,7 +167,8 @@ void vdl2gpu_destroy(vdl2gpu_t *h);
  * Buffer lifetime: a VDL2GPU_MEM_HOST buffer may be reused as soon as the call returns (it has been copied).
  * A VDL2GPU_MEM_DEVICE buffer is read in place by the channeliser, asynchronously: it must stay valid and
  * unchanged until the second push after this one has been issued, or until vdl2gpu_sync() / vdl2gpu_poll()
- * returns -- whichever comes first (at most two pushes are in flight).
+ * returns -- whichever comes first (three pushes can be in the pipeline; the call that issues the second push after this one
+ * waits until this one's channeliser has read the buffer).
  * Errors are sticky: after a call has returned VDL2GPU_EHIP the handle only accepts vdl2gpu_destroy(). */
 int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind);
 
@@ -195,8 +196,8 @@ int vdl2gpu_sync(vdl2gpu_t *h);
  * (1.2 GB with the default max_bursts = 65536 and a consumer that never polls; a few MB with one that does). */
 int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Same, but never waits: hands out only the bursts of pushes the GPU has already finished.  Lets
- * a caller keep the next push running while it consumes the previous one (two pushes can be in
- * flight; a third push first collects the oldest). */
+ * a caller keep the next pushes running while it consumes the earlier ones (three pushes can be in the pipeline;
+ * a fourth first collects the oldest). */
 int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Number of bursts a poll would currently return (implies vdl2gpu_sync). */
 int vdl2gpu_pending(vdl2gpu_t *h);

@@ -31,7 +31,7 @@ def resources():
 
 def test_every_kernel_is_listed(resources):
     names = " ".join(resources)
-    for k in ("k1_fast", "k1_pp", "k1_channelise", "k2a_probe", "k2a_region", "k2a_verify", "k2s_sort", "k2b_clusters",
+    for k in ("k1_fast", "k1_pp", "k1_channelise", "k2a_probe", "k2a_region", "k2a_verify", "k2s_sort", "k2s_merge", "k2b_clusters",
               "k2c_resolve", "k2f_commit", "k2d_payload", "k3_carry", "k3_rebase", "k_export_records", "k4_frames"):
         assert k in names, k
 

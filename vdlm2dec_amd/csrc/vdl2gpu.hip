@@ -1647,8 +1647,12 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			 * shorter) go in front of where the next push's output will start, in the other plane set -- a fixed amount,
 			 * so that it does not wait for the resolver to say how much is still unconsumed (3 MB per stream).  Behind
 			 * this push's scan rather than in front of the next push's channeliser: there the copy sat for 100 us
-			 * behind the cluster kernel, which has the higher priority.  The next plane set (of three) was last read by the
-			 * back stage of the push before last, which this push's front stage waited for before its scan. */
+			 * behind the cluster kernel, which has the higher priority. */
+			/* the next plane set's head was last read by the tail of the push two back (a repaired channel's payloads are
+			 * decoded late: a burst at the very start of that push lies in its head); the next push's channeliser, right
+			 * behind this copy, waits for that same tail anyway */
+			if (two_streams && h->k2_rec[(par + 1) % VDL2_NSET])
+				HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[(par + 1) % VDL2_NSET], 0));
 			K3Params k3{};
 			k3.src = h->d_dec[pset];
 			k3.dst = h->d_dec[(pset + 1) % VDL2_NSET];
