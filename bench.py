@@ -784,7 +784,7 @@ def main():
                                    "how": "4 pushes after the timed region, each synchronised before the next: no other kernel on the GPU"},
                          "note": "live: HIP events around the one full-rate launch of each push inside the timed region (every fourth push "
                                  "carries them), where it runs beside the PREVIOUS push's back stage -- its cluster kernel or verify pass, "
-                                 "both of which fill the GPU by themselves: two pushes are in flight (DESIGN.md 4, Host side), so the "
+                                 "both of which fill the GPU by themselves: three pushes are in the pipeline (DESIGN.md 4, Host side), so the "
                                  "kernel takes longer here than alone (`alone`) while the step as a whole got shorter; algorithmic bytes = sample "
                                  "bytes x samples, read once for all 8 channels; the kernel also writes the 84 kS/s planes (2.7 B per "
                                  "input sample at 2 MS/s), which is intermediate traffic, not algorithmic (SURVEY.md 8d); `traffic` is "
@@ -793,7 +793,7 @@ def main():
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
                            "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms, "demod_chain": k2_ms,
                            "note": "kernel intervals from HIP events; the front stage of one push (channeliser, scan) runs beside the back "
-                                   "stage of the one before (clusters, resolver, verify): the intervals overlap and are longer than the "
+                                   "stage of the one before (clusters, resolver, verify) and the tail of the one before that: the intervals overlap and are longer than the "
                                    "kernels alone -- their sum (demod_chain + k1) exceeds ms_per_step, it is not a critical path"},
             "stats": {k: st[k] for k in ("sync_evals", "triggers", "header_rejects", "bursts", "deferrals",
                                            "candidates", "repairs", "serial_redos", "serial_samples", "overflowed")},
