@@ -289,7 +289,8 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     batch = ntiles * TILE
     tile_dec = TILE * 21 // (rate // 4000)
     NBUF = 2
-    nvar = min(16, ntiles) if nstr == 1 else 1        # different recordings in turn (see tile_order): no recording twice in a push
+    nvar = min(16 if nstr == 1 else 4, ntiles)        # different recordings in turn (see tile_order): no recording twice in a push of one stream (several
+                                                          # streams: four each -- 128 recordings would take the leg's synthesis past a minute)
     flat = make_variants([seed0 + g + 1000 * v for g in range(nstr) for v in range(nvar)], fmt, rate, fos, bursts_per_s)
     variants = [flat[g * nvar:(g + 1) * nvar] for g in range(nstr)]
     order = lambda i: tile_order(i, ntiles, NBUF, nvar)
@@ -487,7 +488,7 @@ def main():
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
     ap.add_argument("--rate", type=int, default=0, help="override the config's SDRINRATE (5000000 / 6000000)")
     ap.add_argument("--streams", type=int, default=0, help="override the config's streams per GPU")
-    ap.add_argument("--recordings", type=int, default=0, help="different synthetic recordings per stream, pushed in turn (0 = 4 for one stream, 2 otherwise)")
+    ap.add_argument("--recordings", type=int, default=0, help="different synthetic recordings per stream, pushed in turn (0 = 16 for one stream, 4 otherwise)")
     ap.add_argument("--frames", action="store_true",
                     help="also run the block path (RS, HDLC, FCS: SURVEY 8f-1) on every push's bursts and collect the frames")
     ap.add_argument("--no-cpu", action="store_true")
@@ -538,7 +539,7 @@ def main():
     # only, one per ~100 channel-seconds, came back in every tile, each time behind the repair of the one before), and the three
     # device buffers pushed in turn start one recording apart; what a push reads was last touched two pushes ago.
     NBUF = 3
-    nvar = max(1, args.recordings or (min(16, ntiles) if nstr == 1 else 2))
+    nvar = max(1, args.recordings or min(16 if nstr == 1 else 4, ntiles))
     flat = make_variants([1234 + g + 1000 * v for g in mine for v in range(nvar)], args.fmt, rate, fos)
     variants = [flat[k * nvar:(k + 1) * nvar] for k in range(len(mine))]
     tiles_np = [per[0] for per in variants]
