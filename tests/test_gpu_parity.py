@@ -601,6 +601,20 @@ def test_busy_channels_stay_on_the_parallel_path(built, oracle, bps):
     assert r["value"] > 20_000          # MS/s; the measured figure is in the bench line (configs.config2_busy_*)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("nstr,ntiles,bps,steps", [(2, 8, 8.0, 5), (1, 4, 30.0, 7), (1, 16, 2.0, 4)])
+def test_three_pushes_in_the_pipeline_equal_the_oracle(built, oracle, nstr, ntiles, bps, steps):
+    """Device-resident pushes back to back, bursts taken as they become ready (bench.py's leg: what scripts/soak_pipeline.py
+    draws at random): the front stage of one push beside the back stage of the one before and the tail of the one before
+    that, on three plane / table sets, three output rings and four slabs -- every burst from the first sample on equals the
+    oracle's, whatever the load and the push length, and nothing is left to the serial redo."""
+    import bench
+    from vdlm2dec_amd import synth as sy
+    r = bench.run_leg("pipeline", "test", 0, 2_000_000, sy.DEFAULT_FO_8CH, "cs16", nstr, ntiles, bps, steps=steps, warmup=2, seed0=4321)
+    assert r["parity"]["equal"] and r["parity"]["bursts_checked"] > 1000, r["parity"]
+    assert r["serial_redos"] == 0 and r["overflowed"] == 0, r
+
+
 def test_paced_live_ring_equals_the_oracle(built, oracle):
     """BASELINE configs[4] through bench.py's own leg: 32768-sample cu8 blocks (one RTL-SDR USB transfer) written in place
     into the 8-slot page-locked ring every 16.384 ms, bursts collected block by block -- the bursts are the oracle's, and

@@ -10,15 +10,16 @@
  * (S = 1: every sample, both parities; S = 2: one parity only -- n-8l and n-2 keep n's parity.)
  *
  * Three uses, all the same tile routine on K2A_TS instants staged in LDS:
- *   k2a_probe   every sample >= pos of each channel, but ONLY the sub-phase the channel's
- *               detector is in at the start of the push.  Finds every burst (a burst fires the
+ *   k2a_probe   every second sample of the push, carry included, in ONE fixed class (sub-phase 0, the parity of the first
+ *               carried frame with history).  Finds every burst (a burst fires the
  *               detector in all 8 (sub-phase, parity) classes within a few samples) and is
  *               already the complete table for that sub-phase.
  *   k2a_region  the other three sub-phases, only in the neighbourhood of the probe's hits.
  *   k2a_verify  after the resolver: every stretch the real chain idled through in a class the
  *               probe did not cover is scanned in exactly that class; a hit means the tables
- *               missed an event and the channel is redone serially (K2f).  This is what makes
- *               the shortcut exact instead of heuristic.
+ *               missed an event: it is listed, and the repair round re-resolves the channel with it
+ *               (what still fails is redone serially by K2f).  This is what makes the shortcut
+ *               exact instead of heuristic.
  * VDL2GPU_F_FULLSCAN makes the probe cover all four sub-phases (no regions/verify needed).
  */
 #ifndef K2A_THREADS
@@ -677,6 +678,8 @@ void k2r_regions(K2Params p)
 		return;
 	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
 		return;		/* repair round: only channels whose verify pass found something */
+	if (p.round > 0 && !p.full_round)
+		return;		/* (launched in round 0, and in a complete round for the reset below) */
 	if (p.full_round) {
 		/* the channel's tables are made again from nothing, by a scan of every class at every instant */
 		if (tid == 0) {
@@ -733,7 +736,7 @@ void k2r_regions(K2Params p)
 			/* more regions than the list holds: the surplus is dropped -- regions are a cost decision, what a
 			 * missing one would have found the verify pass finds (and a repair round scans the channel completely) */
 			p.ctl[CTL_NREG0 + sc] = (unsigned)(n > VDL2_REG_CAP ? VDL2_REG_CAP : n);
-			p.ctl[CTL_NSEED0 + sc] = 0;	/* the seed list now collects what K2a-verify finds */
+			p.ctl[CTL_NSEED0 + sc] = 0;
 		}
 	}
 }
@@ -750,9 +753,7 @@ void k2a_region(K2Params p)
 	if (p.test_noregion && p.round == 0)
 		return;
 #endif
-	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
-		return;
-	const unsigned nreg = p.ctl[CTL_NREG0 + sc];
+	const unsigned nreg = p.ctl[CTL_NREG0 + sc];	/* (round 0 only: a repair round re-resolves or re-scans completely, it scans no regions) */
 	if (blockIdx.x >= nreg)	/* nothing for this workgroup (64 channels x 128 workgroups, 40 regions each): not even the tables */
 		return;
 	const long long dec_base = p.dec_base;
