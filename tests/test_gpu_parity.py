@@ -651,3 +651,31 @@ def test_records_beyond_the_slab_and_uncollected_records_survive(built, oracle, 
     assert _gpu_keys(got) == want
     ends = [(b.end_dec, b.stream, b.chn) for b in got]
     assert ends == sorted(ends)                              # hand-out order: (end, stream, channel)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_long_and_short_pushes_in_any_order(built, oracle, seed):
+    """Pushes long enough for the parallel path (three stages on three streams, their tails on the payload stream) and pushes
+    short enough for the serial one (everything on the main stream), in random order, bursts taken as they become ready:
+    a short push follows the long one's tail, a long one the short one's commit -- the bursts are the oracle's whatever
+    the order (the transitions between the two paths are event waits nothing else exercises)."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    rng = np.random.default_rng(seed)
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 9_000_000, seed=500 + seed, bursts_per_s=25.0, info_max=120)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    assert len(want) >= 200
+    got = []
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1 << 20) as rx:
+        pos, n = 0, spec.nsamples
+        while pos < n:
+            k = int(rng.choice([700_000, 1_000_000, 40_000, 8_192, 131_072, 1 << 20]))     # >= 97 524 samples is the parallel path
+            k = min(k, n - pos)
+            rx.push(raw[2 * pos:2 * (pos + k)])
+            pos += k
+            if rng.integers(0, 3):
+                got += rx.poll_ready()
+        got += rx.poll()
+        st = rx.stats()
+    assert _gpu_keys(got) == want
+    assert st["overflowed"] == 0
