@@ -1,10 +1,12 @@
 /*
  * vdl2gpu.hip -- host side of libvdl2gpu.so: the C ABI of include/vdl2gpu.h.
  *
- * One handle = one MI355X, two pushes in flight.  vdl2gpu_push() enqueues
- *   front stage (fstream):  [H2D copy] -> K1 channelise -> K2a probe / regions -> K2s sort -> carry for the next push
- *   back stage  (stream):   K2b clusters -> K2c resolve -> K2a verify (K2d payload beside it) -> commit -> export -> counters
- * and returns; the front stage of one push runs beside the back stage of the one before (see vdl2gpu::Back).
+ * One handle = one MI355X, three pushes in the pipeline.  vdl2gpu_push() enqueues
+ *   front stage (fstream):     [H2D copy] -> K1 channelise -> K2a probe / regions -> K2s sort -> carry for the next push
+ *   back stage  (stream):      K2b clusters -> K2c resolve -> K2a verify (K2d payload beside it, on the payload stream)
+ *   tail        (pay_stream):  repair round (merge, resolve, verify) -> commit -> re-resolved payloads -> export -> counters
+ * and returns; the front stage of one push runs beside the back stage of the one before and the tail of the one before that
+ * (see vdl2gpu::Back and enqueue_back); plane sets, table sets and output rings exist three times, the slabs four times.
  * vdl2gpu_poll() synchronises and hands burst records back in stream-time order.  There is no CPU fallback: without a HIP device
  * vdl2gpu_create() fails with VDL2GPU_ENODEV.
  *
@@ -192,16 +194,17 @@ struct vdl2gpu {
 		int k1_dbg = 0;			/* VDL2GPU_K1_DBG */
 		int k1_nsub = 0;		/* VDL2GPU_K1_NSUB */
 	} knob;
-	/* A push's work is two stages on two streams, and two pushes are in flight at once -- the tables (candidates, clusters,
-	 * descriptors, control words ...) exist twice:
-	 *   FRONT (fstream): carry copy, channeliser, scan of one class + regions, sort, clusters -- wide kernels that need
+	/* A push's work is three stages on three streams, and three pushes are in the pipeline at once -- the planes, the tables
+	 * (candidates, clusters, descriptors, control words ...) and the output rings exist three times:
+	 *   FRONT (fstream): channeliser, scan of one class + regions, sort, carry copy -- wide kernels that need
 	 *                    nothing of the previous push's RESULT: the scan starts at the first carried frame and in a fixed
 	 *                    class (what the resolver consumes is decided by where it stands, not by where the scan began),
 	 *                    the stream-time base is the host's arithmetic, the carry is a fixed 49152 frames;
-	 *   BACK  (stream):  resolver, verify pass (+ payload decode beside it), repair rounds, commit, block path, counters --
-	 *                    needs the channel state the previous push's BACK committed, so backs run one behind the other.
-	 * FRONT(N+1) runs beside BACK(N): the back's one-workgroup-per-channel kernels (resolver, commit) no longer leave the
-	 * GPU idle, and the channeliser's planes are still in the Infinity Cache when the scan reads them.  Pushes too short
+	 *   BACK  (stream):  clusters, resolver, verify pass (+ payload decode beside it): the resolver needs the channel state
+	 *                    the previous push's tail committed (k2f_done);
+	 *   TAIL  (pay_stream): repair round, commit, block path, export, counters (enqueue_back).
+	 * FRONT(N+1) runs beside BACK(N) and TAIL(N-1): the one-workgroup-per-channel kernels (resolver, commit ...) no longer
+	 * leave the GPU idle, and the channeliser's planes are still in the Infinity Cache when the scan reads them.  Pushes too short
 	 * for the parallel path (the live path: one SDR block) keep everything on the one stream: a hop costs ~30 us. */
 	struct Back {
 		bool valid = false;
@@ -1350,9 +1353,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	pt.fast = false;
 	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
 	const bool staged = pt.staged;
-	/* The channeliser goes on the MAIN stream, in front of the previous push's back half (see vdl2gpu::Back): in stream
-	 * order it follows that push's cluster kernel and runs beside its resolver.  The plane set it writes was released by
-	 * the push before last, earlier on the same stream. */
+	/* The channeliser opens the front stage (fstream; the main stream for a push that takes the serial path). */
 	hipStream_t ks = fs;
 	if (!two_streams && h->last_two_streams)	/* the previous push's channeliser state and carry were written on the front stream */
 		HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
@@ -1547,9 +1548,9 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(h->k1_done[stg], ks));
 		h->k1_rec[stg] = true;
 	}
-	/* The output ring of this push: if the push that last used it (the one before last) has not been collected yet,
-	 * collect it now -- the GPU has the previous push's chain and this push's channeliser to work on while this thread
-	 * waits for that push's records and copies them. */
+	/* The output ring of this push: if the push that last used it (three back) has not been collected yet, collect it now --
+	 * the GPU has the two pushes in between and this push's channeliser to work on while this thread waits for that push's
+	 * tail. */
 	hp(1);	/* channeliser enqueued */
 	if (h->ring_busy[ring]) {
 		const int rch = harvest_ring(h, ring, true);

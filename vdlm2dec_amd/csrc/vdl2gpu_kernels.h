@@ -7,8 +7,8 @@
  *   lo       per (stream, channel) local-oscillator table, L = SDRINRATE/25000
  *            complex floats, computed on the host with libm (d8psk.c:353-357).
  *   dec      84 kS/s channel planes: plane (stream, channel) = `cap` float2,
- *            two ping-pong sets.  K1 appends, K2* read, K3 moves the
- *            unconsumed tail right-aligned below frame VDL2_CARRY_FRAMES of the other
+ *            three sets used in turn.  K1 writes from frame VDL2_CARRY_FRAMES on, K2* read, K3 copies
+ *            the last VDL2_CARRY_FRAMES frames below frame VDL2_CARRY_FRAMES of the next
  *            set, where the next push's K1 output starts.  Frame 0 of a plane is stream
  *            time `dec_base`; VDL2_HIST frames of history are always kept.
  *   state    StreamState (decimator carry) + ChanState (sync detector state:
@@ -19,23 +19,28 @@
  *            under all 8 timing hypotheses (K2a) + what happens after each (K2b).
  *   bursts   staging pool (K2b) and output ring (K2c/K2d) of vdl2gpu_burst_t.
  *
- * Pipeline of one push.  Two stages on two streams, the tables below exist twice: the FRONT stage of push N+1 runs beside
- * the BACK stage of push N (host side: vdl2gpu.hip, struct Back).
+ * Pipeline of one push.  Three stages on three streams, planes / tables / output rings exist three times: the FRONT stage
+ * of push N+1 runs beside the BACK stage of push N and the TAIL of push N-1 (host side: vdl2gpu.hip, enqueue_back).
  *  front
  *   K1   channelise       time-parallel over the whole GPU, the only full-rate kernel (vdl2gpu_k1.h)
  *   K2a  sync scan        probe (ONE fixed detector class over the whole push, carry included), regions (all classes
  *                         around what it found).  Screens that prove where the detector cannot fire; exact FIR /
  *                         atan2f / fit only for what survives them; only the first firing of a run is listed (vdl2gpu_scan.h)
  *   K2s  sort             candidates by time, primaries marked (vdl2gpu_resolve.h)
- *   K3   carry            the last 49152 frames of every plane to the other plane set (a fixed amount: depends on nothing
+ *   K3   carry            the last 49152 frames of every plane to the next plane set (a fixed amount: depends on nothing
  *                         the resolver decides)
  *  back
  *   K2b  burst clusters   one wavefront per primary candidate: exact state machine (vdl2gpu_machine.h)
  *                         from the trigger until the detector is history-free again
  *   K2c  resolve          one workgroup per VDL channel: walks the real chain of bursts through the tables
- *   K2a  verify           every stretch the chain idled through, in the class it idled in, unless the probe covered it
+ *   K2a  verify           every stretch the chain idled through, in the class it idled in, unless the probe covered it;
+ *                         what it finds joins the table (a candidate without a cluster)
  *   K2d  payload          symbols, slicer, descrambler, de-interleaver of the bursts on the chain (beside the verify pass)
- *   K2f  commit           (or serial redo of a channel whose verify pass failed)
+ *  tail
+ *   K2s' K2c K2a          repair round, always scheduled: merge what the verify pass listed into the sorted table,
+ *                         resolve the failing channels again, verify what changed (all exit at once when nothing failed)
+ *   K2f  commit           (or serial redo of a channel whose verify pass still fails)
+ *   K2d  payload          of the channels a round re-resolved
  *   K4   block path       optional: RS / HDLC / FCS per burst (vdl2gpu_blocks.h)
  *   K3   export, rebase   records into page-locked host memory by the GPU's own hand; counters to the host
  *
