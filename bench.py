@@ -489,6 +489,7 @@ def main():
     ap.add_argument("--rate", type=int, default=0, help="override the config's SDRINRATE (5000000 / 6000000)")
     ap.add_argument("--streams", type=int, default=0, help="override the config's streams per GPU")
     ap.add_argument("--recordings", type=int, default=0, help="different synthetic recordings per stream, pushed in turn (0 = 16 for one stream, 4 otherwise)")
+    ap.add_argument("--bursts-per-s", type=float, default=4.0, help="offered load per channel (development: the headline is 4)")
     ap.add_argument("--frames", action="store_true",
                     help="also run the block path (RS, HDLC, FCS: SURVEY 8f-1) on every push's bursts and collect the frames")
     ap.add_argument("--no-cpu", action="store_true")
@@ -540,7 +541,7 @@ def main():
     # device buffers pushed in turn start one recording apart; what a push reads was last touched two pushes ago.
     NBUF = 3
     nvar = max(1, args.recordings or min(16 if nstr == 1 else 4, ntiles))
-    flat = make_variants([1234 + g + 1000 * v for g in mine for v in range(nvar)], args.fmt, rate, fos)
+    flat = make_variants([1234 + g + 1000 * v for g in mine for v in range(nvar)], args.fmt, rate, fos, args.bursts_per_s)
     variants = [flat[k * nvar:(k + 1) * nvar] for k in range(len(mine))]
     tiles_np = [per[0] for per in variants]
     order = lambda i: tile_order(i, ntiles, NBUF, nvar)
@@ -765,8 +766,8 @@ def main():
             "value": value if parity_ok else None, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"] + ("" if not (args.rate or args.streams or args.tiles) else
-                                                       f" [overridden: {nstr} stream(s)/GPU, {rate / 1e6:g} MS/s, {ntiles} tiles]"),
+            "config": {"workload": cfg["workload"] + ("" if not (args.rate or args.streams or args.tiles or args.bursts_per_s != 4.0) else
+                                                       f" [overridden: {nstr} stream(s)/GPU, {rate / 1e6:g} MS/s, {ntiles} tiles, {args.bursts_per_s:g} bursts/s/channel offered]"),
                        "fmt": args.fmt, "samples_per_step": batch * nstr, "air_time_s_per_step": batch / rate,
                        "channels": 8, "streams_per_gpu": nstr, "streams_total": nstreams_total, "sdrinrate": rate,
                        "bursts_per_step": total_bursts / max(1, args.steps * world),
