@@ -679,3 +679,35 @@ def test_long_and_short_pushes_in_any_order(built, oracle, seed):
         st = rx.stats()
     assert _gpu_keys(got) == want
     assert st["overflowed"] == 0
+
+
+def test_a_device_buffer_is_free_once_two_more_pushes_have_been_issued(built, oracle):
+    """include/vdl2gpu.h: a VDL2GPU_MEM_DEVICE buffer is read in place, asynchronously, and must stay unchanged "until the
+    second push after this one has been issued".  Three buffers in turn, each overwritten with noise the moment the call that
+    issues the second push after it has returned -- with three pushes in the pipeline that call is what waits for the
+    buffer's channeliser (an event behind every channeliser)."""
+    import torch
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 8_000_000, seed=777, bursts_per_s=20.0, info_max=100)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    assert len(want) >= 150
+    n, blk = spec.nsamples, 1_000_000
+    bufs = [torch.empty(2 * blk, dtype=torch.int16, device="cuda") for _ in range(3)]
+    noise = torch.randint(-3000, 3000, (2 * blk,), dtype=torch.int16, device="cuda")
+    side = torch.cuda.Stream()      # the overwrites must not be ordered behind the library's work by accident
+    got = []
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=blk) as rx:
+        for i, s0 in enumerate(range(0, n, blk)):
+            k = min(blk, n - s0)
+            b = bufs[i % 3]
+            b[:2 * k].copy_(torch.from_numpy(raw[2 * s0:2 * (s0 + k)]).cuda())
+            torch.cuda.synchronize()
+            rx.push_device(b.data_ptr(), k, 0)
+            if i >= 2:              # the push two back: its buffer is ours again
+                with torch.cuda.stream(side):
+                    bufs[(i - 2) % 3].copy_(noise)
+                side.synchronize()
+            got += rx.poll_ready()
+        got += rx.poll()
+    assert _gpu_keys(got) == want
