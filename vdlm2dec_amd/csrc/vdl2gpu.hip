@@ -107,6 +107,8 @@ struct vdl2gpu {
 	int *d_skey[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	unsigned short *d_sidx[VDL2_NSET] = {nullptr, nullptr, nullptr}, *d_prim[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	int *d_seeds[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	unsigned *d_wcount[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* items in the scan workgroups' private areas, per scan of the push */
+	K2aItem *d_items[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* what passed the scans' first screen (k2x_second works it off) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
@@ -613,6 +615,10 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipFree(h->d_prim[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_seeds[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_items[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_wcount[r]);
 	(void)hipFree(h->d_dbg);
 	(void)hipFree(h->d_headtap);
 	(void)hipFree(h->d_headtap_n);
@@ -702,7 +708,7 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_fmask[r], 16 * sizeof(unsigned)));
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMemsetAsync(h->d_fmask[r], 0, 16 * sizeof(unsigned), h->stream));
-	h->ctl_words = CTL_CAND0 + 8 * (size_t)S * VDL2_CS;
+	h->ctl_words = VDL2_CTL_WORDS((size_t)S * VDL2_CS);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_ctl[r], h->ctl_words * sizeof(unsigned)));
 	for (int r = 0; r < VDL2_NSET; ++r)
@@ -736,6 +742,12 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_prim[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
+	for (int r = 0; r < VDL2_NSET; ++r)
+		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
+	for (int r = 0; r < VDL2_NSET; ++r) {
+		HIPCHK(h, hipMalloc(&h->d_wcount[r], (size_t)VDL2_SURV_SLOTS * S * VDL2_CS * VDL2_MAXWG * sizeof(unsigned)));
+		HIPCHK(h, hipMemsetAsync(h->d_wcount[r], 0, (size_t)VDL2_SURV_SLOTS * S * VDL2_CS * VDL2_MAXWG * sizeof(unsigned), h->stream));
+	}
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
@@ -956,6 +968,29 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking);
 static int enqueue_back(vdl2gpu_t *h);
 static void spill_slab(vdl2gpu_t *h, int slab);
 
+/* A scan kernel and, right behind it on the same stream, the sparse stages over what passed its first screen (k2x_second). */
+enum { SCAN_PROBE, SCAN_REGION, SCAN_VERIFY };
+static void launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st, int slot, int mode, int skip, unsigned tiles_per_wg)
+{
+	K2Params q = k2;
+	/* a scan workgroup's private part of the item list: one and a half times what its tiles yield at the first screen's 2.7 %
+	 * (28 per tile and class; the region scan's tiles are sync words: far more pass) plus a sync word's worth; what it does
+	 * not hold goes to the common area */
+	grid.x = std::min<unsigned>(grid.x, VDL2_MAXWG);
+	const unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u) + 128u + 255u) / 256u * 256u;
+	q.surv_nwg = (int)grid.x;
+	q.surv_pch = (int)std::max(256u, std::min(want, VDL2_ITEM_PRIV / grid.x / 256u * 256u));
+	q.surv_slot = slot;
+	q.surv_mode = mode;
+	q.surv_skip = skip;
+	switch (which) {
+	case SCAN_PROBE: hipLaunchKernelGGL(k2a_probe, grid, dim3(K2A_THREADS), 0, st, q); break;
+	case SCAN_REGION: hipLaunchKernelGGL(k2a_region, grid, dim3(K2A_THREADS), 0, st, q); break;
+	default: hipLaunchKernelGGL(k2a_verify, grid, dim3(K2A_THREADS), 0, st, q); break;
+	}
+	hipLaunchKernelGGL(k2x_second, dim3(K2X_GRID, grid.y, grid.z), dim3(K2X_NT), 0, st, q);
+}
+
 template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
 {
 	hipLaunchKernelGGL(k1_channelise<FMT>, grid, dim3(K1_THREADS), smem, st, p);
@@ -1113,7 +1148,7 @@ static int enqueue_back(vdl2gpu_t *h)
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[12], h->stream));
 	if (!serial)
-		hipLaunchKernelGGL(k2a_verify, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, h->stream, k2);
+		launch_scan(SCAN_VERIFY, k2, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), h->stream, VDL2_SURV_VERIFY, 1, 0, K2A_VRUN);
 	HIPCHK(h, hipGetLastError());
 	/* ---- the TAIL: everything behind the verify pass -- repair rounds, commit, the payloads a round re-resolved, block path,
 	 * export, counters: a chain of one-workgroup-per-channel kernels and a PCIe copy, 0.1 ms while nothing fails and 0.3 ms when
@@ -1155,14 +1190,14 @@ static int enqueue_back(vdl2gpu_t *h)
 				const unsigned want = tiles;
 				unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
 				per = per > want ? want : per;
-				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, ts, k2r);
+				launch_scan(SCAN_PROBE, k2r, dim3(per, (unsigned)h->C, (unsigned)h->S), ts, VDL2_SURV_FULL, 0, 0, 4 * ((want + per - 1) / per));
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
 			} else {
 				hipLaunchKernelGGL(k2s_merge, gch, dim3(K2M_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
-				hipLaunchKernelGGL(k2a_verify, vgrid, dim3(K2A_THREADS), 0, ts, k2r);
+				launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
 			}
 		}
 		HIPCHK(h, hipGetLastError());
@@ -1568,7 +1603,9 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		ki.nsc = h->S * VDL2_CS;
 		ki.fmask = h->d_fmask[par];
 		ki.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
-		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, fs, ki);
+		ki.wcount = h->d_wcount[par];
+		ki.wcount_words = VDL2_SURV_SLOTS * h->S * VDL2_CS * VDL2_MAXWG;
+		hipLaunchKernelGGL(k_push_init, dim3((unsigned)std::min(64, 1 + ki.wcount_words / 16384)), dim3(1024), 0, fs, ki);
 	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[10], fs));
@@ -1619,6 +1656,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.sidx = h->d_sidx[par];
 		k2.prim = h->d_prim[par];
 		k2.seeds = h->d_seeds[par];
+		k2.items = h->d_items[par];
+		k2.wcount = h->d_wcount[par];
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
 		if (!serial) {
@@ -1627,10 +1666,11 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				const unsigned want = h->full_scan ? tiles : tiles / 2 + 1;
 				unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * h->S - 1) / (h->C * h->S));
 				per = per < 1 ? 1 : (per > want ? want : per);
-				hipLaunchKernelGGL(k2a_probe, dim3(per, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, fs, k2);
+				per = std::min<unsigned>(per, VDL2_MAXWG);
+				launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : 2, 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
 			}
 			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs, k2);
-			hipLaunchKernelGGL(k2a_region, dim3(128, (unsigned)h->C, (unsigned)h->S), dim3(K2A_THREADS), 0, fs, k2);
+			launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_REGION, 0, 1, 2);
 			HIPCHK(h, hipGetLastError());
 		}
 		if (!serial)

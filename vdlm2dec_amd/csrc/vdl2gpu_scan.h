@@ -28,14 +28,30 @@
 #ifndef K2A_TS
 #define K2A_TS 1024		/* evaluation instants per tile */
 #endif
+#ifndef K2A_PREFETCH
+#define K2A_PREFETCH 0		/* 1: a workgroup loads its next tile's samples into registers behind the current tile's filter pass (twenty
+				 * registers through the screens: the kernels then need more than the 80 that six wavefronts per SIMD leave) */
+#endif
+#ifndef K2A_FLUSH_ATTR
+#define K2A_FLUSH_ATTR
+#endif
+#ifndef K2A_WPE
+#define K2A_WPE 6		/* wavefronts per SIMD the scan kernels are compiled for */
+#endif
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
-#define K2A_WL2 24		/* survivors of both screens whose exact phases fit in LDS at once */
-#define K2A_DEF 320		/* survivors collected before they are worked off; must hold one more tile pass (K2A_WL) */
-#ifndef K2A_WL
-#define K2A_WL 192		/* screened-in evaluations per tile and sub-phase; more than that and the tile is done in pieces */
-#endif
+#define K2X_WL 20		/* k2x_second: survivors whose exact phases are in LDS at once (1020 phases: four passes of the workgroup) */
+#define K2X_NT 256		/* ... and the items a workgroup takes */
+#define K2X_CV 64		/* of which the fit screen of so many runs in ONE wavefront (11 % get that far) */
+#define VDL2_ITEM_CAP 196608	/* evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
+				 * payload symbols alike: 39 000 of a 33 s class-scan).  The list is in two parts: a private area per scan
+				 * workgroup (p.surv_pch items each, filled through an LDS counter; their counts in p.wcount) and behind
+				 * them a common area for what a workgroup's own area does not hold (one device-scope atomic per wavefront
+				 * and pass: slow, rare) */
+#define VDL2_ITEM_PRIV 131072	/* ... of which private areas at most */
+#define VDL2_MAXWG 512		/* scan workgroups per channel at most (private areas of >= 256 items) */
+#define K2X_GRID (VDL2_ITEM_CAP / K2X_NT)
 #define VDL2_REG_CAP 4096	/* probe-hit regions per channel per push (noise alone seeds ~100 per million 84 kS/s samples) */
 #ifndef VDL2_REG_PAD
 #define VDL2_REG_PAD 40
@@ -57,23 +73,32 @@ struct K2aDef {			/* an evaluation that needs the exact fit */
 	int lo, hi;		/* verify: only hits in [lo, hi) count */
 };
 
+/* An evaluation that passed the first screen, as the scan hands it to k2x_second: five 16-byte words -- {n, r | odd << 8, lo, hi}
+ * and its sixteen phase-step phasors (oldest first) as 2 x 16-bit fixed point (1 / 32767: 2e-5 rad, v_cvt_pknorm_i16_f32) --,
+ * 80 bytes instead of 144 (the lists are written by one kernel and read by the next: 25 MB per class-scan of a 33 s push).
+ * An item with a non-finite phasor carries the `odd` flag instead (k2x_second then looks at it exactly).  Within an area of the
+ * list (a scan workgroup's private area, or the common area) word w of item i lies at (w * area_items + i): consecutive items
+ * -- a wavefront's lanes, on either side -- are consecutive in memory. */
+#define K2A_ITEM_WORDS 5
+struct K2aItem { float4 w[K2A_ITEM_WORDS]; };	/* (size only: see above for the layout) */
+
+/* LDS of a scan workgroup: 19.1 KB (the verify pass: 20.4 KB), seven or eight workgroups per CU as far as LDS goes.
+ *   xs[]  S = 2 (one class: probe, verify): even samples, then (at K2A_XODD) odd samples, so that both FIR tap parities are
+ *         unit-stride across lanes; once the filter pass has read them the SAME memory takes the phase-step phasors
+ *         (wu = xs: the filter's results wait in registers for the barrier).
+ *         S = 1 (all classes: region scan, complete scan): samples in order in the lower half -- they are filtered once per
+ *         sub-phase --, the phasors behind them (wu = xs + K2A_WU1). */
+#define K2A_WU1 (K2A_TS + K2A_XOFF + 4)
+#define K2A_XS_LEN (K2A_WU1 + K2A_TS + K2A_POFF + 4)
 struct alignas(16) K2aShared {
-	float2 xs[K2A_XMAX + 8];	/* S = 1: samples in order; S = 2: even samples, then (at K2A_XODD) odd samples, so that
-					 * both FIR tap parities are unit-stride across lanes */
-	float2 wu[K2A_TS + K2A_POFF + 2];	/* unit phasor of every filtered sample (history first), then in place the phasor
-					 * of the symbol-spaced phase step */
+	float2 xs[K2A_XS_LEN];
 	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45) */
-	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants (vdl2_math.h) */
-	int wl[K2A_WL];			/* evaluations of the current tile the first screen lets through */
-	K2aDef dl[K2A_DEF];		/* survivors of both screens, collected over tiles until there are enough to
-					 * give every lane an exact phase to compute (k2a_flush) */
-	float sph[K2A_WL2][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
-	float we[3][K2A_WL2], wf[K2A_WL2];	/* their exact fit errors, and the slope at the middle one */
-	int nwl, ndl;
+	unsigned it_used, it_limit;	/* items the workgroup has put into its private area; where the first group that did not fit would have begun */
 	unsigned long long prof[16];	/* diagnostics: stage cycle counters of the workgroup's first lane, added to p.dbg at the end
 					 * (a global atomic per stamp would sit in front of the tile's next s_waitcnt vmcnt) */
 };
-static_assert((K2A_XMAX / 2 + 4) % 2 == 0 && (K2A_XMAX + 8) % 2 == 0, "16-byte reads of xs[] and wu[]");
+static_assert(K2A_WU1 % 2 == 0 && K2A_XS_LEN >= K2A_XMAX + 8 && (K2A_XMAX / 2 + 4) % 2 == 0, "16-byte reads of xs[] and wu[]");
+static_assert(K2A_TS + K2A_POFF / 2 + 2 <= K2A_XS_LEN && K2A_WU1 >= K2A_TS + K2A_XOFF, "phasor areas");
 #define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
 
 /* Screens for the 17-point fit (the expensive part of the scan).
@@ -97,6 +122,36 @@ static_assert((K2A_XMAX / 2 + 4) % 2 == 0 && (K2A_XMAX + 8) % 2 == 0, "16-byte r
 #define VDL2_SCREEN_R2 56.25f	/* R^2: (16 - 7.5) / 2 = 4.25 */
 #define VDL2_SCREEN_R22 42.25f	/* R2^2: (15 - 6.5) / 2 = 4.25 */
 #define VDL2_SCREEN_R32 30.25f	/* R3^2: (14 - 5.5) / 2 = 4.25 */
+/* Fourth screen: the fit error itself, from approximate angles.  The reference's unwrapped phases (d8psk.c:262-274) differ
+ * from one symbol to the next by the template-corrected phase step wrapped once into [-pi, pi] -- the angle D_l of the
+ * rotated step phasor c_l * u_l the second screen has in registers (unless |D_l| is within rounding of pi, where the fit
+ * error is far above any threshold anyway) -- so with q_l = D_1 + .. + D_l (q_0 = 0: the fit error does not depend on the
+ * first phase) the reference's err is  sum q^2 - (sum q)^2 / 17 - (sum q (l - 8))^2 / 408  in real arithmetic.  With angles
+ * good to 2e-5 rad (polynomial) + 1e-5 (fused filter, reciprocal square root, two phasor products) every q_l is good to
+ * l * 3e-5, the residual vector to 3e-5 * sqrt(sum l^2) = 1.2e-3 in norm, err to 2 * sqrt(7.25) * 1.2e-3 + 3e-3 (float
+ * cancellation in the three sums, q up to 50) < 0.01: an evaluation whose approximate err exceeds the detector's 4 (the
+ * probe's seed limit 7) by VDL2_FIT_MARGIN = 0.25 cannot be below it exactly.  On noise 1.5 % of what the second and third
+ * screens let through is below 7.25 and 0.05 % below 4.25 (numpy model of the chain over 2 M instants): the exact phases
+ * (51 filters and 51 atan2f per survivor: a third of the probe's and the verify pass's vector instructions) are computed
+ * around sync words only. */
+#define VDL2_FIT_MARGIN 0.25f
+#define VDL2_NB_MARGIN 0.1f	/* k2x_second's fifth screen: what two approximate fit errors must differ by to be ordered */
+__device__ __forceinline__ float k2_fast_angle(float y, float x)
+{
+	const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+	const float mn = __builtin_fminf(ax, ay), mx = __builtin_fmaxf(ax, ay);
+	const float t = mn * __builtin_amdgcn_rcpf(mx);
+	const float s = t * t;
+	float p = __fmaf_rn(s, -0.0117212f, 0.05265332f);
+	p = __fmaf_rn(s, p, -0.11643287f);
+	p = __fmaf_rn(s, p, 0.19354346f);
+	p = __fmaf_rn(s, p, -0.33262347f);
+	p = __fmaf_rn(s, p, 0.99997726f) * t;
+	p = ay > ax ? 1.57079637f - p : p;
+	p = x < 0.0f ? 3.14159274f - p : p;
+	return __builtin_copysignf(p, y);
+}
+
 __device__ __forceinline__ v2f k2_rot(v2f acc, v2f u, float cx, float cy)
 {
 	/* acc += (cx + j cy) * u */
@@ -167,12 +222,13 @@ __device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long de
 }
 
 /* The samples of a tile travel HBM -> registers -> LDS.  The registers of the *next* tile of the
- * same workgroup are loaded right after the current tile's have been parked in LDS, so that the
- * memory latency (several thousand cycles under load) is hidden behind the current tile's arithmetic. */
+ * same workgroup are loaded once the current tile's filter pass is through (its sample registers are free then), so that
+ * the memory latency (several thousand cycles under load) is hidden behind the current tile's screens. */
 template <int S> struct K2aPre {
 	static constexpr int NL = (S * (K2A_TS - 1) + 1 + K2A_XOFF + K2A_THREADS - 1) / K2A_THREADS;
 	float2 v[NL];
 	bool loaded;
+	int tiles;		/* tiles this workgroup has done: which of its wavefronts takes the sparse pass rotates */
 };
 
 /* once per workgroup, before its first tile */
@@ -180,11 +236,22 @@ __device__ __forceinline__ void k2a_tables(K2aShared &sh)
 {
 	for (int i = threadIdx.x; i < 72; i += K2A_THREADS)
 		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
-	if (threadIdx.x < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
-		sh.atab[threadIdx.x] = vdl2_atan_tab_entry(threadIdx.x);
-	if (threadIdx.x == 0)
-		sh.ndl = 0;
+	if (threadIdx.x == 0) {
+		sh.it_used = 0;
+		sh.it_limit = 0xffffffffu;
+	}
 	__syncthreads();
+}
+
+/* at the end of a scan workgroup: how much of its private area holds items */
+__device__ __forceinline__ void k2a_finish(K2aShared &sh, const K2Params &p, int sc)
+{
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned n = sh.it_used < sh.it_limit ? sh.it_used : sh.it_limit;
+		n = n < (unsigned)p.surv_pch ? n : (unsigned)p.surv_pch;
+		p.wcount[((size_t)p.surv_slot * p.nstreams * VDL2_CS + sc) * VDL2_MAXWG + blockIdx.x] = n;
+	}
 }
 
 template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const K2Params &p, int sc, long long dec_base, long long nbase, int cnt)
@@ -200,26 +267,265 @@ template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const
 	pre.loaded = true;
 }
 
-/* mode 0: append candidates; mode 1: report hits in [chk_lo, chk_hi) to *fail and append them;
- * mode 2: probe (candidates + seeds).  One sub-phase per pass:
- *   FIR + unit phasor of every instant | phase-step phasors | first screen -> worklist |
- *   second screen of the worklist | exact phases of the survivors | exact fits | detector test. */
-/* Work off the collected survivors: exact phases (FIR from the channel plane in HBM/L2 -- the tile
- * they came from has left LDS -- then atan2f, d8psk.c:219-229), exact fits (d8psk.c:257-289) of the
- * evaluation and its two neighbours, detector test (d8psk.c:292).  Every lane has work: 51 phases
- * per survivor. */
-__device__ void k2a_flush(K2aShared &sh, const K2Params &p, int sc, long long dec_base, int mode, int *fail, int skip_r, int skip_par)
+/* The scan kernels do the DENSE part only: filter, phasors and the first screen at every instant of a tile, all four
+ * wavefronts of a workgroup in step.  What passes the first screen (2.7 % of the instants) leaves the kernel as an item --
+ * instant, class and the sixteen phase-step phasors it was screened on -- in the channel's item list, and k2x_second, the next
+ * kernel on the stream, takes the lists through the sparse stages with every lane busy: second and third screen, the fit
+ * screen, then for the few survivors exact phases, exact fits and the detector test.  [Until round 4 the sparse stages ran
+ * inside the tile loop: one wavefront of four worked on 27 items of 64 lanes while the other three waited at the barrier --
+ * a third of the probe's time -- and the exact work's registers capped the scan kernels at four wavefronts per SIMD.]
+ * mode 0: append candidates; mode 1: report hits in [chk_lo, chk_hi) to *fail and append them; mode 2: probe (candidates + seeds). */
+
+/* The lanes of a wavefront whose evaluation passed the first screen append their items: one atomic per wavefront and pass,
+ * the items in lane order (= time order: k2x_second finds an evaluation's neighbours next to it). */
+__device__ __forceinline__ void k2a_append(K2aShared &sh, const K2Params &p, int sc, bool pass, int n_rel, int r, int lo, int hi, const float2 (&uu)[16], bool odd, int mode, int *fail)
 {
+	const unsigned long long m = __ballot(pass);
+	if (m == 0)
+		return;
+	const unsigned lane_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+	const unsigned cnt = (unsigned)__popcll(m);
+	unsigned base = 0, stride = 0;	/* in 16-byte words: where word 0 of the group's first item goes, and from word to word */
+	if (lane_rank == 0 && pass) {
+		const unsigned pch = (unsigned)p.surv_pch;
+		const unsigned off = atomicAdd(&sh.it_used, cnt);	/* LDS */
+		if (off + cnt <= pch) {
+			base = blockIdx.x * pch * K2A_ITEM_WORDS + off;
+			stride = pch;
+		} else {
+			/* the workgroup's own area is full (a stretch where far more than 2.7 % pass: a carrier, a run of sync words):
+			 * the common area behind the private ones, through the channel's counter in device memory */
+			atomicMin(&sh.it_limit, off);
+			const unsigned priv = (unsigned)p.surv_nwg * pch;
+			const unsigned off2 = atomicAdd(p.ctl + CTL_NSURV0 + p.surv_slot * p.nstreams * VDL2_CS + sc, cnt);
+			stride = VDL2_ITEM_CAP - priv;
+			base = (off2 + cnt <= stride) ? priv * K2A_ITEM_WORDS + off2 : 0xffffffffu;
+		}
+	}
+	const int lead = __builtin_ctzll(m);
+	base = (unsigned)__builtin_amdgcn_readlane((int)base, lead);
+	stride = (unsigned)__builtin_amdgcn_readlane((int)stride, lead);
+	if (!pass)
+		return;
+	if (base != 0xffffffffu) {
+		float4 *dst = reinterpret_cast<float4 *>(p.items) + (size_t)sc * VDL2_ITEM_CAP * K2A_ITEM_WORDS + base + lane_rank;
+		dst[0] = make_float4(__int_as_float(n_rel), __int_as_float(r | (odd ? 0x100 : 0)), __int_as_float(lo), __int_as_float(hi));
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			typedef short s2 __attribute__((ext_vector_type(2)));
+			union { s2 v; int i; } c[4];
+#pragma unroll
+			for (int l = 0; l < 4; ++l)
+				c[l].v = __builtin_amdgcn_cvt_pknorm_i16(uu[4 * w + l].x, uu[4 * w + l].y);
+			dst[(size_t)(1 + w) * stride] = make_float4(__int_as_float(c[0].i), __int_as_float(c[1].i), __int_as_float(c[2].i), __int_as_float(c[3].i));
+		}
+	} else if (mode == 1)
+		atomicMin(fail, 0);	/* the verify pass cannot vouch for the channel: it is re-resolved, in the end redone serially */
+	else
+		p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] = 1u;	/* as if the candidate table had overflowed: the serial machine takes the channel */
+}
+
+/* the fourth screen's fit error from the sixteen rotated phase-step phasors (see k2_fast_angle) */
+__device__ __forceinline__ float k2x_fit(const v2f (&v)[16])
+{
+	float q = 0.0f, sq = 0.0f, sqq = 0.0f, sql = 0.0f;
+#pragma unroll
+	for (int l = 0; l < 16; ++l) {
+		q += k2_fast_angle(v[l].y, v[l].x);
+		sq += q;
+		sqq = __fmaf_rn(q, q, sqq);
+		sql = __fmaf_rn(q, (float)(l - 7), sql);
+	}
+	return sqq - sq * sq * (1.0f / 17.0f) - sql * sql * (1.0f / 408.0f);
+}
+
+struct K2xShared {
+	float smf[72];
+	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];
+	K2aDef dl[K2X_NT];		/* the workgroup's survivors of all screens */
+	int it_n[K2X_NT + 2];		/* the items' instants, ... */
+	int it_st[K2X_NT + 2];		/* ... sub-phase | status << 4 (0: cannot fire, 1: fit error known approximately, 2: must be looked at exactly), ... */
+	float it_ea[K2X_NT + 2];	/* ... approximate fit errors */
+	float2 cv[K2X_CV][17];		/* rotated phasors of the items that passed the second and third screen (row padded: a lane per row) */
+	int cidx[K2X_CV];		/* ... whose they are */
+	int nc;
+	int ns;
+	float sph[K2X_WL][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
+	float we[3][K2X_WL], wf[K2X_WL];	/* their exact fit errors, and the slope at the middle one */
+};
+
+/* K2x: a workgroup takes 256 items of a channel's list, a lane each through the second, third and fourth screen (dense: the
+ * list holds nothing else), then the workgroup together through the exact stage for the survivors: exact phases (FIR in the
+ * reference's order from the channel plane, then atan2f, d8psk.c:219-229), exact fits (d8psk.c:257-289) of the evaluation and
+ * its two neighbours, detector test (d8psk.c:292).  Survivors are rare since the fourth screen: a handful per sync word and
+ * class, one per 20 000 instants of noise. */
+__global__ __launch_bounds__(K2X_NT)
+void k2x_second(K2Params p)
+{
+	__shared__ K2xShared sh;
 	const int tid = threadIdx.x;
+	const int c = blockIdx.y, s = blockIdx.z;
+	const int sc = s * VDL2_CS + c;
+	const int mode = p.surv_mode;
+	/* this workgroup's 256 items: part of a scan workgroup's private area, or of the common area behind them */
+	const unsigned pch = (unsigned)p.surv_pch, priv = (unsigned)p.surv_nwg * pch;
+	const unsigned first = blockIdx.x * K2X_NT;
+	unsigned nhere, w0, stride;	/* items of this workgroup; 16-byte word index of its first item's word 0; words from word to word */
+	if (first < priv) {
+		const unsigned wg = first / pch, off = first - wg * pch;
+		const unsigned cnt = p.wcount[((size_t)p.surv_slot * p.nstreams * VDL2_CS + sc) * VDL2_MAXWG + wg];
+		nhere = cnt > off ? cnt - off : 0;
+		w0 = wg * pch * K2A_ITEM_WORDS + off;
+		stride = pch;
+	} else {
+		stride = VDL2_ITEM_CAP - priv;
+		unsigned nc = p.ctl[CTL_NSURV0 + p.surv_slot * p.nstreams * VDL2_CS + sc];
+		nc = nc > stride ? stride : nc;
+		const unsigned off = first - priv;
+		nhere = nc > off ? nc - off : 0;
+		w0 = priv * K2A_ITEM_WORDS + off;
+	}
+	if (nhere == 0)
+		return;
+	nhere = nhere > K2X_NT ? K2X_NT : nhere;
+	for (int i = tid; i < 72; i += K2X_NT)
+		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+		sh.atab[tid] = vdl2_atan_tab_entry(tid);
+	if (tid == 0) {
+		sh.ns = 0;
+		sh.nc = 0;
+	}
+	if (tid < 2) {
+		sh.it_n[K2X_NT + tid] = 0x7fffffff;
+		sh.it_st[K2X_NT + tid] = 0;
+	}
 	__syncthreads();
-	const int nd = sh.ndl;
+	/* exp(-j (SW[l] - SW[l-1])), l = 1..16: the template steps are 1,7,5,-7,1,3,-3,-7,3,-1,5,-5,-3,-5,-1,7 (x pi/8) */
+	constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
+	constexpr float rc[16] = {C1, -C1, -S1, -C1, C1, S1, S1, -C1, S1, C1, -S1, -S1, S1, -S1, C1, -C1};
+	constexpr float rs[16] = {-S1, -S1, -C1, S1, -S1, -C1, C1, S1, -C1, S1, -C1, C1, C1, C1, S1, -S1};
+	const float fit_limit = mode == 2 ? VDL2_SEED_ERR + VDL2_FIT_MARGIN : 4.0f + VDL2_FIT_MARGIN;
+	int st = 0;
+	float erra = 0.0f;
+	K2aDef d{};
+	const bool have = (unsigned)tid < nhere;
+	if (have) {
+		const float4 *src = reinterpret_cast<const float4 *>(p.items) + (size_t)sc * VDL2_ITEM_CAP * K2A_ITEM_WORDS + w0 + tid;
+		float4 raw[K2A_ITEM_WORDS];
+#pragma unroll
+		for (int l = 0; l < K2A_ITEM_WORDS; ++l)
+			raw[l] = src[(size_t)l * stride];
+		d.n = __float_as_int(raw[0].x);
+		const int rflags = __float_as_int(raw[0].y);
+		d.r = rflags & 0xff;
+		d.lo = __float_as_int(raw[0].z);
+		d.hi = __float_as_int(raw[0].w);
+		v2f v[16];
+#pragma unroll
+		for (int l = 0; l < 16; ++l) {
+			const float4 q4 = raw[1 + l / 4];
+			const int pk = __float_as_int((l & 3) == 0 ? q4.x : ((l & 3) == 1 ? q4.y : ((l & 3) == 2 ? q4.z : q4.w)));
+			const v2f u = {(float)(short)(pk & 0xffff) * (1.0f / 32767.0f), (float)(pk >> 16) * (1.0f / 32767.0f)};
+			v[l] = k2_rot((v2f){0.0f, 0.0f}, u, rc[l], rs[l]);
+		}
+		/* second screen: lag-2 steps as products of neighbouring rotated lag-1 phasors; third: lag-3 steps, 14 of them */
+		v2f acc = {0.0f, 0.0f}, acc3 = {0.0f, 0.0f};
+#pragma unroll
+		for (int l = 0; l < 15; ++l) {
+			const v2f p2 = k2_rot((v2f){0.0f, 0.0f}, v[l], v[l + 1].x, v[l + 1].y);
+			acc += p2;
+			if (l < 14)
+				acc3 = k2_rot(acc3, p2, v[l + 2].x, v[l + 2].y);
+		}
+		const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
+		const float r3 = __fmaf_rn(acc3.x, acc3.x, acc3.y * acc3.y);
+		if (rflags & 0x100)
+			st = 2;		/* a non-finite phasor: the exact stage decides */
+		else if (!(r2 <= VDL2_SCREEN_R22) && !(r3 <= VDL2_SCREEN_R32)) {
+			/* fourth screen: the fit itself on approximate step angles (see k2_fast_angle) -- for the first K2X_CV of the
+			 * workgroup in one wavefront behind the barrier, a lane each; for more than that (a list of sync words) here */
+			const int slot = atomicAdd(&sh.nc, 1);
+			if (slot < K2X_CV) {
+				sh.cidx[slot] = tid;
+#pragma unroll
+				for (int l = 0; l < 16; ++l)
+					sh.cv[slot][l] = make_float2(v[l].x, v[l].y);
+				st = 3;	/* (pending) */
+			} else {
+				erra = k2x_fit(v);
+				st = (erra > fit_limit) ? 0 : 1;
+			}
+		}
+	}
+	sh.it_n[tid] = have ? d.n : 0x7fffffff;
+	sh.it_st[tid] = d.r | (st << 4);
+	sh.it_ea[tid] = erra;
+	__syncthreads();
+	{
+		const int nc = sh.nc < K2X_CV ? sh.nc : K2X_CV;
+		if (tid < nc) {
+			v2f v[16];
+#pragma unroll
+			for (int l = 0; l < 16; ++l) {
+				const float2 t = sh.cv[tid][l];
+				v[l] = (v2f){t.x, t.y};
+			}
+			const float e = k2x_fit(v);
+			const int who = sh.cidx[tid];
+			sh.it_ea[who] = e;
+			sh.it_st[who] = (sh.it_st[who] & 15) | ((e > fit_limit ? 0 : 1) << 4);
+		}
+	}
+	__syncthreads();
+	st = sh.it_st[tid] >> 4;
+	erra = sh.it_ea[tid];
+	if (st == 1) {
+		/* Fifth screen: the detector's own test on the approximate errors of NEIGHBOURING evaluations.  A scan wavefront's items
+		 * are in the list in time order, so the evaluation one step later (n + 2: the `err` to this evaluation's `perr`) is
+		 * the next item or the one after, the evaluation one step earlier the previous or the one before -- or it is not in
+		 * the list: then it failed the first screen (its error is above 4.25: a rising step) or it lies in another wavefront's
+		 * group (unknown: treated the same, which keeps this evaluation).
+		 *   falling step: err(n + 2) < err(n) -- neither the detector nor a seed can fire at n + 2 on this evaluation;
+		 *   later step of a run: err(n - 2) < 4 and err(n) > err(n - 2) -- k2a_emit would not list a hit at n + 2 (only the
+		 *   first firing of a run is listed: see there; the verify pass and the complete scan list everything).
+		 * Both with VDL2_NB_MARGIN between the approximate values, which are good to 0.02.  Of the five evaluations around a
+		 * sync word's minimum in a class, the one at the minimum is left. */
+		const int same = d.r | (1 << 4);
+		int nx = -1, pv = -1;
+		if (sh.it_n[tid + 1] == d.n + 2 && sh.it_st[tid + 1] == same)
+			nx = tid + 1;
+		else if (sh.it_n[tid + 2] == d.n + 2 && sh.it_st[tid + 2] == same)
+			nx = tid + 2;
+		if (tid >= 1 && sh.it_n[tid - 1] == d.n - 2 && sh.it_st[tid - 1] == same)
+			pv = tid - 1;
+		else if (tid >= 2 && sh.it_n[tid - 2] == d.n - 2 && sh.it_st[tid - 2] == same)
+			pv = tid - 2;
+		if (nx >= 0 && sh.it_ea[nx] < erra - VDL2_NB_MARGIN)
+			st = 0;
+		const bool first_only = (mode == 0 || mode == 2) && p.round == 0 && !p.full_scan;	/* k2a_emit's condition */
+		if (first_only && pv >= 0 && sh.it_ea[pv] < 4.0f - VDL2_NB_MARGIN && erra > sh.it_ea[pv] + VDL2_NB_MARGIN)
+			st = 0;
+	}
+	if (st)
+		sh.dl[atomicAdd(&sh.ns, 1)] = d;
+	__syncthreads();
+	const int nd = sh.ns;
+#ifdef K2X_NO_EXACT
+	return;
+#endif
+	if (nd == 0)
+		return;
+	const long long dec_base = p.dec_base;
+	const int skip_r = p.surv_skip ? p.probe_r : -1, skip_par = p.probe_par;
+	int *fail = p.fail + sc;
 	const float2 *x0 = p.dec + (size_t)sc * p.cap;	/* x0[n] = sample at stream-relative time n */
 	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
 	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
 	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
-	for (int b0 = 0; b0 < nd; b0 += K2A_WL2) {
-		const int nb = (nd - b0 < K2A_WL2) ? nd - b0 : K2A_WL2;
-		for (int t = tid; t < 51 * nb; t += K2A_THREADS) {
+	for (int b0 = 0; b0 < nd; b0 += K2X_WL) {
+		const int nb = (nd - b0 < K2X_WL) ? nd - b0 : K2X_WL;
+		for (int t = tid; t < 51 * nb; t += K2X_NT) {
 			const int slot = t / 51, rem = t - 51 * slot, w = rem / 17, l = rem - 17 * w;
 			const K2aDef d = sh.dl[b0 + slot];
 			const float2 *x = x0 + (d.n + (w - 1) * 2 - 8 * (16 - l) - 16);
@@ -240,30 +546,26 @@ __device__ void k2a_flush(K2aShared &sh, const K2Params &p, int sc, long long de
 			sh.sph[slot][w][l] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
 		}
 		__syncthreads();
-		for (int k = tid; k < 3 * nb; k += K2A_THREADS) {
-			const int slot = k / 3, w = k - 3 * slot;
+		for (int kk = tid; kk < 3 * nb; kk += K2X_NT) {
+			const int slot = kk / 3, w = kk - 3 * slot;
 			float fr;
 			sh.we[w][slot] = k2_sync_metric<1>(&sh.sph[slot][w][0], &fr);
 			if (w == 1)
 				sh.wf[slot] = fr;
 		}
 		__syncthreads();
-		for (int k = tid; k < nb; k += K2A_THREADS) {
-			const K2aDef d = sh.dl[b0 + k];
+		for (int kk = tid; kk < nb; kk += K2X_NT) {
+			const K2aDef d = sh.dl[b0 + kk];
 			k2a_emit(p, sc, dec_base, dec_base + d.n + 2, d.r, mode, dec_base + d.lo, dec_base + d.hi, fail, skip_r, skip_par,
-				 sh.we[0][k], sh.we[1][k], sh.we[2][k], sh.wf[k], cntp, ovf, cl);
+				 sh.we[0][kk], sh.we[1][kk], sh.we[2][kk], sh.wf[kk], cntp, ovf, cl);
 		}
 		__syncthreads();
 	}
-	if (tid == 0)
-		sh.ndl = 0;
-	__syncthreads();
 }
 
 /* Filtered samples of the tile instants q0 (even) and q0 + 1, sub-phase taps mf[] (d8psk.c:219-228), for
  * the screens only: fused multiply-adds,
- * and the 18 or 19 samples the two share are read once, 16 bytes per lane and read -- the filter pass is
- * bound by LDS bandwidth (one pipe per CU against four SIMDs), not by arithmetic.  A tap that does not
+ * and the 18 or 19 samples the two share are read once, 16 bytes per lane and read.  A tap that does not
  * exist has mf[] = 0. */
 template <int S> __device__ __forceinline__ void k2a_fir2(const K2aShared &sh, int q0, const float (&mf)[17], v2f &acc0, v2f &acc1)
 {
@@ -317,6 +619,23 @@ template <int S> __device__ __forceinline__ void k2a_fir2(const K2aShared &sh, i
 	}
 }
 
+/* unit phasor of a filtered sample (for the screens): atan2f(0, 0) = 0; anything else odd becomes NaN and passes every screen */
+__device__ __forceinline__ v2f k2a_unit(v2f a)
+{
+	const float n2 = __fmaf_rn(a.x, a.x, a.y * a.y);
+	v2f w = a * __frsqrt_rn(n2);
+	if (!(n2 >= 1e-30f && n2 <= 1e30f)) {
+		const float bad = (a.x == 0.0f && a.y == 0.0f) ? 0.0f : __builtin_nanf("");
+		w = (v2f){1.0f + bad, bad};
+	}
+	return w;
+}
+
+__device__ __forceinline__ float k2a_lane_from(int byte_addr, float v)
+{
+	return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
 					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail,
 					   K2aPre<S> &pre, long long next_nbase, int next_cnt, int skip_r = -1, int skip_par = 0)
@@ -325,8 +644,14 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	constexpr int PH = K2A_POFF / S;	/* phase instants of history */
 	constexpr int LSTR = 8 / S;		/* one symbol in instants */
 	constexpr int E2 = 2 / S, E4 = 4 / S;	/* previous two evaluations in instants */
-	constexpr int NQ = (K2A_TS + PH + K2A_THREADS - 1) / K2A_THREADS;
+	/* filter pass: a lane takes a PAIR of neighbouring instants; the phasor one symbol earlier is KH lanes down in the same
+	 * wavefront, whose first KH lanes repeat the pairs of the wavefront before (they only supply, they do not store) */
+	constexpr int KH = LSTR / 2;
+	constexpr int PPW = 64 - KH;				/* pairs a wavefront owns per round */
+	constexpr int PPI = (K2A_THREADS / 64) * PPW;		/* ... the workgroup */
+	constexpr int NIT = ((K2A_TS + PH + 1) / 2 + PPI - 1) / PPI;
 	static_assert(K2A_POFF == S * PH, "phase history must be a whole number of instants");
+	float2 *const wu = (S == 2) ? sh.xs : sh.xs + K2A_WU1;	/* phase-step phasors (see K2aShared) */
 	/* exp(-j (SW[l] - SW[l-1])), l = 1..16: the template steps are 1,7,5,-7,1,3,-3,-7,3,-1,5,-5,-3,-5,-1,7 (x pi/8) */
 	constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
 	constexpr float rc[16] = {C1, -C1, -S1, -C1, C1, S1, S1, -C1, S1, C1, -S1, -S1, S1, -S1, C1, -C1};
@@ -335,22 +660,44 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	const bool prof = p.dbg && (mode == 2 || (mode == 0 && S == 1 && skip_r >= 0)) && tid == 0 && (blockIdx.x & 7) == 0;	/* probe, region scan */
 	long long tq = prof ? clock64() : 0;
 #define K2A_STAMP(slot) do { if (prof) { const long long tn = clock64(); sh.prof[slot] += (unsigned long long)(tn - tq); tq = tn; } } while (0)
+	/* park slots: sample i = tid + k * K2A_THREADS of the tile goes to xs[pbase + k * pstep] */
+	const int pbase = (S == 2) ? (tid & 1) * K2A_XODD + (tid >> 1) : tid;
+	constexpr int pstep = (S == 2) ? K2A_THREADS / 2 : K2A_THREADS;
+#if K2A_PREFETCH
 	if (!pre.loaded)
 		k2a_fetch<S>(pre, p, sc, dec_base, nbase, cnt);
 	__syncthreads();
 	K2A_STAMP(12);
 #pragma unroll
-	for (int k = 0; k < K2aPre<S>::NL; ++k) {
-		const int i = tid + k * K2A_THREADS;
-		if (i < nx)
-			sh.xs[S == 2 ? (i & 1) * K2A_XODD + (i >> 1) : i] = pre.v[k];
-	}
+	for (int k = 0; k < K2aPre<S>::NL; ++k)
+		if (tid + k * K2A_THREADS < nx)
+			sh.xs[pbase + k * pstep] = pre.v[k];
 	pre.loaded = false;
+#else
+	{
+		/* no software prefetch: six workgroups per CU are in different phases of their tiles, one's wait for its samples is
+		 * another's filter pass (the twenty registers a prefetch holds through the screens are what six wavefronts per SIMD
+		 * do not leave) */
+		const float2 *x = p.dec + (size_t)sc * p.cap + (nbase - K2A_XOFF - dec_base);
+		float2 v[K2aPre<S>::NL];
+#pragma unroll
+		for (int k = 0; k < K2aPre<S>::NL; ++k)
+			if (tid + k * K2A_THREADS < nx)
+				v[k] = x[tid + k * K2A_THREADS];
+		K2A_STAMP(12);
+#pragma unroll
+		for (int k = 0; k < K2aPre<S>::NL; ++k)
+			if (tid + k * K2A_THREADS < nx)
+				sh.xs[pbase + k * pstep] = v[k];
+	}
+#endif
+	pre.tiles++;
 	K2A_STAMP(13);
-	if (next_cnt > 0)
-		k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
 	__syncthreads();
 	K2A_STAMP(0);
+	const int npairs = (cnt + PH + 1) / 2;
+	const int wv = tid >> 6, ln = tid & 63;
+	const int src_lane = (ln - KH) * 4;	/* ds_bpermute address of the lane KH down (wraps for the first KH lanes: their result is not used) */
 #pragma unroll 1
 	for (int r = 0; r < 4; ++r) {
 		if (!(rmask & (1u << r)))
@@ -359,135 +706,68 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 #pragma unroll
 		for (int j = 0; j < 17; ++j)	/* mflt[r + 64] exists only for r == 0 (16 taps otherwise) */
 			mf[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.smf[r + 4 * j])));
-		/* ---- unit phasors of the filtered samples of instants -PH .. cnt-1 */
-		for (int q0 = 2 * tid; q0 < cnt + PH; q0 += 2 * K2A_THREADS) {	/* (the odd one out at the end lands in wu[]'s padding) */
-			v2f acc[2];
-			k2a_fir2<S>(sh, q0, mf, acc[0], acc[1]);
-			float4 out;
+		/* ---- phase-step phasors u[q] = w[q] * conj(w[q - LSTR]) of instants -PH + LSTR .. cnt-1, w = unit phasor of the
+		 *      filtered sample */
+		float4 hold[NIT];
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				const float n2 = __fmaf_rn(acc[h].x, acc[h].x, acc[h].y * acc[h].y);
-				v2f w = acc[h] * __frsqrt_rn(n2);
-				if (!(n2 >= 1e-30f && n2 <= 1e30f)) {	/* atan2f(0, 0) = 0; anything else odd: let it through */
-					const float bad = (acc[h].x == 0.0f && acc[h].y == 0.0f) ? 0.0f : __builtin_nanf("");
-					w = (v2f){1.0f + bad, bad};
-				}
-				if (h == 0) {
-					out.x = w.x;
-					out.y = w.y;
-				} else {
-					out.z = w.x;
-					out.w = w.y;
-				}
-			}
-			*reinterpret_cast<float4 *>(&sh.wu[q0]) = out;
-		}
-		K2A_STAMP(1);
-		__syncthreads();
-		K2A_STAMP(2);
-		/* ---- in place: wu[q] <- wu[q] * conj(wu[q - LSTR]) */
-		{
-			v2f u[NQ];
-			float2 a[NQ], b[NQ];
-			const int qmax = cnt + PH - 1;
-#pragma unroll
-			for (int k = 0; k < NQ; ++k) {	/* clamped, unpredicated: all reads in flight together */
-				int q = tid + k * K2A_THREADS;
-				q = q < LSTR ? LSTR : (q > qmax ? qmax : q);
-				a[k] = sh.wu[q];
-				b[k] = sh.wu[q - LSTR];
-			}
-#pragma unroll
-			for (int k = 0; k < NQ; ++k)
-				u[k] = (v2f){__fmaf_rn(a[k].x, b[k].x, a[k].y * b[k].y), __fmaf_rn(a[k].y, b[k].x, -(a[k].x * b[k].y))};
-			__syncthreads();
-#pragma unroll
-			for (int k = 0; k < NQ; ++k) {
-				const int q = tid + k * K2A_THREADS;
-				if (q >= LSTR && q < cnt + PH)
-					sh.wu[q] = make_float2(u[k].x, u[k].y);
-			}
-		}
-		K2A_STAMP(3);
-		/* ---- the instants of the tile, all at once unless the worklist overflows (pathological
-		 *      input such as a constant-phase tone): then in pieces it cannot overflow on */
-		int piece = cnt;
-		for (int c0 = 0; c0 < cnt;) {
-			const int c1 = (c0 + piece < cnt) ? c0 + piece : cnt;
-			if (tid == 0)
-				sh.nwl = 0;
-			__syncthreads();
-			const int ndl0 = sh.ndl;	/* nobody appends between this barrier and the next */
-			/* first screen, of the evaluation that is the `perr` of instant i: j = i + E2 */
-			for (int i = c0 + tid; i < c1; i += K2A_THREADS) {
-				const int j = i + E2;
-				const float2 *uq = &sh.wu[PH - E4 + j - 15 * LSTR];
-				float2 uu[16];
-#pragma unroll
-				for (int l = 0; l < 16; ++l)	/* all sixteen LDS reads in flight before the arithmetic */
-					uu[l] = uq[l * LSTR];
-				v2f acc = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
-#pragma unroll
-				for (int l = 0; l < 16; l += 2) {
-					acc = k2_rot(acc, (v2f){uu[l].x, uu[l].y}, rc[l], rs[l]);
-					acc1 = k2_rot(acc1, (v2f){uu[l + 1].x, uu[l + 1].y}, rc[l + 1], rs[l + 1]);
-				}
-				acc += acc1;
-				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-				if (!(r2 <= VDL2_SCREEN_R2)) {
-					const int k = atomicAdd(&sh.nwl, 1);
-					if (k < K2A_WL)
-						sh.wl[k] = j;
-				}
-			}
-			K2A_STAMP(4);
-			__syncthreads();
-			K2A_STAMP(5);
-			const int nwl = sh.nwl;
-			if (prof)
-				sh.prof[10] += (unsigned long long)nwl;
-			if (nwl > K2A_WL) {
-				piece = K2A_WL;
-				__syncthreads();	/* everyone has read nwl before it is reset */
+		for (int it = 0; it < NIT; ++it) {
+			const int pw = it * PPI + wv * PPW;	/* first pair this wavefront owns in this round */
+			if (pw >= npairs) {	/* (wave-uniform) */
+				hold[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 				continue;
 			}
-			if (ndl0 + nwl > K2A_DEF) {	/* no room for this pass's survivors: work the list off first */
-				K2A_STAMP(6);
-				k2a_flush(sh, p, sc, dec_base, mode, fail, skip_r, skip_par);
-				K2A_STAMP(7);
-			}
-			/* second screen: lag-2 steps as products of neighbouring rotated lag-1 phasors */
-			for (int k = tid; k < nwl; k += K2A_THREADS) {
-				const int j = sh.wl[k];
-				const float2 *uq = &sh.wu[PH - E4 + j - 15 * LSTR];
-				v2f v[16];
-#pragma unroll
-				for (int l = 0; l < 16; ++l) {
-					const float2 u = uq[l * LSTR];
-					v[l] = k2_rot((v2f){0.0f, 0.0f}, (v2f){u.x, u.y}, rc[l], rs[l]);
-				}
-				v2f acc = {0.0f, 0.0f}, acc3 = {0.0f, 0.0f};
-#pragma unroll
-				for (int l = 0; l < 15; ++l) {
-					const v2f p2 = k2_rot((v2f){0.0f, 0.0f}, v[l], v[l + 1].x, v[l + 1].y);	/* lag-2 step l */
-					acc += p2;
-					if (l < 14)	/* third screen: lag-3 steps, 14 of them */
-						acc3 = k2_rot(acc3, p2, v[l + 2].x, v[l + 2].y);
-				}
-				const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-				const float r3 = __fmaf_rn(acc3.x, acc3.x, acc3.y * acc3.y);
-				if (!(r2 <= VDL2_SCREEN_R22) && !(r3 <= VDL2_SCREEN_R32)) {
-					K2aDef d;
-					d.n = (int)(nbase - dec_base) + S * (j - E4);
-					d.r = r;
-					d.lo = (mode == 1) ? (int)(chk_lo - dec_base) : 0;
-					d.hi = (mode == 1) ? (int)(chk_hi - dec_base) : 0;
-					sh.dl[atomicAdd(&sh.ndl, 1)] = d;
-				}
-			}
-			K2A_STAMP(6);
-			c0 = c1;
+			int q0 = 2 * (pw + ln - KH);
+			q0 = q0 < 0 ? 0 : (q0 > K2A_TS + PH - 2 ? K2A_TS + PH - 2 : q0);	/* keeps the reads inside xs[]; what a clamped lane computes is not stored */
+			v2f acc[2];
+			k2a_fir2<S>(sh, q0, mf, acc[0], acc[1]);
+			const v2f w0 = k2a_unit(acc[0]), w1 = k2a_unit(acc[1]);
+			const float p0x = k2a_lane_from(src_lane, w0.x), p0y = k2a_lane_from(src_lane, w0.y);
+			const float p1x = k2a_lane_from(src_lane, w1.x), p1y = k2a_lane_from(src_lane, w1.y);
+			hold[it] = make_float4(__fmaf_rn(w0.x, p0x, w0.y * p0y), __fmaf_rn(w0.y, p0x, -(w0.x * p0y)),
+					       __fmaf_rn(w1.x, p1x, w1.y * p1y), __fmaf_rn(w1.y, p1x, -(w1.x * p1y)));
+			__builtin_amdgcn_sched_barrier(0);	/* one round's nineteen samples in registers at a time */
 		}
+		K2A_STAMP(1);
+#if K2A_PREFETCH
+		if (next_cnt > 0 && !pre.loaded)	/* the next tile's samples: in flight during this tile's screens */
+			k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
+#endif
+		if (S == 2)
+			__syncthreads();	/* wu[] is xs[]: every wavefront is through with the samples */
+		K2A_STAMP(2);
+#pragma unroll
+		for (int it = 0; it < NIT; ++it) {
+			const int q0 = 2 * (it * PPI + wv * PPW + ln - KH);
+			if (ln >= KH && q0 >= LSTR && q0 < cnt + PH)	/* (the odd one out at the end lands in wu[]'s padding) */
+				*reinterpret_cast<float4 *>(&wu[q0]) = hold[it];
+		}
+		K2A_STAMP(3);
+		__syncthreads();
+		/* ---- first screen, of the evaluation that is the `perr` of instant i: j = i + E2; what passes goes to the item list */
+		for (int i0 = 0; i0 < cnt; i0 += K2A_THREADS) {	/* (wave-uniform trip count: k2a_append votes) */
+			const int i = i0 + tid;
+			const int j = (i < cnt ? i : cnt - 1) + E2;
+			const float2 *uq = &wu[PH - E4 + j - 15 * LSTR];
+			float2 uu[16];
+#pragma unroll
+			for (int l = 0; l < 16; ++l)	/* all sixteen LDS reads in flight before the arithmetic */
+				uu[l] = uq[l * LSTR];
+			v2f acc = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+#pragma unroll
+			for (int l = 0; l < 16; l += 2) {
+				acc = k2_rot(acc, (v2f){uu[l].x, uu[l].y}, rc[l], rs[l]);
+				acc1 = k2_rot(acc1, (v2f){uu[l + 1].x, uu[l + 1].y}, rc[l + 1], rs[l + 1]);
+			}
+			acc += acc1;
+			const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
+			const long long n_abs = nbase + S * (j - E4);	/* the evaluation's instant */
+			bool pass = i < cnt && !(r2 <= VDL2_SCREEN_R2);
+			if (mode == 0 && r == skip_r && (int)(n_abs & 1) == skip_par)
+				pass = false;	/* region scan: that class is the probe's, its hits are in the table already */
+			k2a_append(sh, p, sc, pass, (int)(n_abs - dec_base), r, (mode == 1) ? (int)(chk_lo - dec_base) : 0,
+				   (mode == 1) ? (int)(chk_hi - dec_base) : 0, uu, !(r2 == r2), mode, fail);
+		}
+		K2A_STAMP(4);
 		K2A_STAMP(8);
 		__syncthreads();
 		K2A_STAMP(9);
@@ -497,7 +777,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 #undef K2A_STAMP
 }
 
-__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A_WPE, 8)))
 void k2a_probe(K2Params p)
 {
 	__shared__ K2aShared sh;
@@ -516,6 +796,7 @@ void k2a_probe(K2Params p)
 	if (p.full_scan || p.full_round) {
 		K2aPre<1> pre;
 		pre.loaded = false;
+		pre.tiles = 0;
 		const long long step = (long long)gridDim.x * K2A_TS;
 		for (long long n0 = p.scan_lo + (long long)blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
 			const int nt = (int)((avail_end - n0 < K2A_TS) ? (avail_end - n0) : K2A_TS);
@@ -523,13 +804,14 @@ void k2a_probe(K2Params p)
 			const int nt1 = n1 < avail_end ? (int)((avail_end - n1 < K2A_TS) ? (avail_end - n1) : K2A_TS) : 0;
 			k2a_tile<1>(sh, p, sc, dec_base, n0, nt, 0xfu, 0, 0, 0, nullptr, pre, n1, nt1);
 		}
-		k2a_flush(sh, p, sc, dec_base, 0, nullptr, -1, 0);
+		k2a_finish(sh, p, sc);
 		return;
 	}
 	/* ONE class everywhere: sub-phase probe_r at the instants of scan_lo's parity -- any class finds the bursts; which
 	 * stretches the chain relied on in OTHER classes is what the verify pass re-scans */
 	K2aPre<2> pre;
 	pre.loaded = false;
+	pre.tiles = 0;
 	const unsigned rmask = 1u << p.probe_r;
 	const long long step = 2LL * gridDim.x * K2A_TS;
 	for (long long n0 = p.scan_lo + 2LL * blockIdx.x * K2A_TS; n0 < avail_end; n0 += step) {
@@ -540,8 +822,7 @@ void k2a_probe(K2Params p)
 		const int nt1 = n1 < avail_end ? (int)(left1 < K2A_TS ? left1 : K2A_TS) : 0;
 		k2a_tile<2>(sh, p, sc, dec_base, n0, nt, rmask, 2, 0, 0, nullptr, pre, n1, nt1);
 	}
-	k2a_flush(sh, p, sc, dec_base, 2, nullptr, -1, 0);
-	__syncthreads();
+	k2a_finish(sh, p, sc);
 	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
 		atomicAdd(p.dbg + 32 + threadIdx.x, sh.prof[threadIdx.x]);
 }
@@ -741,7 +1022,7 @@ void k2r_regions(K2Params p)
 	}
 }
 
-__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A_WPE, 8)))
 void k2a_region(K2Params p)
 {
 	__shared__ K2aShared sh;
@@ -764,6 +1045,7 @@ void k2a_region(K2Params p)
 	k2a_tables(sh);
 	K2aPre<1> pre;
 	pre.loaded = false;
+	pre.tiles = 0;
 	const bool prof = p.dbg && threadIdx.x == 0 && (blockIdx.x & 7) == 0;
 	const long long t0 = prof ? clock64() : 0;
 	for (unsigned k = blockIdx.x; k < nreg; k += gridDim.x) {
@@ -775,13 +1057,8 @@ void k2a_region(K2Params p)
 	}
 	const long long t1 = prof ? clock64() : 0;
 	if (prof)
-		sh.prof[13] += (unsigned long long)sh.ndl;	/* survivors left for the final flush */
-	k2a_flush(sh, p, sc, dec_base, 0, nullptr, skip_r, skip_par);
-	if (prof) {
-		sh.prof[14] += (unsigned long long)(clock64() - t1);	/* final flush */
 		sh.prof[12] += (unsigned long long)(t1 - t0);		/* all tiles */
-	}
-	__syncthreads();
+	k2a_finish(sh, p, sc);
 	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
 		atomicAdd(p.dbg + 48 + threadIdx.x, sh.prof[threadIdx.x]);
 }
@@ -792,7 +1069,7 @@ void k2a_region(K2Params p)
 #define K2A_VRUN 4
 #endif
 #define K2A_VITEMS 64
-__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A_WPE, 8)))
 void k2a_verify(K2Params p)
 {
 	__shared__ K2aShared sh;
@@ -854,13 +1131,14 @@ void k2a_verify(K2Params p)
 	}
 	K2aPre<2> pre;
 	pre.loaded = false;
+	pre.tiles = 0;
 	for (int q = 0; q < ni; ++q) {
 		const int4 it = s_item[q];
 		const int4 nx = (q + 1 < ni) ? s_item[q + 1] : make_int4(0, 0, 0, 0);
 		k2a_tile<2>(sh, p, sc, dec_base, dec_base + it.x, (it.y - it.x + 1) / 2, 1u << it.z, 1, dec_base + it.x, dec_base + it.y,
 			    p.fail + sc, pre, dec_base + nx.x, (nx.y - nx.x + 1) / 2);
 	}
-	k2a_flush(sh, p, sc, dec_base, 1, p.fail + sc, -1, 0);
+	k2a_finish(sh, p, sc);
 }
 
 #endif

@@ -134,6 +134,7 @@ struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs)
 	int wend[84];		/* last sample of each window, relative to the period's first sample */
 };
 
+struct K2aItem;
 struct K2Params {
 	const float2 *dec;
 	long long cap;
@@ -179,6 +180,12 @@ struct K2Params {
 	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
 	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
+	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen, worked off by k2x_second (the next kernel on the stream) */
+	unsigned *wcount;	/* [VDL2_SURV_SLOTS][S*8][VDL2_MAXWG] items in each scan workgroup's private area (zeroed by k_push_init) */
+	int surv_pch, surv_nwg;	/* items a private area holds (a multiple of 256), scan workgroups per channel (= private areas) */
+	int surv_slot;		/* which of the push's scans this is: its item counters are ctl[CTL_NSURV0 + slot * S*8 ...] (VDL2_SURV_*) */
+	int surv_mode;		/* k2x_second: what a detector hit among the survivors means (k2a_emit: 0 candidates, 1 verify, 2 probe) */
+	int surv_skip;		/* k2x_second: hits in the probe's class are in the table already (region scan) */
 	unsigned long long *dbg;	/* diagnostics: cycle counters */
 	HeadTap *headtap;	/* diagnostics: every trigger any kernel of the push handled (nullptr: off) */
 	unsigned *headtap_n;
@@ -196,6 +203,9 @@ struct K2Params {
 #define CTL_NPRIM0 (CTL_CAND0 + 5 * p.nstreams * VDL2_CS)
 #define CTL_NSEED0 (CTL_CAND0 + 6 * p.nstreams * VDL2_CS)
 #define CTL_NCLUST0 (CTL_CAND0 + 7 * p.nstreams * VDL2_CS)	/* candidates [0, n) had their clusters decided by the previous K2s/K2b of this push */
+#define CTL_NSURV0 (CTL_CAND0 + 8 * p.nstreams * VDL2_CS)	/* [VDL2_SURV_SLOTS][S*8] item counts, one set per scan of the push */
+enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repair round (1..4) */, VDL2_SURV_FULL = 7, VDL2_SURV_SLOTS = 8 };
+#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (8 + VDL2_SURV_SLOTS) * (size_t)(nsc))
 
 struct K3Params {
 	const float2 *src;
@@ -223,6 +233,8 @@ struct KInitParams {		/* per-push reset of the demodulator's control words */
 	int nsc;
 	unsigned *fmask;	/* 16 words */
 	unsigned *fcnt;		/* 4 words: this ring's block-path counters, or nullptr */
+	unsigned *wcount;	/* the scans' private-area counts */
+	int wcount_words;
 };
 
 /* ---- constant data tables (d8psk.h:20-249) as bit patterns ------------- */
