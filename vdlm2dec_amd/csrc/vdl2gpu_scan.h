@@ -388,10 +388,6 @@ void k2x_second(K2Params p)
 	if (nhere == 0)
 		return;
 	nhere = nhere > K2X_NT ? K2X_NT : nhere;
-	for (int i = tid; i < 72; i += K2X_NT)
-		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
-	if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
-		sh.atab[tid] = vdl2_atan_tab_entry(tid);
 	if (tid == 0) {
 		sh.ns = 0;
 		sh.nc = 0;
@@ -516,6 +512,11 @@ void k2x_second(K2Params p)
 #endif
 	if (nd == 0)
 		return;
+	for (int i = tid; i < 72; i += K2X_NT)	/* (the tables of the exact stage: only now, one workgroup in ten gets here) */
+		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+		sh.atab[tid] = vdl2_atan_tab_entry(tid);
+	__syncthreads();
 	const long long dec_base = p.dec_base;
 	const int skip_r = p.surv_skip ? p.probe_r : -1, skip_par = p.probe_par;
 	int *fail = p.fail + sc;
