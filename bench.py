@@ -210,7 +210,8 @@ def _reference_run(raw, fmt, fos, rate, budget_s, names, n_tile, reps, tmpdir, h
                 total += time.perf_counter() - t0
                 runs += 1
             nb = sum(1 for ln in open(os.path.join(td, "out.txt")) if ln.startswith("B"))
-            res = {"value": n * runs / total / 1e6, "unit": "MS/s", "cores": len(fos) + 1, "kind": "reference",
+            dropin = _dropin_replay(here, td, path, fmt, rate, fo, fr, n)
+            res = {"value": n * runs / total / 1e6, "unit": "MS/s", "cores": len(fos) + 1, "kind": "reference", "dropin_replay": dropin,
                    "sample": f"{runs} runs of oracle/_ref/{name} (vdlm2dec's own sources"
                              f"{', its own -Ofast -march=native' if name.endswith('_ofast') else ', -O2'}; producer + one rcv_thread per "
                              f"channel as in rtl.c/main.c) over {n} samples ({reps} x the 4.2 MS tile) from a file in "
@@ -219,6 +220,39 @@ def _reference_run(raw, fmt, fos, rate, budget_s, names, n_tile, reps, tmpdir, h
                              f"parity is pinned one channel per process, tests/test_oracle_vs_ref.py)"}
             break
     return res
+
+
+def _dropin_replay(here, td, path, fmt, rate, fo, fr, n):
+    """The literal drop-in over the very file the CPU reference was just timed on: oracle/_ref/ref_rtl_gpu = the same harness
+    (producer converting blocks of RTLINBUFSZ into Cbuff, two barriers per block) with the reference's UNCHANGED vdlm2.c /
+    rs.c / crc.c behind dropin/vdl2gpu_rcv.c + libvdl2gpu.so instead of d8psk.c / viterbi.c.  The harness reports the time from
+    the first hand-off to the last burst delivered (process start and HIP initialisation are not replay time)."""
+    import re
+    import subprocess
+    exe = os.path.join(here, "oracle", "_ref", "ref_rtl_gpu")
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = os.path.join(td, "out_gpu.txt")
+    best = None
+    try:
+        for _ in range(3):
+            r = subprocess.run([exe, path, fmt, str(rate), fo, fr, out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=180, env=env)
+            m = re.search(r"replay (\d+) samples ([0-9.]+) s", r.stderr or "")
+            if r.returncode or not m:
+                return {"error": (r.stderr or "")[-300:]}
+            ns, sec = int(m.group(1)), float(m.group(2))
+            if best is None or sec < best[1]:
+                best = (ns, sec)
+        nb = sum(1 for ln in open(out) if ln.startswith("B"))
+        nf = sum(1 for ln in open(out) if ln.startswith("F"))
+    except (subprocess.SubprocessError, OSError) as e:
+        return {"error": repr(e)}
+    return {"value": best[0] / best[1] / 1e6, "unit": "MS/s", "samples": best[0], "seconds": best[1], "bursts": nb, "frames": nf,
+            "what": "oracle/_ref/ref_rtl_gpu (the reference's unchanged host path behind the drop-in shim) over the file the CPU reference was timed on, "
+                    "best of 3; first Cbuff hand-off -> last burst through decodeVdlm2(); the producer (sample conversion into Cbuff, two barriers "
+                    "per 32768 samples, rtl.c:283-294) is the harness's, on one host thread: it bounds the figure (see DESIGN.md)"}
 
 
 def oracle_stream(tiles, fmt: str, rate: int, fos, ntiles: int, order=None):
@@ -273,7 +307,8 @@ def oracle_streams(tiles, fmt, rate, fos, ntiles, order=None):
     return [r[0] for r in res], max(r[1] for r in res)
 
 
-def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, steps, warmup, seed0, check_streams=4):
+def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, steps, warmup, seed0, check_streams=4, stream_base=0, fence=None,
+            want_records=False):
     """One more workload inside the same `bench.py --gpus 1` run (the `configs` object of the JSON line): resident input,
     pushes of ntiles x 4.2 MS per stream, bursts delivered to the host -- measured like the headline (pipelined, everything
     drained before the clock stops) and checked like it: every burst of the WHOLE run (first push included) against the
@@ -291,7 +326,8 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     NBUF = 2
     nvar = min(16 if nstr == 1 else 4, ntiles)        # different recordings in turn (see tile_order): no recording twice in a push of one stream (several
                                                           # streams: four each -- 128 recordings would take the leg's synthesis past a minute)
-    flat = make_variants([seed0 + g + 1000 * v for g in range(nstr) for v in range(nvar)], fmt, rate, fos, bursts_per_s)
+    # (stream_base: the global index of this rank's first stream in an N > 1 run -- every stream of the job has its own recordings)
+    flat = make_variants([seed0 + stream_base + g + 1000 * v for g in range(nstr) for v in range(nvar)], fmt, rate, fos, bursts_per_s)
     variants = [flat[g * nvar:(g + 1) * nvar] for g in range(nstr)]
     order = lambda i: tile_order(i, ntiles, NBUF, nvar)
     dbufs = device_buffers(variants, ntiles, NBUF, dev)
@@ -332,6 +368,8 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
             drain(False)
         rx.sync()
         torch.cuda.synchronize(dev)
+        if fence:
+            fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             push()
@@ -340,6 +378,8 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
         drain(False)
         rx.sync()
         torch.cuda.synchronize(dev)
+        if fence:
+            fence()
         dt = time.perf_counter() - t0
         slow = [sync_push() for _ in range(3)]
         st = rx.stats()
@@ -371,7 +411,12 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
     equal = bad == 0 and nb > 0
     value = nstr * batch * steps / dt / 1e6
     dec_total = st["dec_samples"] * 8 * nstr
-    return {"workload": workload, "value": value if equal else None, "unit": "MS/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+    extra = {}
+    if want_records:       # for the gather of an N > 1 run: this rank's records with GLOBAL stream indices, and its wall time
+        pk = got[tidx < t_hi].copy()
+        pk["stream"] += stream_base
+        extra = {"_records": pk, "_dt": dt}
+    return {**extra, "workload": workload, "value": value if equal else None, "unit": "MS/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "warmup": warmup, "fmt": fmt, "sdrinrate": rate, "streams": nstr, "channels": 8 * nstr, "samples_per_step": batch * nstr,
             "bursts_per_s_per_channel_offered": bursts_per_s, "recordings_per_stream": nvar, "bursts_per_step": int(round(nrec / max(1, npush))),
             "first_push_ms": first_ms, "max_push_ms": max(slow),
@@ -435,6 +480,37 @@ def live_leg(local=0, nblocks=300, paced=True, nslots=8, bursts_per_s=8.0, seed=
             "parity": {"equal": equal, "bursts_checked": len(want), "what": "every burst of the run vs the oracle over the same recording"}}
 
 
+def ring_rate(local, rate, fos, fmt, batch, recs, ntiles):
+    """PCIe-inclusive rate for one format: pushes of `batch` samples from page-locked ring slots, bursts delivered."""
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    buf = (_lib.BurstT * 16384)()
+    raw = np.concatenate([recs[k % len(recs)] for k in range(ntiles)]).view(np.uint8).reshape(1, -1)
+    with Receiver(rate, plan_channels(FC, fos), fmt=fmt, max_push=batch, device=local, max_bursts=1 << 18) as rx:
+        rx.ring_init(batch, nslots=3)
+        nb = batch * rx.sample_bytes
+        for _ in range(3):
+            slot = rx.ring_acquire()
+            slot[:, :nb] = raw[:, :nb]
+            rx.ring_commit(batch)
+        while rx.poll_raw(buf, 16384) == 16384:
+            pass
+        rx.sync()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            rx.ring_acquire()
+            rx.ring_commit(batch)
+            while rx.poll_ready_raw(buf, 16384) == 16384:
+                pass
+        while rx.poll_raw(buf, 16384) == 16384:
+            pass
+        rx.sync()
+        dt = time.perf_counter() - t0
+    return {"value": 6 * batch / dt / 1e6, "unit": "MS/s", "pushes": 6, "fmt": fmt, "bytes_per_sample": 2 if fmt == "cu8" else 4,
+            "host_GBps": 6 * batch * (2 if fmt == "cu8" else 4) / dt / 1e9,
+            "note": "as host_ring, for the reference's native cu8 (rtl.c:285-292): half the bytes per sample over the same link"}
+
+
 def extra_legs(local):
     """The `configs` object: configs[2], the per-GPU share of configs[3], configs[1] on busy channels, configs[4]."""
     from vdlm2dec_amd import synth
@@ -466,8 +542,8 @@ def respawn(args, argv):
     """`python bench.py --gpus N` on its own: become N ranks."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
-        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (no CPU fallback, no oversubscription)")
+    if have < (1 if args.share_gpu else args.gpus):
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (no CPU fallback; ranks share a GPU only with --backend gloo --share-gpu)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -496,7 +572,14 @@ def main():
     ap.add_argument("--no-ring", action="store_true", help="skip the PCIe-inclusive extra pass (ingest ring from pinned host memory)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `configs` object (configs[2], [3]-share, busy channels, [4] live ring)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process group of an N > 1 run: nccl (= RCCL over xGMI, the default) or gloo (host sockets; with --share-gpu it lets the "
+                         "whole N > 1 path run on a box with ONE GPU: RCCL refuses two ranks on one device)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (needs --backend gloo): the multi-rank path on a one-GPU box")
+    ap.add_argument("--gather-out", default="", help="rank 0 writes the gathered records of the timed region here (.npy, shard.REC_DTYPE): for tests")
     args = ap.parse_args()
+    if args.share_gpu and args.backend != "gloo":
+        sys.exit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn(args, sys.argv[1:])
 
@@ -512,12 +595,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu:
+        local = 0
     if torch.cuda.device_count() <= local:
         sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)")
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     dev = torch.device("cuda", local)
+    cdev = dev if (world > 1 and args.backend == "nccl") else torch.device("cpu")     # where the collectives' tensors live
 
     cfg = CONFIGS[args.config]
     rate = args.rate or cfg["rate"]
@@ -607,8 +696,10 @@ def main():
     fence()
     host_s[0] = host_s[1] = 0.0
     t0 = time.perf_counter()
+    t_steps = []
     for _ in range(args.steps):
         step(True)
+        t_steps.append(time.perf_counter())
     drain(False)                        # every burst of every step is on the host before the clock stops
     rx.sync()
     fence()
@@ -629,7 +720,15 @@ def main():
     # also outside the timed region: the same hand-off from page-locked host memory through the ingest ring (SURVEY 8
     # f-2) -- the PCIe-inclusive rate.  Reported beside `value`, never as `value`.
     host_ring = None
+    host_ring_cu8 = None
     if rank == 0 and world == 1 and not args.no_ring and args.config == 2:
+        try:
+            if args.fmt == "cs16":      # the reference's native RTL format through the same ring, on a handle of its own (2 bytes per sample)
+                host_ring_cu8 = ring_rate(local, rate, fos, "cu8", batch, [v for v in make_variants([4321 + k for k in range(4)], "cu8", rate, fos, args.bursts_per_s)], ntiles)
+            else:
+                host_ring_cu8 = None
+        except Exception as e:
+            host_ring_cu8 = {"error": str(e)}
         try:
             hb = dbufs[0].cpu().numpy().view(np.uint8).reshape(nstr, -1)
             rx.ring_init(batch, nslots=3)
@@ -696,10 +795,10 @@ def main():
 
     # ---- collection across ranks: counts, verdicts, and the packed records on rank 0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        okt = torch.tensor([1 if ok_local else 0], device=dev, dtype=torch.int32)
+        okt = torch.tensor([1 if ok_local else 0], device=cdev, dtype=torch.int32)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok_all = bool(okt.item())
         g = shard.run_sharded(nstreams_total, lambda idx: shard.pack_records(timed, stream_offset=idx.start))
@@ -708,11 +807,16 @@ def main():
         # counts + per-rank digests reach every rank (40 bytes each); the records only rank 0, point to point in chunks
         gathered = {"records_on_rank0": int(len(allrecs)), "per_rank": counts,
                     "digest": shard.digest(allrecs).hex()[:16] if rank == 0 else None,
-                    "digest_of_rank_digests": g.combined.hex()[:16]}
+                    "digest_of_rank_digests": g.combined.hex()[:16], "backend": args.backend,
+                    "ranks_share_one_gpu": bool(args.share_gpu)}
+        if rank == 0 and args.gather_out:
+            np.save(args.gather_out, allrecs)
     else:
         ok_all = ok_local
         total_bursts = int(len(timed))
         gathered = None
+        if args.gather_out:
+            np.save(args.gather_out, shard.pack_records(timed))
 
     rc = 0
     if rank == 0:
@@ -737,13 +841,36 @@ def main():
         iso_ms = tm_iso["channelise_fast_ms"] / max(1, tm_iso["fast_pushes"])
         value = world * nstr * batch * args.steps / dt / 1e6
         ms_step = dt / args.steps * 1e3
-        traffic = None
+        # Steady state: `value` is defined over exactly --steps steps between two fences, so it contains the pipeline's fill and drain
+        # (three pushes deep: about two steps' worth, 7 % of a 20-step run and 4 % of a 32-step one).  vdl2gpu_push() returns when
+        # the push is enqueued and -- three being in flight -- the push three back has been collected, so the times the calls
+        # return, from the fourth step to the last, are the pipeline's own rate whatever --steps is.
+        steady = None
+        if len(t_steps) >= 8:
+            ss_ms = (t_steps[-1] - t_steps[3]) / (len(t_steps) - 4) * 1e3
+            steady = {"ms_per_step": ss_ms, "value": world * nstr * batch / (ss_ms * 1e-3) / 1e6, "unit": "MS/s", "steps_used": len(t_steps) - 4,
+                      "definition": "(return of the last vdl2gpu_push+poll_ready - return of the fourth) / steps between them: the pipelined rate without the fill "
+                                    "and the final drain that `value` (exactly --steps steps between two fences, the contract's figure) contains"}
+        traffic, traffic_src, whole_step = None, None, None
         try:
-            pmf = [f for f in ("r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            pmf = [f for f in ("r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
             if args.config == 2 and not args.tiles and args.fmt == "cs16" and not args.rate and not args.streams:
                 fk = [k for k in pm["FETCH_SIZE_KB_per_launch"] if kname in k][0]
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"][fk] + pm["WRITE_SIZE_KB_per_launch"][fk]) * 1024.0
+                traffic_src = f"profiles/{pmf}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command (2 x FETCH_SIZE + WRITE_SIZE per launch, the gfx950 " \
+                              "correction of MI355X_MICROARCH.md), replayed from the committed file -- PMC counters cannot be read by the run itself"
+                # the whole step from the same committed passes: every kernel's HBM traffic and vector instructions, launches per step as in the trace
+                sqf = pmf.replace("_hbm", "_sq")
+                sq = json.load(open(os.path.join(ROOT, "profiles", sqf)))["per_launch"]
+                per_step = pm.get("launches_per_step", {})
+                hbm = sum((2.0 * pm["FETCH_SIZE_KB_per_launch"].get(k, 0.0) + pm["WRITE_SIZE_KB_per_launch"].get(k, 0.0)) * 1024.0 * per_step.get(k, 1.0)
+                          for k in pm["FETCH_SIZE_KB_per_launch"])
+                vinst = sum(v.get("SQ_INSTS_VALU", 0.0) * per_step.get(k, 1.0) for k, v in sq.items())
+                floor_ms = vinst * 4 / 1024 / 2.4e9 * 1e3
+                whole_step = {"valu_wave_insts": vinst, "valu_floor_ms": floor_ms, "hbm_traffic_bytes": hbm, "step_over_valu_floor": ms_step / floor_ms if floor_ms > 0 else None,
+                              "hbm_traffic_over_algorithmic": hbm / (batch * nstr * sample_bytes) if batch else None,
+                              "source": f"profiles/{sqf} (SQ_INSTS_VALU) and profiles/{pmf}, kernels x launches per step; 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz"}
         except (OSError, KeyError, ValueError, IndexError):
             pass
         parity_ok = ok_all or args.no_parity
@@ -766,7 +893,10 @@ def main():
             "value": value if parity_ok else None, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"] + ("" if not (args.rate or args.streams or args.tiles or args.bursts_per_s != 4.0) else
+            "steady_state": steady,
+            "config": {"workload": (cfg["workload"] if world == 1 else
+                                    (f"{world} x configs[1]: one 8-channel 2 MS/s stream per GPU, {world} GPUs, stream-sharded (weak scaling; the 512-channel job is configs.config4_512ch)"
+                                     if args.config == 2 else cfg["workload"] + f" -- {world} of 8 GPUs" * (world != 8))) + ("" if not (args.rate or args.streams or args.tiles or args.bursts_per_s != 4.0) else
                                                        f" [overridden: {nstr} stream(s)/GPU, {rate / 1e6:g} MS/s, {ntiles} tiles, {args.bursts_per_s:g} bursts/s/channel offered]"),
                        "fmt": args.fmt, "samples_per_step": batch * nstr, "air_time_s_per_step": batch / rate,
                        "channels": 8, "streams_per_gpu": nstr, "streams_total": nstreams_total, "sdrinrate": rate,
@@ -777,7 +907,8 @@ def main():
                        "input_note": f"{nvar} different synthetic recordings of {TILE / rate:.1f} s per stream, in turn; the {NBUF} device "
                                      "buffers pushed in turn start one recording apart (bench.py tile_order)"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_from_profiles": traffic,
+                         "whole_step": whole_step,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
                          "whole_path_frac": (batch * nstr * sample_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
                          "valu_issue": valu,
@@ -790,8 +921,7 @@ def main():
                                  "kernel takes longer here than alone (`alone`) while the step as a whole got shorter; algorithmic bytes = sample "
                                  "bytes x samples, read once for all 8 channels; the kernel also writes the 84 kS/s planes (2.7 B per "
                                  "input sample at 2 MS/s), which is intermediate traffic, not algorithmic (SURVEY.md 8d); `traffic` is "
-                                 "not measured by this run (PMC counters need rocprofv3): traffic_from_profiles is the committed "
-                                 "measurement of this command (profiles/r03_bench_pmc_hbm.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"},
+                                 "a REPLAY of the committed rocprofv3 PMC passes over this command (traffic_source), not a measurement of this run"},
             "kernels_ms": {"k1_channelise": k1_ms, "k2a_scan": k2a_ms, "k2b_clusters": k2b_ms,
                            "k2c_resolve+k2d_gather": k2c_ms, "k3_compact": k3_ms, "demod_chain": k2_ms,
                            "note": "kernel intervals from HIP events; the front stage of one push (channeliser, scan) runs beside the back "
@@ -812,6 +942,8 @@ def main():
                              "frames are collected like the bursts: what is ready after every push, everything before the clock stops"}
         if host_ring is not None:
             out["host_ring"] = host_ring
+        if host_ring_cu8 is not None:
+            out["host_ring_cu8"] = host_ring_cu8
         if os.environ.get("VDL2GPU_DEBUG_COUNTERS") or os.environ.get("VDL2GPU_K1_PROF"):
             out["dbg"] = rx.debug_counters(64)
         if not args.no_cpu and world == 1:
@@ -826,11 +958,50 @@ def main():
             print("bench.py: PARITY FAILED -- value withheld", file=sys.stderr)
             rc = 1
     rx.close()
+    leg4 = None
+    if world > 1 and args.config == 2 and not args.no_extra and not (args.rate or args.streams):
+        # configs[3] across ALL ranks: 8 streams x 8 channels per rank (64 streams = 512 channels on 8 GPUs), every stream its own
+        # recordings, the timed region fenced across the ranks, results collected as SURVEY 8e says.  (The headline above stays the
+        # config-2 workload per GPU, so that an N = 1 line and BENCH agree.)
+        del dbufs
+        torch.cuda.empty_cache()
+        from vdlm2dec_amd import synth as _sy
+        lt = args.tiles or 16
+        leg = run_leg("config4_512ch", workload=CONFIGS[4]["workload"], local=local, rate=2_000_000, fos=_sy.DEFAULT_FO_8CH, fmt="cs16", nstr=8,
+                      ntiles=lt, bursts_per_s=4.0, steps=min(6, args.steps), warmup=min(3, max(1, args.warmup)), seed0=1234, check_streams=2,
+                      stream_base=8 * rank, fence=fence, want_records=True)
+        recs4, dt4 = leg.pop("_records"), leg.pop("_dt")
+        t = torch.tensor([dt4], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        okt = torch.tensor([1 if leg["parity"]["equal"] else 0], device=cdev, dtype=torch.int32)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        g4 = shard.run_sharded(8 * world, lambda idx: recs4)
+        if rank == 0:
+            all_ok = bool(okt.item())
+            leg4 = dict(leg)
+            leg4.update({"workload": CONFIGS[4]["workload"] + (f" -- here {world} of the 8 GPUs: {8 * world} streams, {64 * world} channels" if world != 8 else ""),
+                         "value": (8 * world * lt * TILE * leg["steps"] / float(t.item()) / 1e6) if all_ok else None, "unit": "MS/s",
+                         "ms_per_step": float(t.item()) / leg["steps"] * 1e3, "n_gpus": world, "streams": 8 * world, "channels": 64 * world,
+                         "samples_per_step": 8 * world * lt * TILE, "rank0": {k: leg[k] for k in ("first_push_ms", "max_push_ms", "repairs", "serial_redos")},
+                         "gather": {"records_on_rank0": int(len(g4[0])), "per_rank": g4[1], "digest": shard.digest(g4[0]).hex()[:16],
+                                    "digest_of_rank_digests": g4.combined.hex()[:16], "backend": args.backend, "ranks_share_one_gpu": bool(args.share_gpu)},
+                         "parity": {**leg["parity"], "equal": all_ok, "what": "every rank checks two of its eight streams burst for burst against the oracle; verdicts MIN-reduced"}})
+            if args.gather_out:
+                np.save(args.gather_out.replace(".npy", "") + "_config4.npy", g4[0])
     if rank == 0:
+        if leg4 is not None:
+            out.setdefault("configs", {})["config4_512ch"] = leg4
+            if leg4["value"] is None:
+                rc = 1
         if world == 1 and not args.no_extra and args.config == 2 and not (args.rate or args.streams or args.tiles):
             del dbufs
             torch.cuda.empty_cache()
             out["configs"] = extra_legs(local)
+            if isinstance(out.get("cpu_baseline"), dict) and out["cpu_baseline"].get("dropin_replay") is not None:
+                dr = out["cpu_baseline"].pop("dropin_replay")
+                if isinstance(dr, dict) and dr.get("value"):
+                    dr["over_cpu_reference"] = dr["value"] / out["cpu_baseline"]["value"]
+                out["configs"]["dropin_replay"] = dr
             if any(isinstance(v, dict) and (v.get("parity") or {}).get("equal") is False for v in out["configs"].values()):
                 print("bench.py: a `configs` leg differs from the oracle -- its value is withheld", file=sys.stderr)
                 rc = 1

@@ -26,10 +26,12 @@
  *
  * This file contains no DSP.  It is compiled against the reference's own vdlm2.h.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <complex.h>
 #include "vdlm2.h"
 #include "vdl2gpu.h"
 
@@ -62,6 +64,23 @@ static struct timeval stamp_of(long long sample)
 }
 static volatile int g_ready;	/* channels initialised so far (channel 0 must be first, vdlm2.c:172) */
 
+/* Hand-offs of Cbuff are collected in a slot of the library's ingest ring (page-locked memory) and the slot is committed when
+ * it is full or the GPU is about to run out of work (vdl2gpu_inflight() <= 1): a live source is committed block by block, a file
+ * replay in pushes of BATCH_BLOCKS blocks -- the pipeline behind the ring wants pushes of a million samples to run at its rate,
+ * and a hand-off is 32768.  Bursts are collected with the never-waiting call after every hand-off [round 3: the waiting
+ * vdl2gpu_poll(), one pipeline drain per 32768 samples: the CPU reference's own 133 MS/s]; vdl2gpu_rcv_flush() -- for the
+ * program's shutdown path, next to stopVdlm2() (main.c:106-110) -- commits what is collected and waits for the rest. */
+#define BATCH_BLOCKS 64
+static vdl2gpu_t *g_h;
+static char *g_slot;		/* the slot being filled, or NULL */
+static size_t g_fill;		/* samples in it */
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;	/* deliver() and the slot: the feeding thread against vdl2gpu_rcv_flush() */
+#ifdef WITH_RTL
+#define SAMPLE_BYTES sizeof(complex float)
+#else
+#define SAMPLE_BYTES sizeof(float)
+#endif
+
 int initD8psk(channel_t *ch)
 {
 	(void)ch;
@@ -69,13 +88,13 @@ int initD8psk(channel_t *ch)
 }
 
 #ifdef VDL2GPU_FRAMES
-static void deliver(vdl2gpu_t *h)
+static void deliver(vdl2gpu_t *h, int wait)
 {
 	static vdl2gpu_burst_t b[64];
 	static vdl2gpu_frame_t f[128];
 	static msgblk_t blk;	/* what out() reads of it: chn, Fr, tv, ppm, nbrow, nlbyte */
 	int n, nf, i, dropped = 0;
-	while ((n = vdl2gpu_poll(h, b, 64)) > 0) {
+	while ((n = wait ? vdl2gpu_poll(h, b, 64) : vdl2gpu_poll_ready(h, b, 64)) > 0) {
 		nf = vdl2gpu_decode_blocks(h, b, n, f, 128, &dropped);
 		if (dropped)	/* more frames than the buffer holds (or than 12 in one burst): never silent */
 			fprintf(stderr, "vdl2gpu_decode_blocks: %d frame(s) dropped\n", dropped);
@@ -94,11 +113,11 @@ static void deliver(vdl2gpu_t *h)
 		fprintf(stderr, "vdl2gpu_poll: %s\n", vdl2gpu_strerror(n));
 }
 #else
-static void deliver(vdl2gpu_t *h)
+static void deliver(vdl2gpu_t *h, int wait)
 {
 	static vdl2gpu_burst_t b[64];
 	int n, i;
-	while ((n = vdl2gpu_poll(h, b, 64)) > 0) {
+	while ((n = wait ? vdl2gpu_poll(h, b, 64) : vdl2gpu_poll_ready(h, b, 64)) > 0) {
 		for (i = 0; i < n; i++) {
 			channel_t *ch = &g_ch[b[i].chn];
 			vdl2gpu_burst_to_msgblk(&b[i], ch->blk, sizeof(msgblk_t));
@@ -114,6 +133,28 @@ static void deliver(vdl2gpu_t *h)
 }
 
 #endif
+
+static void commit_slot(void)
+{
+	if (g_slot && g_fill) {
+		const int rc = vdl2gpu_ring_commit(g_h, g_fill);
+		if (rc)
+			fprintf(stderr, "vdl2gpu_ring_commit: %s (%s)\n", vdl2gpu_strerror(rc), vdl2gpu_last_error(g_h));
+		g_slot = NULL;
+		g_fill = 0;
+	}
+}
+
+/* End of stream / shutdown: decode what has been handed over so far and pass every burst on.  Safe from any thread. */
+void vdl2gpu_rcv_flush(void)
+{
+	pthread_mutex_lock(&g_mu);
+	if (g_h) {
+		commit_slot();
+		deliver(g_h, 1);
+	}
+	pthread_mutex_unlock(&g_mu);
+}
 
 void *rcv_thread(void *arg)
 {
@@ -155,28 +196,50 @@ void *rcv_thread(void *arg)
 		cfg.nbch = nbch;
 		cfg.nstreams = 1;
 		cfg.chan = plan;
-		cfg.max_push = RTLINBUFSZ / 2;
+		cfg.max_push = (size_t)BATCH_BLOCKS * (RTLINBUFSZ / 2);
 		rc = vdl2gpu_create(&cfg, &h);
 		if (rc) {
 			fprintf(stderr, "vdl2gpu_create: %s\n", vdl2gpu_strerror(rc));
 			exit(1);
 		}
+		rc = vdl2gpu_ring_init(h, cfg.max_push, 4);
+		if (rc) {
+			fprintf(stderr, "vdl2gpu_ring_init: %s\n", vdl2gpu_strerror(rc));
+			exit(1);
+		}
+		pthread_mutex_lock(&g_mu);
+		g_h = h;
+		pthread_mutex_unlock(&g_mu);
 	}
 
 	pthread_barrier_wait(&Bar1);
 	for (;;) {
 		pthread_barrier_wait(&Bar2);
 		if (h) {
-			/* returns once Cbuff has been copied out; demodulation continues asynchronously */
-			int rc;
+			/* Cbuff is copied out before the producer is let go; demodulation happens asynchronously */
+			pthread_mutex_lock(&g_mu);
 			stamp_push(RTLINBUFSZ / 2);
-			rc = vdl2gpu_push(h, Cbuff, RTLINBUFSZ / 2, 0, VDL2GPU_MEM_HOST);
-			if (rc)
-				fprintf(stderr, "vdl2gpu_push: %s (%s)\n", vdl2gpu_strerror(rc), vdl2gpu_last_error(h));
+			if (!g_slot) {
+				size_t stride;
+				g_slot = vdl2gpu_ring_acquire(h, &stride);
+				g_fill = 0;
+				if (!g_slot)
+					fprintf(stderr, "vdl2gpu_ring_acquire: %s\n", vdl2gpu_last_error(h));
+			}
+			if (g_slot) {
+				memcpy(g_slot + g_fill * SAMPLE_BYTES, (const void *)Cbuff, (RTLINBUFSZ / 2) * SAMPLE_BYTES);
+				g_fill += RTLINBUFSZ / 2;
+			}
+			pthread_mutex_unlock(&g_mu);
 		}
 		pthread_barrier_wait(&Bar1);	/* producer may refill Cbuff */
-		if (h)
-			deliver(h);
+		if (h) {
+			pthread_mutex_lock(&g_mu);
+			if (g_fill >= (size_t)BATCH_BLOCKS * (RTLINBUFSZ / 2) || vdl2gpu_inflight(h) <= 1)	/* (two pushes side by side keep the pipeline's stages busy) */
+				commit_slot();
+			deliver(h, 0);
+			pthread_mutex_unlock(&g_mu);
+		}
 	}
 	return NULL;
 }

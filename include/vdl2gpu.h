@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VDL2GPU_ABI_VERSION 4	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_*; 4: vdl2gpu_stats_t.repairs */
+#define VDL2GPU_ABI_VERSION 5	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_*; 4: vdl2gpu_stats_t.repairs; 5: vdl2gpu_inflight, the handle lock ("Threads") */
 #define VDL2GPU_MAXCH 8		/* MAXNBCHANNELS vdlm2.h:26 */
 #define VDL2GPU_MAXROWS 8	/* bursts with more rows are rejected, d8psk.c:103 */
 #define VDL2GPU_ROWLEN 255
@@ -159,6 +159,27 @@ int vdl2gpu_abi_version(void);
 int vdl2gpu_create(const vdl2gpu_config_t *cfg, vdl2gpu_t **out);
 void vdl2gpu_destroy(vdl2gpu_t *h);
 
+/* ---- Threads ------------------------------------------------------------------------------------------------
+ * A handle may be used from several threads at once.  The reference has a producer thread -- the SDR library's callback,
+ * in_callback() under rtlsdr_read_async() (rtl.c:274-295, 302) / rx_callback() (air.c:191-217) -- and consumer threads behind
+ * it (main.c:225-231, vdlm2.c:84); a shim built on this library keeps that shape on ONE handle:
+ *   - every call that takes a vdl2gpu_t* locks the handle for its duration; calls from different threads are serialised, none is
+ *     lost, and each burst / frame record is handed out exactly once, whichever thread asks;
+ *   - PRODUCER side: vdl2gpu_push(), or vdl2gpu_ring_acquire() / vdl2gpu_ring_commit().  One producer at a time: acquire and
+ *     commit alternate, and pushes are decoded in the order the calls were made.  A producer call holds the lock while it
+ *     enqueues (~0.1 ms) and, when three pushes are already in the pipeline, while it waits for the oldest of them;
+ *   - CONSUMER side: vdl2gpu_poll_ready() / vdl2gpu_poll_frames_ready() never wait.  vdl2gpu_poll(), vdl2gpu_poll_frames() and
+ *     vdl2gpu_pending() wait for everything that was pushed BEFORE the call -- with the lock released while they wait for the
+ *     GPU, so a producer thread keeps committing blocks meanwhile (what it commits after the call began is not waited for);
+ *   - per (stream, channel) the bursts come out in time order across calls, as decodeVdlm2() receives them (d8psk.c:201);
+ *   - vdl2gpu_sync(), vdl2gpu_get_stats(), vdl2gpu_get_timing() and the vdl2gpu_debug_*() calls drain the pipeline under the
+ *     lock: fine from any thread, but they hold the others up for that long;
+ *   - vdl2gpu_last_error()'s string is valid until the next call on the handle from any thread;
+ *   - vdl2gpu_destroy() must not run beside any other call on the handle (join the threads first);
+ *   - different handles share nothing.
+ * tests/ctests/thread_stress.c is this shape (one pthread committing ring slots, one collecting), held to the oracle ten times
+ * over by tests/test_gpu_dropin.py. */
+
 /* Feed `nsamples` samples of every stream.  Stream s starts at
  * (const char*)iq + s*stream_stride_bytes.  Asynchronous: returns once the
  * work is enqueued on the handle's HIP stream.  Replaces one Bar2/Bar1
@@ -201,6 +222,11 @@ int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Number of bursts a poll would currently return (implies vdl2gpu_sync). */
 int vdl2gpu_pending(vdl2gpu_t *h);
+/* Pushes the GPU has not finished yet (0..3); never waits.  Lets a producer that is not bound to real time batch: the
+ * drop-in (dropin/vdl2gpu_rcv.c) collects the 32768-sample hand-offs of Cbuff in a ring slot and commits the slot when it is
+ * full OR the pipeline is idle -- a live source (a block every 16 ms) is committed block by block with no added latency, a file
+ * replay in pushes of a million samples, which is what the pipeline needs to run at its rate. */
+int vdl2gpu_inflight(vdl2gpu_t *h);
 
 int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out);
 int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset);

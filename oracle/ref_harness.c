@@ -38,6 +38,7 @@
 #include <pthread.h>
 #include <complex.h>
 #include <sys/time.h>
+#include <time.h>
 #include "vdlm2.h"
 
 unsigned int SDRINRATE = 2000000;
@@ -225,6 +226,8 @@ int main(int argc, char **argv)
 	}
 #endif
 	unsigned char *raw = malloc(ssz * NB);
+	struct timespec t_replay0;
+	clock_gettime(CLOCK_MONOTONIC, &t_replay0);
 	for (;;) {
 		size_t got = fread(raw, ssz, NB, f);
 		if (got != (size_t) NB)
@@ -263,7 +266,15 @@ int main(int argc, char **argv)
 	}
 	pthread_barrier_wait(&Bar1);	/* consumer finished the last block */
 #ifdef VDL2GPU_DROPIN
-	usleep(200000);			/* the drop-in delivers after Bar1: let it hand the last bursts over */
+	{
+		extern void vdl2gpu_rcv_flush(void);	/* dropin/vdl2gpu_rcv.c: the shutdown path's call, next to stopVdlm2() */
+		struct timespec t1;
+		vdl2gpu_rcv_flush();
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		/* file replay through the drop-in, first hand-off to last burst delivered (bench.py's dropin_replay leg reads this) */
+		fprintf(stderr, "replay %llu samples %.6f s\n", (unsigned long long)sample_clock,
+			(double)(t1.tv_sec - t_replay0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t_replay0.tv_nsec));
+	}
 #endif
 	/* drain blk_thread: every enqueued block is freed at vdlm2.c:157 */
 	int spins = 0;

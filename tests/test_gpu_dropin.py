@@ -114,3 +114,32 @@ def test_c_speed_caller_ring_and_frames_are_deterministic(built, oracle, tmp_pat
                              ["32768", "3"], capture_output=True, text=True, env=env, timeout=120)
         assert out.returncode == 0, out.stderr[-2000:]
         assert sorted(out.stdout.split("\n")[:-1]) == want, rep
+
+
+def test_producer_and_consumer_threads_on_one_handle(built, oracle, tmp_path):
+    """The reference's threading shape (include/vdl2gpu.h "Threads"): one pthread commits blocks through the ingest ring like
+    the SDR library's callback (rtl.c:274-295, 302), another collects bursts meanwhile with vdl2gpu_poll_ready() and, every
+    eighth turn, the waiting vdl2gpu_poll() -- which must not hold the producer up and must not lose or reorder anything.  Ten
+    runs, every one the oracle's bursts, each channel's in time order."""
+    import scenarios as S
+    from vdlm2dec_amd import synth
+    from vdlm2dec_amd.lib import LIB_PATH
+    exe = str(tmp_path / "thread_stress")
+    subprocess.check_call(["gcc", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "ctests", "thread_stress.c"), LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(LIB_PATH)])
+    spec = synth.random_scenario(2_000_000, S.FO8[:4], 3_000_000, seed=815, bursts_per_s=30.0, info_max=200)
+    raw = synth.synth_stream(spec, "cu8")
+    iq = str(tmp_path / "iq.raw")
+    raw.tofile(iq)
+    ob = oracle.run_oracle(raw, "cu8", spec.rate, spec.fo, S.FC)
+    want = sorted("B %d %d %d %016x" % (b.chn, b.nbrow, b.nlbyte, _fnv(bytes(b.data[:b.nbrow * 255]))) for b in ob)
+    assert len(want) >= 40
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for rep in range(10):
+        blk, slots = (("32768", "3"), ("65536", "4"), ("8000", "8"))[rep % 3]
+        out = subprocess.run([exe, iq, "cu8", str(spec.rate), str(len(spec.fo))] + [str(f) for f in spec.fo] + [blk, slots],
+                             capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert sorted(out.stdout.split("\n")[:-1]) == want, rep

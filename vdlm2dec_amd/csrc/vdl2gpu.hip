@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -50,6 +51,11 @@ struct PushTiming {
 };
 
 struct vdl2gpu {
+	/* Every public call on the handle takes this lock (see "Threads" in include/vdl2gpu.h): the reference's shape -- the SDR
+	 * library's callback thread committing blocks (rtl.c:274-295, 302) while another thread collects msgblk_t's -- works on one
+	 * handle.  Recursive because public calls use each other (get_stats -> sync ...).  The blocking collectors release it while
+	 * they wait for the GPU (wait_harvest). */
+	std::recursive_mutex mu;
 	vdl2gpu_config_t cfg;
 	std::vector<vdl2gpu_chan_t> chans;
 	int S, C, L, maxwin, sdrclk;
@@ -161,6 +167,7 @@ struct vdl2gpu {
 									 * one more than rings, so that a ring collected at the last moment -- by the call that is about to reuse it -- still lies
 									 * untouched in its slab while the caller polls once more, instead of being copied aside at once */
 	int ring_slab[VDL2_NRING] = {0, 0, 0};	/* the slab of the push that filled the ring */
+	size_t slab_lo[VDL2_NSLAB] = {0, 0, 0, 0}, slab_hi[VDL2_NSLAB] = {0, 0, 0, 0};	/* ready_idx[lo, hi): where the handles into each slab lie (a push's are contiguous) */
 	unsigned slab_cap = 0;
 	size_t ready_pos = 0;
 	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
@@ -396,9 +403,14 @@ extern "C" const char *vdl2gpu_strerror(int code)
 	}
 }
 
+#define HLOCK(h) std::unique_lock<std::recursive_mutex> hlock_((h)->mu)
+
 extern "C" const char *vdl2gpu_last_error(vdl2gpu_t *h)
 {
-	return h ? h->err.c_str() : "null handle";
+	if (!h)
+		return "null handle";
+	HLOCK(h);
+	return h->err.c_str();	/* (valid until the next call on the handle, from any thread) */
 }
 
 /* msgblk_t, vdlm2.h:39-47, LP64: prev@0(8) chn@8 Fr@12 tv@16(16) ppm@32 nbrow@36 nlbyte@40 data@44 */
@@ -1032,6 +1044,9 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 
 extern "C" int vdl2gpu_push(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind)
 {
+	if (!h)
+		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	/* the caller may reuse a host buffer as soon as we return (the reference's producer refills Cbuff
 	 * right after the consumers pass Bar1, d8psk.c:383): wait for the copy, not for the kernels */
 	return push_checked(h, iq, nsamples, stream_stride_bytes, memkind, true);
@@ -1042,6 +1057,7 @@ extern "C" int vdl2gpu_ring_init(vdl2gpu_t *h, size_t slot_samples, int nslots)
 {
 	if (!h || slot_samples == 0 || slot_samples > h->cfg.max_push || nslots < 2 || nslots > 64)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	if (h->ring_host) {
 		h->err = "vdl2gpu_ring_init: the ring exists already";
 		return VDL2GPU_EINVAL;
@@ -1060,7 +1076,10 @@ extern "C" int vdl2gpu_ring_init(vdl2gpu_t *h, size_t slot_samples, int nslots)
 
 extern "C" void *vdl2gpu_ring_acquire(vdl2gpu_t *h, size_t *stream_stride_bytes)
 {
-	if (!h || !h->ring_host || h->ring_acquired)
+	if (!h)
+		return nullptr;
+	HLOCK(h);
+	if (!h->ring_host || h->ring_acquired)
 		return nullptr;
 	const size_t slot = (size_t)(h->ring_next % (unsigned long long)h->ring_nslots);
 	if (h->ring_inflight[slot]) {	/* its copy to the GPU must have left the slot */
@@ -1078,7 +1097,10 @@ extern "C" void *vdl2gpu_ring_acquire(vdl2gpu_t *h, size_t *stream_stride_bytes)
 
 extern "C" int vdl2gpu_ring_commit(vdl2gpu_t *h, size_t nsamples)
 {
-	if (!h || !h->ring_host || !h->ring_acquired || nsamples > h->ring_slot_samples)
+	if (!h)
+		return VDL2GPU_EINVAL;
+	HLOCK(h);
+	if (!h->ring_host || !h->ring_acquired || nsamples > h->ring_slot_samples)
 		return VDL2GPU_EINVAL;
 	const size_t slot = (size_t)(h->ring_next % (unsigned long long)h->ring_nslots);
 	h->ring_acquired = false;
@@ -1650,8 +1672,14 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.headtap = h->d_headtap;
 		k2.headtap_n = h->d_headtap_n;
 		k2.headtap_cap = h->headtap_cap;
-		if (h->d_headtap)
+		if (h->d_headtap) {
+			/* VDL2GPU_F_DEBUG_HEADS: one tap buffer for the handle, so the pipeline is drained first -- the back stage and the
+			 * tail of the two pushes before would otherwise still be appending to it ("every trigger of the LAST push") */
+			HIPCHK(h, hipStreamSynchronize(h->stream));
+			HIPCHK(h, hipStreamSynchronize(h->pay_stream));
+			HIPCHK(h, hipStreamSynchronize(h->copy_stream));
 			HIPCHK(h, hipMemsetAsync(h->d_headtap_n, 0, sizeof(unsigned), fs));
+		}
 		k2.full_scan = h->full_scan;
 		k2.test_noregion = noregion ? 1 : 0;
 		k2.regs = h->d_regs[par];
@@ -1754,6 +1782,7 @@ extern "C" int vdl2gpu_sync(vdl2gpu_t *h)
 {
 	if (!h)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	HIPCHK(h, hipStreamSynchronize(h->fstream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1786,7 +1815,11 @@ static inline vdl2gpu_burst_t *rec_of(vdl2gpu_t *h, uint64_t hd)
  * handed out yet moves to the pageable queue.  A consumer that polls after every push never gets here with anything. */
 static void spill_slab(vdl2gpu_t *h, int slab)
 {
-	for (size_t i = h->ready_pos; i < h->ready_idx.size(); ++i)
+	/* only the stretch of the hand-out order that the slab's push put there (a consumer that polls rarely may have 4 x max_bursts
+	 * unread entries: walking all of them in every push cost the calling thread more than enqueueing the push) */
+	const size_t lo = std::max(h->slab_lo[slab], h->ready_pos), hi = std::min(h->slab_hi[slab], h->ready_idx.size());
+	h->slab_lo[slab] = h->slab_hi[slab] = 0;
+	for (size_t i = lo; i < hi; ++i)
 		if (((h->ready_idx[i] >> 32) & 7u) == (unsigned)(1 + slab)) {
 			h->ready.emplace_back();
 			rec_copy(&h->ready.back(), &h->h_slab[slab][(uint32_t)h->ready_idx[i]], true);
@@ -1869,6 +1902,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			h->ready.clear();
 			h->ready_idx.clear();
 			h->ready_pos = 0;
+			for (int k = 0; k < VDL2_NSLAB; ++k)
+				h->slab_lo[k] = h->slab_hi[k] = 0;
 		} else if (h->ready_pos > 1024 && h->ready_pos > h->ready_idx.size() / 2) {	/* the handed-out prefix is the larger part of the storage: drop it
 											 * (so the storage never exceeds 2 x the unread records + one push: <= (8 + 1) x max_bursts records) */
 			std::vector<vdl2gpu_burst_t> keep;
@@ -1882,6 +1917,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			for (size_t i = 0; i < h->ready_idx.size(); ++i)
 				h->ready_idx[i] = (uint64_t)i;
 			h->ready_pos = 0;
+			for (int k = 0; k < VDL2_NSLAB; ++k)	/* (no handle points into a slab any more) */
+				h->slab_lo[k] = h->slab_hi[k] = 0;
 		}
 		/* the first slab_cap records are already in this ring's slab (k_export_records ran before the event this call
 		 * waited for); a push with more than that brings the rest through the bounce buffer */
@@ -1917,6 +1954,8 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			take(h->h_slab[h->ring_slab[ring]][i], ((uint64_t)(1 + h->ring_slab[ring]) << 32) | i);
 		for (size_t i = old; i < h->ready.size(); ++i)
 			take(h->ready[i], (uint64_t)i);
+		h->slab_lo[h->ring_slab[ring]] = iold;
+		h->slab_hi[h->ring_slab[ring]] = h->ready_idx.size();
 		std::sort(h->ready_idx.begin() + iold, h->ready_idx.end(), [h](uint64_t x, uint64_t y) {
 			const vdl2gpu_burst_t &a = *rec_of(h, x), &b = *rec_of(h, y);
 			if (a.end_dec != b.end_dec)
@@ -2033,6 +2072,35 @@ static int harvest_all(vdl2gpu_t *h, bool blocking)
 	return 0;
 }
 
+/* Collect everything pushed before this call, waiting for the GPU where it has to -- with the handle's lock RELEASED during every
+ * wait, so that a producer thread keeps committing blocks while a consumer thread sits in vdl2gpu_poll().  A ring that the
+ * producer reuses meanwhile was collected by the producer's own call first (push_impl), in order. */
+static int wait_harvest(vdl2gpu_t *h, std::unique_lock<std::recursive_mutex> &lk)
+{
+	const uint64_t upto = h->pushes;
+	for (;;) {
+		int r = -1;
+		for (int k = 0; k < VDL2_NRING; ++k)
+			if (h->ring_busy[k] && h->ring_push[k] < upto && (r < 0 || h->ring_push[k] < h->ring_push[r]))
+				r = k;
+		if (r < 0)
+			return 0;
+		const int rc = harvest_ring(h, r, false);
+		if (rc < 0)
+			return rc;
+		if (rc == 1) {
+			hipEvent_t ev = h->ring_done[r];
+			lk.unlock();
+			const hipError_t e = hipEventSynchronize(ev);
+			lk.lock();
+			if (e != hipSuccess) {
+				h->err = std::string("hipEventSynchronize(ring_done): ") + hipGetErrorString(e);
+				return VDL2GPU_EHIP;
+			}
+		}
+	}
+}
+
 static int hand_out(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	const int n = std::min<int>(max, (int)(h->ready_idx.size() - h->ready_pos));
@@ -2054,6 +2122,7 @@ extern "C" int vdl2gpu_decode_blocks(vdl2gpu_t *h, const vdl2gpu_burst_t *blocks
 		*dropped = 0;
 	if (n == 0 || max_frames == 0)
 		return 0;
+	HLOCK(h);
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	vdl2gpu_burst_t *d_blk = nullptr;
 	vdl2gpu_frame_t *d_fr = nullptr;
@@ -2123,8 +2192,9 @@ static int poll_frames_impl(vdl2gpu_t *h, vdl2gpu_frame_t *out, int max, bool bl
 		h->err = "vdl2gpu_poll_frames needs VDL2GPU_F_FRAMES";
 		return VDL2GPU_EINVAL;
 	}
+	HLOCK(h);
 	HIPCHK(h, hipSetDevice(h->cfg.device));
-	int rc = harvest_all(h, blocking);
+	int rc = blocking ? wait_harvest(h, hlock_) : harvest_all(h, false);
 	if (rc)
 		return rc;
 	const int n = std::min<int>(max, (int)(h->fready_idx.size() - h->fready_pos));
@@ -2151,21 +2221,46 @@ extern "C" int vdl2gpu_pending(vdl2gpu_t *h)
 {
 	if (!h)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	HIPCHK(h, hipSetDevice(h->cfg.device));
-	int rc = harvest_all(h, true);
+	int rc = wait_harvest(h, hlock_);
 	if (rc)
 		return rc;
 	return (int)(h->ready_idx.size() - h->ready_pos);
+}
+
+/* Pushes the GPU has not finished yet (0..3).  Never waits. */
+extern "C" int vdl2gpu_inflight(vdl2gpu_t *h)
+{
+	if (!h)
+		return VDL2GPU_EINVAL;
+	HLOCK(h);
+	if (h->failed)
+		return VDL2GPU_EHIP;
+	HIPCHK(h, hipSetDevice(h->cfg.device));
+	int n = 0;
+	for (int r = 0; r < VDL2_NRING; ++r)
+		if (h->ring_busy[r]) {
+			const hipError_t q = hipEventQuery(h->ring_done[r]);
+			if (q == hipErrorNotReady)
+				++n;
+			else if (q != hipSuccess) {
+				h->err = std::string("hipEventQuery: ") + hipGetErrorString(q);
+				return VDL2GPU_EHIP;
+			}
+		}
+	return n;
 }
 
 extern "C" int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	if (!h || (max > 0 && !out) || max < 0)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	if (h->failed)
 		return VDL2GPU_EHIP;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
-	int rc = harvest_all(h, true);
+	int rc = wait_harvest(h, hlock_);
 	if (rc)
 		return rc;
 	return hand_out(h, out, max);
@@ -2175,6 +2270,7 @@ extern "C" int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max)
 {
 	if (!h || (max > 0 && !out) || max < 0)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	if (h->failed)
 		return VDL2GPU_EHIP;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -2188,6 +2284,7 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 {
 	if (!h || !out)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2210,7 +2307,12 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 		}
 	out->overflowed = h->overflowed;
 	out->frames_dropped = h->frames_dropped;
-	out->repairs = h->repairs_seen;
+	{	/* the running total on the device (k2f_commit adds to it), like the channel counters above: current whether or not
+		 * the caller has collected the pushes yet */
+		unsigned rep = 0;
+		HIPCHK(h, hipMemcpy(&rep, h->d_outc + 9, sizeof rep, hipMemcpyDeviceToHost));
+		out->repairs = rep;
+	}
 	return VDL2GPU_OK;
 }
 
@@ -2218,6 +2320,7 @@ extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset
 {
 	if (!h || !out)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2246,6 +2349,7 @@ extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *ou
 {
 	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out || !h->pushes)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2264,6 +2368,7 @@ extern "C" int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, in
 {
 	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out || max_complex < h->L)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	HIPCHK(h, hipSetDevice(h->cfg.device));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	HIPCHK(h, hipMemcpy(out, h->d_lo + ((size_t)stream * VDL2_CS + ch) * h->L, (size_t)h->L * sizeof(float2), hipMemcpyDeviceToHost));
@@ -2274,6 +2379,7 @@ extern "C" int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x
 {
 	if (!h || !y || !x || !out)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	if (!n)
 		return VDL2GPU_OK;
 	HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -2300,6 +2406,7 @@ extern "C" int vdl2gpu_debug_counters(vdl2gpu_t *h, unsigned long long *out, int
 {
 	if (!h || !out || n < 0 || n > 64)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2317,6 +2424,7 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 {
 	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2336,6 +2444,7 @@ extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
 {
 	if (!h || !out || n < h->S * VDL2_CS)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2347,6 +2456,7 @@ extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, in
 {
 	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
@@ -2367,6 +2477,7 @@ extern "C" int vdl2gpu_debug_heads(vdl2gpu_t *h, uint32_t *out, int max_entries)
 {
 	if (!h || !out || max_entries < 0)
 		return VDL2GPU_EINVAL;
+	HLOCK(h);
 	if (!h->d_headtap) {
 		h->err = "vdl2gpu_debug_heads needs VDL2GPU_F_DEBUG_HEADS";
 		return VDL2GPU_EINVAL;

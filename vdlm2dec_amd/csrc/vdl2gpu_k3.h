@@ -61,7 +61,7 @@ __global__ void k3_rebase(K3Params p)
 		for (int sc = (int)threadIdx.x; sc < (p.nstreams * VDL2_CS + 63) / 64 * 64; sc += 64) {
 			const bool live = sc < p.nstreams * VDL2_CS && sc % VDL2_CS < p.nbch;
 			const unsigned nc = live ? p.ctl[CTL_CAND0 + sc] : 0u;
-			const bool over = live && (nc > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc]);
+			const bool over = live && (nc > VDL2_CAND_CAP || (p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] & 1u));	/* (bit 1: unusable for another reason than their size) */
 			novf += (unsigned)__popcll(__ballot(over));
 			maxc = nc > maxc ? nc : maxc;
 		}

@@ -100,7 +100,8 @@ void k2s_merge(K2Params p)
 		return;		/* (a channel that failed for another reason than an unlisted event: the resolver will find nothing new) */
 	if (nnew > K2S_MERGE) {	/* a handicapped test build, a pathological input: not worth a sort kernel's footprint in every push */
 		if (tid == 0)
-			*ovf = 1u;	/* the resolver takes the channel through the serial machine (a complete round resets this) */
+			atomicOr(ovf, 2u);	/* the resolver takes the channel through the serial machine (a complete round resets this); bit 1, not
+						 * bit 0: the tables were not full, the host must not shorten its parts for this (k3_rebase) */
 		return;
 	}
 	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
