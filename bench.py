@@ -247,12 +247,21 @@ def _dropin_replay(here, td, path, fmt, rate, fo, fr, n):
                 best = (ns, sec)
         nb = sum(1 for ln in open(out) if ln.startswith("B"))
         nf = sum(1 for ln in open(out) if ln.startswith("F"))
+        # what the hand-off protocol alone allows on this host: the same executable with the shim doing nothing but the barriers
+        ceil = None
+        r = subprocess.run([exe, path, fmt, str(rate), fo, fr, out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=180,
+                           env={**env, "VDL2GPU_RCV_NULL": "1"})
+        m = re.search(r"replay (\d+) samples ([0-9.]+) s", r.stderr or "")
+        if not r.returncode and m:
+            ceil = int(m.group(1)) / float(m.group(2)) / 1e6
     except (subprocess.SubprocessError, OSError) as e:
         return {"error": repr(e)}
     return {"value": best[0] / best[1] / 1e6, "unit": "MS/s", "samples": best[0], "seconds": best[1], "bursts": nb, "frames": nf,
+            "protocol_ceiling": ceil,
             "what": "oracle/_ref/ref_rtl_gpu (the reference's unchanged host path behind the drop-in shim) over the file the CPU reference was timed on, "
                     "best of 3; first Cbuff hand-off -> last burst through decodeVdlm2(); the producer (sample conversion into Cbuff, two barriers "
-                    "per 32768 samples, rtl.c:283-294) is the harness's, on one host thread: it bounds the figure (see DESIGN.md)"}
+                    "per 32768 samples among nbch + 1 threads, rtl.c:283-294) is the harness's, on one host thread; protocol_ceiling = the same executable with the shim "
+                    "doing nothing but the barriers (VDL2GPU_RCV_NULL=1): what the reference's hand-off protocol allows on this host"}
 
 
 def oracle_stream(tiles, fmt: str, rate: int, fos, ntiles: int, order=None):

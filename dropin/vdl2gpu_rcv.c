@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <time.h>
 #include <complex.h>
 #include "vdlm2.h"
 #include "vdl2gpu.h"
@@ -65,13 +66,18 @@ static struct timeval stamp_of(long long sample)
 static volatile int g_ready;	/* channels initialised so far (channel 0 must be first, vdlm2.c:172) */
 
 /* Hand-offs of Cbuff are collected in a slot of the library's ingest ring (page-locked memory) and the slot is committed when
- * it is full or the GPU is about to run out of work (vdl2gpu_inflight() <= 1): a live source is committed block by block, a file
- * replay in pushes of BATCH_BLOCKS blocks -- the pipeline behind the ring wants pushes of a million samples to run at its rate,
- * and a hand-off is 32768.  Bursts are collected with the never-waiting call after every hand-off [round 3: the waiting
+ * it is full or the source is live (the previous hand-off came a millisecond or more ago): a live source is committed block by
+ * block with no added latency, a file replay in pushes of BATCH_BLOCKS blocks -- enqueueing a push costs the feeding thread
+ * 0.1 ms whatever its size, a hand-off is 32768 samples, and the pipeline behind the ring wants pushes of a million to run at
+ * its rate.  Bursts are collected with the never-waiting call after every hand-off [round 3: the waiting
  * vdl2gpu_poll(), one pipeline drain per 32768 samples: the CPU reference's own 133 MS/s]; vdl2gpu_rcv_flush() -- for the
  * program's shutdown path, next to stopVdlm2() (main.c:106-110) -- commits what is collected and waits for the rest. */
 #define BATCH_BLOCKS 64
+#define LIVE_GAP_NS 1000000	/* hand-offs at least this far apart are a live source: committed at once (a block is 16.4 ms of air time
+				 * at 2 MS/s, 3.3 ms at 10 MS/s); closer together the source is a replay and the slot fills first */
 static vdl2gpu_t *g_h;
+static long long g_last_ns;	/* when the previous hand-off came */
+static int g_null;		/* VDL2GPU_RCV_NULL=1: keep the barrier protocol, do nothing else (measures what the protocol alone allows) */
 static char *g_slot;		/* the slot being filled, or NULL */
 static size_t g_fill;		/* samples in it */
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;	/* deliver() and the slot: the feeding thread against vdl2gpu_rcv_flush() */
@@ -207,6 +213,7 @@ void *rcv_thread(void *arg)
 			fprintf(stderr, "vdl2gpu_ring_init: %s\n", vdl2gpu_strerror(rc));
 			exit(1);
 		}
+		g_null = getenv("VDL2GPU_RCV_NULL") != NULL;
 		pthread_mutex_lock(&g_mu);
 		g_h = h;
 		pthread_mutex_unlock(&g_mu);
@@ -215,8 +222,15 @@ void *rcv_thread(void *arg)
 	pthread_barrier_wait(&Bar1);
 	for (;;) {
 		pthread_barrier_wait(&Bar2);
-		if (h) {
+		int live = 0;
+		if (h && !g_null) {
 			/* Cbuff is copied out before the producer is let go; demodulation happens asynchronously */
+			struct timespec ts;
+			long long now;
+			clock_gettime(CLOCK_MONOTONIC, &ts);
+			now = (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+			live = g_last_ns == 0 || now - g_last_ns >= LIVE_GAP_NS;
+			g_last_ns = now;
 			pthread_mutex_lock(&g_mu);
 			stamp_push(RTLINBUFSZ / 2);
 			if (!g_slot) {
@@ -233,9 +247,9 @@ void *rcv_thread(void *arg)
 			pthread_mutex_unlock(&g_mu);
 		}
 		pthread_barrier_wait(&Bar1);	/* producer may refill Cbuff */
-		if (h) {
+		if (h && !g_null) {
 			pthread_mutex_lock(&g_mu);
-			if (g_fill >= (size_t)BATCH_BLOCKS * (RTLINBUFSZ / 2) || vdl2gpu_inflight(h) <= 1)	/* (two pushes side by side keep the pipeline's stages busy) */
+			if (live || g_fill >= (size_t)BATCH_BLOCKS * (RTLINBUFSZ / 2))
 				commit_slot();
 			deliver(h, 0);
 			pthread_mutex_unlock(&g_mu);

@@ -222,10 +222,9 @@ int vdl2gpu_poll(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 int vdl2gpu_poll_ready(vdl2gpu_t *h, vdl2gpu_burst_t *out, int max);
 /* Number of bursts a poll would currently return (implies vdl2gpu_sync). */
 int vdl2gpu_pending(vdl2gpu_t *h);
-/* Pushes the GPU has not finished yet (0..3); never waits.  Lets a producer that is not bound to real time batch: the
- * drop-in (dropin/vdl2gpu_rcv.c) collects the 32768-sample hand-offs of Cbuff in a ring slot and commits the slot when it is
- * full OR the pipeline is idle -- a live source (a block every 16 ms) is committed block by block with no added latency, a file
- * replay in pushes of a million samples, which is what the pipeline needs to run at its rate. */
+/* Pushes the GPU has not finished yet (0..3); never waits.  For a producer that is not bound to real time and wants to
+ * size its pushes by what the pipeline can take (a push of a million samples costs the calling thread the same 0.1 ms to enqueue
+ * as one of 32768). */
 int vdl2gpu_inflight(vdl2gpu_t *h);
 
 int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out);
