@@ -87,6 +87,7 @@ struct vdl2gpu {
 	ChanState *d_cs = nullptr;
 	ChanCfg *d_cfg = nullptr;
 	uint8_t *d_pn = nullptr;
+	uint8_t *d_pn8 = nullptr;	/* ... by payload byte (K2Params.pn8) */
 	vdl2gpu_burst_t *d_recs[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* output rings, used in turn (push % 3): the calling thread waits for the
 									 * ring's previous push only three pushes later -- with two rings it waited for the tail of the push
 									 * before last in every call, and the GPU's front stream waited for the calling thread */
@@ -550,6 +551,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_cs);
 	(void)hipFree(h->d_cfg);
 	(void)hipFree(h->d_pn);
+	(void)hipFree(h->d_pn8);
 	(void)hipFree(h->d_recs[0]);
 	(void)hipFree(h->d_recs[1]);
 	(void)hipFree(h->d_recs[2]);
@@ -858,6 +860,13 @@ static int create_impl(vdl2gpu_t *h)
 		pn[i] = (uint8_t)b;
 	}
 	HIPCHK(h, hipMemcpyAsync(h->d_pn, pn.data(), pn.size(), hipMemcpyHostToDevice, h->stream));
+	std::vector<uint8_t> pn8(2048, 0);	/* 2040 payload bytes at most (8 rows of 255) */
+	for (size_t b = 0; b < pn8.size(); ++b)
+		for (int i = 0; i < 8; ++i)
+			if (25 + 8 * b + i < pn.size())
+				pn8[b] |= (uint8_t)(pn[25 + 8 * b + i] << i);
+	HIPCHK(h, hipMalloc(&h->d_pn8, pn8.size()));
+	HIPCHK(h, hipMemcpyAsync(h->d_pn8, pn8.data(), pn8.size(), hipMemcpyHostToDevice, h->stream));
 
 	/* canonical start state: everything zero except initD8psk's perr=100 (d8psk.c:28-37);
 	 * 16 zero frames stand for the empty Inbuff ring */
@@ -1650,6 +1659,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.cs = h->d_cs;
 		k2.cfg = h->d_cfg;
 		k2.pn = h->d_pn;
+		k2.pn8 = h->d_pn8;
 		k2.cands = h->d_cands[par];
 		k2.clusters = h->d_clusters[par];
 		k2.clhead = h->d_clhead[par];
@@ -1667,6 +1677,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.probe_r = 0;				/* the one class scanned everywhere: fixed, not the class the channel is in */
 		k2.probe_par = (int)((dec_base + VDL2_HIST) & 1);
 		k2.force_serial = serial ? 1 : 0;
+		k2.sel_reserved = (!h->full_scan && !serial && h->S * VDL2_CS <= 512) ? 1 : 0;	/* (enqueue_back's `spec`) */
 		k2.prim_drop = h->prim_drop;
 		k2.dbg = h->knob.debug_counters ? h->d_dbg : nullptr;
 		k2.headtap = h->d_headtap;

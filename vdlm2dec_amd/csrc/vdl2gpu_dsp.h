@@ -57,6 +57,29 @@ __device__ __forceinline__ float k2_fir_phase(const float2 *x, int tap0)
 	return vdl2_atan2f(si, sr);
 }
 
+/* The same with the table-driven atan2f (vdl2_math.h: the same result bits, no data-dependent branches) and the taps from an
+ * LDS copy of mflt[] (72 floats, zero padded): for the payload decode, where 256 lanes take a symbol each. */
+__device__ __forceinline__ float k2_fir_phase_tab(const float2 *x, int tap0, const float *smf, const float *atab)
+{
+	float2 v[17];
+#pragma unroll
+	for (int j = 0; j < 17; ++j)
+		v[j] = x[j];
+	float sr = 0.0f, si = 0.0f;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {	/* tap0 <= 3: sixteen taps always exist */
+		const float m = smf[tap0 + 4 * j];
+		sr += v[j].x * m;
+		si += v[j].y * m;
+	}
+	if (tap0 == 0) {	/* mflt[64] exists only for tap0 == 0 */
+		const float m = smf[64];
+		sr += v[16].x * m;
+		si += v[16].y * m;
+	}
+	return vdl2_atan2f_tab(si, sr, atab);
+}
+
 /* d8psk.c:257-289: ph[0], ph[STRIDE], ... ph[16*STRIDE] are the 17 phases one symbol apart */
 /* The reference compares the float phase step with the DOUBLE constants +-M_PI.  M_PI lies strictly
  * between the adjacent floats 0x40490fda (3.14159250) and 0x40490fdb (3.14159274), so for a float x
@@ -115,9 +138,9 @@ __device__ __forceinline__ int k2_grey_index(float p, float pprev, float df)
 	return i < 0 ? 0 : (i > 256 ? 256 : i);
 }
 
-__device__ __forceinline__ float k2_soft_bit(int idx, int which, int pnbit)
+__device__ __forceinline__ float k2_soft_bit(int idx, int which, int pnbit, const float *grey = nullptr)
 {
-	const float v = d_tab(which == 0 ? c_grey1 : (which == 1 ? c_grey2 : c_grey3), idx);
+	const float v = grey ? grey[which * 257 + idx] : d_tab(which == 0 ? c_grey1 : (which == 1 ? c_grey2 : c_grey3), idx);
 	return pnbit ? (float)(1.0 - (double)v) : v;	/* descrambler, d8psk.c:60-63 */
 }
 

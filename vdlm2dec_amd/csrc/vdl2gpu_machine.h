@@ -66,7 +66,7 @@ __device__ __forceinline__ void burst_timing(int clk0, int *j0, int *rb)
 /* (inlined: as a call it costs the resolver and the gather kernel 8 % -- callee-saved registers through scratch) */
 template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
 						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph = nullptr,
-						  int tag = 1, int slot = 0)
+						  int tag = 1, int slot = 0, const float *lds_tabs = nullptr, const uint8_t *pn8 = nullptr)
 {
 	const int tid = threadIdx.x;
 	int j0, rb;
@@ -80,8 +80,14 @@ template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t 
 	const float2 *xs0 = x0 + (nsym0 - 16);
 	if (sph) {
 		const int kmax = (25 + 8 * (g.ND + g.NF) - 1) / 3;
-		for (int k = 7 + tid; k <= kmax; k += NT)
-			sph[k - 7] = k2_fir_phase(xs0 + 8LL * k, rb);
+		/* lds_tabs (K2d): mflt[72], the atanf range table and the three soft-bit tables in LDS -- the lanes' table look-ups are
+		 * LDS reads instead of dependent loads from constant memory, the atan2f has no branches (same result bits) */
+		if (lds_tabs)
+			for (int k = 7 + tid; k <= kmax; k += NT)
+				sph[k - 7] = k2_fir_phase_tab(xs0 + 8LL * k, rb, lds_tabs, lds_tabs + 72);
+		else
+			for (int k = 7 + tid; k <= kmax; k += NT)
+				sph[k - 7] = k2_fir_phase(xs0 + 8LL * k, rb);
 		__syncthreads();
 	}
 	for (int b = tid; b < g.ND + g.NF; b += NT) {
@@ -89,13 +95,15 @@ template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t 
 		const int k0 = q0 / 3;	/* >= 8: never needs P1 */
 		int q = q0;
 		unsigned byte = 0;
+		const float *grey = lds_tabs ? lds_tabs + 72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE : nullptr;
+		const unsigned pnb = pn8 ? pn8[b] : 0u;	/* the byte's eight scrambler bits in one load (pn[25 + 8b + i] << i) */
 		float pprev = sph ? sph[k0 - 8] : k2_fir_phase(xs0 + 8LL * (k0 - 1), rb);
 		for (int k = k0; q < q0 + 8; ++k) {
 			const float pk = sph ? sph[k - 7] : k2_fir_phase(xs0 + 8LL * k, rb);
 			const int idx = k2_grey_index(pk, pprev, df);
 			pprev = pk;
 			for (int i = q - 3 * k; i < 3 && q < q0 + 8; ++i, ++q) {
-				const float v = k2_soft_bit(idx, i, pn[q]);
+				const float v = k2_soft_bit(idx, i, pn8 ? (int)((pnb >> (q - q0)) & 1u) : (int)pn[q], grey);
 				if ((double)v > 0.5)
 					byte |= 1u << (q - q0);
 			}

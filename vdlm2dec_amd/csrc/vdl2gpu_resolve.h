@@ -724,6 +724,11 @@ void k2c_resolve(K2Params p)
 	if (tid == 0) {
 		*nsel = (unsigned)s_walk[0];
 		*nseg = (unsigned)s_walk[1];
+		/* the output records of the selected bursts, reserved in one piece: K2d's workgroups (one per burst) then need no
+		 * atomic of their own -- a thousand of them asking one device-scope counter for a slot at the same moment took 80 us,
+		 * more than decoding the bursts (the same effect as in k4_frames) */
+		if (s_walk[0] > 0 && p.sel_reserved)
+			p.ctl[CTL_SELBASE0 + sc] = atomicAdd(p.outc, (unsigned)s_walk[0]);
 	}
 	__syncthreads();
 	if (steady_end) {
@@ -821,6 +826,7 @@ void k2d_payload(K2Params p)
 {
 	__shared__ unsigned s_slot;
 	__shared__ float sph[VDL2_MAXSYM];
+	__shared__ float s_tabs[72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE + 3 * 257];	/* mflt[], atanf range table, Grey1/2/3 (see burst_payload) */
 	const int sc = blockIdx.y;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of a stream */
 	if ((sc % VDL2_CS) >= p.nbch)
 		return;
@@ -831,22 +837,41 @@ void k2d_payload(K2Params p)
 	unsigned n = p.ctl[CTL_NSEL0 + sc];
 	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
 	const unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
+	if (blockIdx.x >= n)
+		return;
+	for (int i = threadIdx.x; i < 72; i += K2D_NT)
+		s_tabs[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	if (threadIdx.x < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+		s_tabs[72 + threadIdx.x] = vdl2_atan_tab_entry(threadIdx.x);
+	for (int i = threadIdx.x; i < 257; i += K2D_NT) {
+		float *g = s_tabs + 72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE;
+		g[i] = d_tab(c_grey1, i);
+		g[257 + i] = d_tab(c_grey2, i);
+		g[514 + i] = d_tab(c_grey3, i);
+	}
+	__syncthreads();
+	const unsigned base = p.ctl[CTL_SELBASE0 + sc];	/* reserved by K2c (sel_reserved: the payload decode runs beside the verify pass and
+							 * again for what a repair round re-resolved; every reserved record is written, the void ones tagged) */
 	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-		if (threadIdx.x == 0) {
-			unsigned slot = atomicAdd(p.outc, 1u);
-			if (slot >= p.rec_cap) {
-				atomicAdd(p.outc + 1, 1u);
-				slot = 0xffffffffu;
-			}
-			s_slot = slot;
+		unsigned slot;
+		if (p.sel_reserved)
+			slot = base + i;
+		else {
+			if (threadIdx.x == 0)
+				s_slot = atomicAdd(p.outc, 1u);
+			__syncthreads();
+			slot = s_slot;
 		}
-		__syncthreads();
-		const unsigned slot = s_slot;
+		if (slot >= p.rec_cap) {	/* ring full: counted, never silent */
+			if (threadIdx.x == 0)
+				atomicAdd(p.outc + 1, 1u);
+			slot = 0xffffffffu;
+		}
 		if (slot != 0xffffffffu) {
 			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.dec_base;
-			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc);
+			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc, s_tabs, p.pn8);
 		}
 		__syncthreads();
 	}

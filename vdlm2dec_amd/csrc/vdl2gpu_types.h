@@ -148,6 +148,7 @@ struct K2Params {
 	ChanState *cs;
 	const ChanCfg *cfg;
 	const uint8_t *pn;
+	const uint8_t *pn8;	/* the scrambler sequence by payload byte: bit i of pn8[b] = pn[25 + 8 b + i] */
 	Cand *cands;		/* [S*8][CAND_CAP] */
 	Cluster *clusters;	/* [S*8][CAND_CAP] */
 	int2 *clhead;		/* [S*8][CAND_CAP] what the resolver needs of every cluster, 8 bytes: see cl_pack() */
@@ -163,6 +164,7 @@ struct K2Params {
 	int full_round;		/* this repair round scans the failing channels completely (all classes, every instant): no regions, no verify */
 	int mini_round;		/* this repair round re-resolves with what the verify pass found and appended to the tables, nothing else: no scan, no
 				 * clusters (the resolver replays the few new candidates itself) */
+	int sel_reserved;	/* K2c reserves the output records of a channel's selected bursts in one piece (CTL_SELBASE0), K2d fills them without atomics */
 	int pay_final;		/* K2d: second pass, behind the repair rounds (only masked channels, records tagged final) */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
@@ -205,7 +207,8 @@ struct K2Params {
 #define CTL_NCLUST0 (CTL_CAND0 + 7 * p.nstreams * VDL2_CS)	/* candidates [0, n) had their clusters decided by the previous K2s/K2b of this push */
 #define CTL_NSURV0 (CTL_CAND0 + 8 * p.nstreams * VDL2_CS)	/* [VDL2_SURV_SLOTS][S*8] item counts, one set per scan of the push */
 enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repair round (1..4) */, VDL2_SURV_FULL = 7, VDL2_SURV_SLOTS = 8 };
-#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (8 + VDL2_SURV_SLOTS) * (size_t)(nsc))
+#define CTL_SELBASE0 (CTL_CAND0 + (8 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)	/* first output record of the channel's selected bursts (K2c reserves, K2d fills) */
+#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (9 + VDL2_SURV_SLOTS) * (size_t)(nsc))
 
 struct K3Params {
 	const float2 *src;
