@@ -106,6 +106,7 @@ struct vdl2gpu {
 	int2 *d_clhead[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	BurstDesc *d_stage[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	unsigned *d_sel_list[VDL2_NSET] = {nullptr, nullptr, nullptr};
+	unsigned *d_sel_list2[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* the repair rounds' selection (K2Params.sel_list2) */
 	int2 *d_regs[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	Seg *d_segs[VDL2_NSET] = {nullptr, nullptr, nullptr};
 	int *d_fail[VDL2_NSET] = {nullptr, nullptr, nullptr};
@@ -196,7 +197,7 @@ struct vdl2gpu {
 	struct {
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
 		bool no_tail = false;		/* VDL2GPU_NO_TAIL: everything behind the verify pass stays on the main stream */
-		bool pay_copy = false;		/* VDL2GPU_PAY_COPY: the payload decode beside the verify pass on the copy stream instead of the payload (tail) stream */
+		bool pay_tail = false;		/* VDL2GPU_PAY_TAIL: the payload decode beside the verify pass on the payload (tail) stream instead of the copy stream */
 		bool k2b_front = false;		/* VDL2GPU_K2B_FRONT: the cluster kernel at the end of the front stage instead of the start of the back stage */
 		bool k1_pp = false;		/* VDL2GPU_K1_PP: k1_pp at 2 MS/s as well */
 		bool debug_counters = false;	/* VDL2GPU_DEBUG_COUNTERS: cycle counters of the demodulator kernels */
@@ -613,6 +614,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_sel_list[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_sel_list2[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_regs[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_segs[r]);
@@ -740,6 +743,8 @@ static int create_impl(vdl2gpu_t *h)
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_sel_list[r], (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
 	for (int r = 0; r < VDL2_NSET; ++r)
+		HIPCHK(h, hipMalloc(&h->d_sel_list2[r], (size_t)S * VDL2_CS * VDL2_SEL_CAP * sizeof(unsigned)));
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_regs[r], (size_t)S * VDL2_CS * VDL2_REG_CAP * sizeof(int2)));
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_segs[r], (size_t)S * VDL2_CS * VDL2_SEG_CAP * sizeof(Seg)));
@@ -772,7 +777,7 @@ static int create_impl(vdl2gpu_t *h)
 	h->hprof_on = getenv("VDL2GPU_HOST_PROF") != nullptr;
 	h->knob.k2b_front = env_int("VDL2GPU_K2B_FRONT", 0) != 0;
 	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
-	h->knob.pay_copy = env_int("VDL2GPU_PAY_COPY", 0) != 0;
+	h->knob.pay_tail = env_int("VDL2GPU_PAY_TAIL", 0) != 0;
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
 	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
 	h->knob.k1f_nfam = env_int("VDL2GPU_K1F_NFAM", 0);
@@ -1173,10 +1178,13 @@ static int enqueue_back(vdl2gpu_t *h)
 	h->ring_spec[ring] = spec;
 	if (spec)
 		HIPCHK(h, hipEventRecord(h->k2c_done, rs));
-	/* the payload decode beside the verify pass: on the payload stream, in front of the push's tail (VDL2GPU_PAY_COPY=1: on the copy
-	 * stream, a hardware queue of its own -- the tail of the push before may still be running on the payload stream; measured:
-	 * 0.48 .. 0.56 ms per step against 0.50 .. 0.51, no gain) */
-	hipStream_t ps = h->knob.pay_copy ? h->copy_stream : h->pay_stream;
+	/* The payload decode beside the verify pass: on the copy stream (a hardware queue of its own), so that the push's TAIL on the
+	 * payload stream -- the repair round and the commit, which the NEXT push's resolver waits for: the pipeline's loop-carried
+	 * dependency -- starts when the verify pass ends, not when this latency-bound kernel has found CUs between the verify pass's
+	 * workgroups and finished.  The repair rounds write a selection of their own (K2Params.sel_list2), so nothing the decode
+	 * reads changes under it; the tail waits for it only where it needs its records: in front of the second payload pass and the
+	 * export.  (VDL2GPU_PAY_TAIL=1: on the payload stream in front of the tail, round 3's arrangement.) */
+	hipStream_t ps = h->knob.pay_tail ? h->pay_stream : h->copy_stream;
 	if (spec) {
 		HIPCHK(h, hipStreamWaitEvent(ps, h->k2c_done, 0));
 		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ps, k2);
@@ -1199,8 +1207,6 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(h->verify_done, h->stream));
 		HIPCHK(h, hipStreamWaitEvent(ts, h->verify_done, 0));
 	}
-	if (spec && ps != ts && ts != h->stream)	/* (on the main stream the waits below cover it) */
-		HIPCHK(h, hipStreamWaitEvent(ts, h->pay_done, 0));	/* the repair round rewrites the selection the payload decode reads; the export needs its records */
 	if (h->tail_prev && h->tail_prev != ts && h->k2_rec[(par + VDL2_NSET - 1) % VDL2_NSET])	/* tails follow each other (running totals, StreamState) */
 		HIPCHK(h, hipStreamWaitEvent(ts, h->k2_done[(par + VDL2_NSET - 1) % VDL2_NSET], 0));
 	h->tail_prev = ts;
@@ -1217,8 +1223,10 @@ static int enqueue_back(vdl2gpu_t *h)
 		 * (~0.1 ms for a channel of a 67 MS push) -- their tables rebuilt from nothing, which leaves nothing to verify and
 		 * nothing to cascade.  What still fails after the last round is redone serially by K2f. */
 		K2Params k2r = k2;
-		if (spec && h->repair_rounds > 0 && ts == h->stream)	/* a repair round rewrites the selection K2d is reading (on the payload stream the tail is behind it anyway) */
-			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));
+		/* (a repair round writes its own selection, sel_list2: the payload decode of the first one goes on beside it -- unless the
+		 * last round is a complete one: that re-makes the failing channels' clusters, whose descriptors the decode may be reading) */
+		if (spec && h->repair_rounds >= 2 && ts != ps)
+			HIPCHK(h, hipStreamWaitEvent(ts, h->pay_done, 0));
 		const dim3 vgrid((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S);
 		for (int rr = 1; rr <= h->repair_rounds; ++rr) {
 			k2r.round = rr;
@@ -1247,15 +1255,19 @@ static int enqueue_back(vdl2gpu_t *h)
 	HIPCHK(h, hipEventRecord(h->k2f_done, ts));
 	h->k2f_rec = true;
 	if (h->ring_spec[ring]) {
-		if (ts == h->stream)
-			HIPCHK(h, hipStreamWaitEvent(h->stream, h->pay_done, 0));	/* K3 publishes the record count */
+		if (ts != ps)
+			HIPCHK(h, hipStreamWaitEvent(ts, h->pay_done, 0));	/* the export needs the first pass's records, K3 publishes the record count */
 		if (h->repair_rounds > 0 && !h->full_scan && !serial) {
 			K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
 			k2p.pay_final = 1;
+			k2p.sel_mode = 1;
 			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2p);
 		}
-	} else
-		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2);
+	} else {
+		K2Params k2p = k2;	/* one pass behind the commit: the repaired selection where there is one */
+		k2p.sel_mode = 2;
+		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2p);
+	}
 	HIPCHK(h, hipGetLastError());
 	if (h->frames_on) {
 		/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
@@ -1666,6 +1678,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.ctl = h->d_ctl[par];
 		k2.stage = h->d_stage[par];
 		k2.sel_list = h->d_sel_list[par];
+		k2.sel_list2 = h->d_sel_list2[par];
+		k2.sel_mode = 0;
 		k2.stage_cap = h->stage_cap;
 		k2.recs = h->d_recs[ring];
 		k2.outc = h->d_outc + 2 * ring;

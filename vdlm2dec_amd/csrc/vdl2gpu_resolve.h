@@ -380,7 +380,7 @@ void k2c_resolve(K2Params p)
 			if (p.dbg)
 				atomicAdd(p.dbg + 24, 1ull);
 			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
-			p.ctl[CTL_NSEL0 + sc] = 0;
+			p.ctl[CTL_NSEL1 + sc] = 0;	/* (the repair rounds' own selection: see CTL_NSEL1) */
 			p.ctl[CTL_NSEG0 + sc] = 0;
 			/* if K2d ran ahead on the first pass's selection, what it made of this channel is void (the host and K4
 			 * drop the records tagged 0 of masked channels); K2d decodes the repaired selection in its second pass */
@@ -391,8 +391,8 @@ void k2c_resolve(K2Params p)
 	}
 	const ChanState *cs = p.cs + sc;	/* input state: left untouched until K2f commits */
 	ChanState *cs_out = p.cs_out + sc;
-	unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
-	unsigned *nsel = p.ctl + CTL_NSEL0 + sc;
+	unsigned *sel = (p.round > 0 ? p.sel_list2 : p.sel_list) + (size_t)sc * VDL2_SEL_CAP;
+	unsigned *nsel = p.ctl + (p.round > 0 ? CTL_NSEL1 : CTL_NSEL0) + sc;
 	Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
 	unsigned *nseg = p.ctl + CTL_NSEG0 + sc;
 	MachCtx cx;
@@ -728,7 +728,7 @@ void k2c_resolve(K2Params p)
 		 * atomic of their own -- a thousand of them asking one device-scope counter for a slot at the same moment took 80 us,
 		 * more than decoding the bursts (the same effect as in k4_frames) */
 		if (s_walk[0] > 0 && p.sel_reserved)
-			p.ctl[CTL_SELBASE0 + sc] = atomicAdd(p.outc, (unsigned)s_walk[0]);
+			p.ctl[(p.round > 0 ? CTL_SELBASE1 : CTL_SELBASE0) + sc] = atomicAdd(p.outc, (unsigned)s_walk[0]);
 	}
 	__syncthreads();
 	if (steady_end) {
@@ -807,7 +807,7 @@ void k2f_commit(K2Params p)
 		cs->n_slow += (unsigned long long)(st.pos - p0);
 		cs->n_redo += 1;
 		atomicAdd(p.outc_total_redo, 1u);
-		p.ctl[CTL_NSEL0 + sc] = 0;	/* K2d: nothing of the resolver's for this channel ... */
+		p.ctl[CTL_NSEL1 + sc] = 0;	/* K2d: nothing of the resolver's for this channel (it is masked: K2d reads the repair rounds' selection) ... */
 		if (p.fmask && sc < 512)	/* ... and if K2d ran ahead of the verify pass, the host drops what it made of it */
 			atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
 	}
@@ -832,11 +832,13 @@ void k2d_payload(K2Params p)
 		return;
 	/* second pass (pay_final): only the channels a repair round re-resolved behind the first pass's back; their records
 	 * are final (tag 1).  A channel K2f redid serially has nothing selected. */
-	if (p.pay_final && !(sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u)))
+	const bool masked = sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u);
+	if (p.sel_mode == 1 && !masked)
 		return;
-	unsigned n = p.ctl[CTL_NSEL0 + sc];
+	const bool alt = p.sel_mode == 1 || (p.sel_mode == 2 && masked);	/* which of the two selections (see CTL_NSEL1) */
+	unsigned n = p.ctl[(alt ? CTL_NSEL1 : CTL_NSEL0) + sc];
 	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
-	const unsigned *sel = p.sel_list + (size_t)sc * VDL2_SEL_CAP;
+	const unsigned *sel = (alt ? p.sel_list2 : p.sel_list) + (size_t)sc * VDL2_SEL_CAP;
 	if (blockIdx.x >= n)
 		return;
 	for (int i = threadIdx.x; i < 72; i += K2D_NT)
@@ -850,7 +852,7 @@ void k2d_payload(K2Params p)
 		g[514 + i] = d_tab(c_grey3, i);
 	}
 	__syncthreads();
-	const unsigned base = p.ctl[CTL_SELBASE0 + sc];	/* reserved by K2c (sel_reserved: the payload decode runs beside the verify pass and
+	const unsigned base = p.ctl[(alt ? CTL_SELBASE1 : CTL_SELBASE0) + sc];	/* reserved by K2c (sel_reserved: the payload decode runs beside the verify pass and
 							 * again for what a repair round re-resolved; every reserved record is written, the void ones tagged) */
 	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
 		unsigned slot;

@@ -41,7 +41,7 @@
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
-#define K2X_WL 20		/* k2x_second: survivors whose exact phases are in LDS at once (1020 phases: four passes of the workgroup) */
+#define K2X_WL 40		/* k2x_second: survivors whose exact phases are in LDS at once (2040 phases: four passes of the workgroup, two phases a lane and pass) */
 #define K2X_NT 256		/* ... and the items a workgroup takes */
 #define K2X_CV 64		/* of which the fit screen of so many runs in ONE wavefront (11 % get that far) */
 #define VDL2_ITEM_CAP 196608	/* evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
@@ -526,25 +526,44 @@ void k2x_second(K2Params p)
 	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
 	for (int b0 = 0; b0 < nd; b0 += K2X_WL) {
 		const int nb = (nd - b0 < K2X_WL) ? nd - b0 : K2X_WL;
-		for (int t = tid; t < 51 * nb; t += K2X_NT) {
-			const int slot = t / 51, rem = t - 51 * slot, w = rem / 17, l = rem - 17 * w;
-			const K2aDef d = sh.dl[b0 + slot];
-			const float2 *x = x0 + (d.n + (w - 1) * 2 - 8 * (16 - l) - 16);
-			float2 xv[17];
+		/* two phases per lane and pass, their loads and dependent chains (17 taps, then the atan2f's divisions and polynomial)
+		 * interleaved: the stage is a chain of latencies, not of throughput */
+		for (int t0 = tid; t0 < 51 * nb; t0 += 2 * K2X_NT) {
+			float2 xv[2][17];
+			int rr[2], slot[2], ww[2], ll[2];
 #pragma unroll
-			for (int j = 0; j < 17; ++j)
-				xv[j] = x[j];
-			v2f acc = {0.0f, 0.0f};
+			for (int u = 0; u < 2; ++u) {
+				const int t = t0 + u * K2X_NT < 51 * nb ? t0 + u * K2X_NT : t0;	/* (the odd one out repeats its partner) */
+				slot[u] = t / 51;
+				const int rem = t - 51 * slot[u];
+				ww[u] = rem / 17;
+				ll[u] = rem - 17 * ww[u];
+				const K2aDef d = sh.dl[b0 + slot[u]];
+				rr[u] = d.r;
+				const float2 *x = x0 + (d.n + (ww[u] - 1) * 2 - 8 * (16 - ll[u]) - 16);
+#pragma unroll
+				for (int j = 0; j < 17; ++j)
+					xv[u][j] = x[j];
+			}
+			v2f acc[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
 			for (int j = 0; j < 16; ++j) {
-				const float m = sh.smf[d.r + 4 * j];
-				acc += (v2f){xv[j].x, xv[j].y} * (v2f){m, m};
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const float m = sh.smf[rr[u] + 4 * j];
+					acc[u] += (v2f){xv[u][j].x, xv[u][j].y} * (v2f){m, m};
+				}
 			}
-			if (d.r == 0) {	/* mflt[r + 64] exists only for r == 0 */
-				const float m = sh.smf[64];
-				acc += (v2f){xv[16].x, xv[16].y} * (v2f){m, m};
-			}
-			sh.sph[slot][w][l] = vdl2_atan2f_tab(acc.y, acc.x, sh.atab);
+#pragma unroll
+			for (int u = 0; u < 2; ++u)
+				if (rr[u] == 0) {	/* mflt[r + 64] exists only for r == 0 */
+					const float m = sh.smf[64];
+					acc[u] += (v2f){xv[u][16].x, xv[u][16].y} * (v2f){m, m};
+				}
+			const float ph0 = vdl2_atan2f_tab(acc[0].y, acc[0].x, sh.atab), ph1 = vdl2_atan2f_tab(acc[1].y, acc[1].x, sh.atab);
+			sh.sph[slot[0]][ww[0]][ll[0]] = ph0;
+			if (t0 + K2X_NT < 51 * nb)
+				sh.sph[slot[1]][ww[1]][ll[1]] = ph1;
 		}
 		__syncthreads();
 		for (int kk = tid; kk < 3 * nb; kk += K2X_NT) {

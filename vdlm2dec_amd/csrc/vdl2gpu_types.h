@@ -156,6 +156,10 @@ struct K2Params {
 				 * [8 + S*8 ...] cand counts, then cand overflow flags */
 	BurstDesc *stage;	/* burst descriptors of all clusters */
 	unsigned *sel_list;	/* descriptors on the real chain (K2c -> K2d) */
+	unsigned *sel_list2;	/* ... as the repair rounds re-resolved them (channels in fmask) */
+	int sel_mode;		/* K2d: 0 = the first selection of every channel (beside the verify pass: the mask is not final yet);
+				 * 1 = the repaired selection of the masked channels (second pass);
+				 * 2 = one pass behind the commit: the repaired selection for masked channels, the first for the others */
 	unsigned stage_cap;
 	vdl2gpu_burst_t *recs;	/* output ring of this push */
 	unsigned *outc;		/* [0] = records written, [1] = records dropped (ring full) */
@@ -208,7 +212,12 @@ struct K2Params {
 #define CTL_NSURV0 (CTL_CAND0 + 8 * p.nstreams * VDL2_CS)	/* [VDL2_SURV_SLOTS][S*8] item counts, one set per scan of the push */
 enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repair round (1..4) */, VDL2_SURV_FULL = 7, VDL2_SURV_SLOTS = 8 };
 #define CTL_SELBASE0 (CTL_CAND0 + (8 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)	/* first output record of the channel's selected bursts (K2c reserves, K2d fills) */
-#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (9 + VDL2_SURV_SLOTS) * (size_t)(nsc))
+/* The selection exists twice: the first resolver pass writes sel_list / CTL_NSEL0 / CTL_SELBASE0, the repair rounds sel_list2 and
+ * the words below -- the payload decode of the first selection runs beside the verify pass AND beside the repair round (on a
+ * stream of its own), which therefore must not touch what it reads. */
+#define CTL_NSEL1 (CTL_CAND0 + (9 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)
+#define CTL_SELBASE1 (CTL_CAND0 + (10 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)
+#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (11 + VDL2_SURV_SLOTS) * (size_t)(nsc))
 
 struct K3Params {
 	const float2 *src;
