@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates profiles/rNN_* on a GPU box (gpurun):  R=r03 scripts/make_profiles.sh   (copy gpurun_out/profiles/* to profiles/ afterwards)
+# Regenerates profiles/rNN_* on a GPU box (gpurun):  R=r04 scripts/make_profiles.sh   (copy gpurun_out/profiles/* to profiles/ afterwards)
 #   ${R}_bench_line.json         the bench line of the default command
 #   ${R}_bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats summary of the same command
 #   ${R}_bench_pmc_hbm.json      FETCH_SIZE / WRITE_SIZE per kernel launch (separate --pmc passes)
@@ -8,7 +8,7 @@
 #   (round 2's micro-benchmarks and k1_fast ablations -- profiles/r02_valu_rate.txt, r02_clock_rate.txt, r02_k1_ablation.txt --
 #    describe kernels this round did not change; WITH_BER=1 adds the Es/N0 sweep)
 cd "$(dirname "$0")/.."
-R=${R:-r03}
+R=${R:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles
 mkdir -p $OUT
@@ -51,6 +51,13 @@ res = {"FETCH_SIZE_KB_per_launch": {k: v["FETCH_SIZE"] for k, v in hb.items() if
                 "--steps 4 --warmup 2`; KB per kernel launch, averaged over the full-size launches (the first push of the handle runs as four parts; the "
                 "synchronised pushes bench.py adds after its timed region are included).  Per MI355X_MICROARCH.md FETCH_SIZE reports half the bytes of wide coalesced reads on "
                 "gfx950: bench.py's traffic_from_profiles = 2 x FETCH_SIZE + WRITE_SIZE"}
+# launches of every kernel per step (push), from the traced run: what bench.py's roofline.whole_step multiplies the per-launch figures by
+try:
+    ks = {r["Name"].split("(")[0]: int(r["Calls"]) for r in csv.DictReader(open(out + "/" + R + "_bench_kernel_stats.csv"))}
+    pushes = ks.get("k2a_probe", 0) or 1
+    res["launches_per_step"] = {k: round(v / pushes, 2) for k, v in ks.items() if k.startswith(("k", "void k"))}
+except (OSError, KeyError, ValueError):
+    pass
 json.dump(res, open(out + "/" + R + "_bench_pmc_hbm.json", "w"), indent=1)
 sq = collect(["/tmp/pr_s1", "/tmp/pr_s2", "/tmp/pr_s3"])
 json.dump({"per_launch": sq, "_note": "SQ_* in quad-cycles / instructions summed over the chip, GRBM_GUI_ACTIVE summed over the 8 XCDs; "

@@ -673,9 +673,11 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	static_assert(K2A_POFF == S * PH, "phase history must be a whole number of instants");
 	float2 *const wu = (S == 2) ? sh.xs : sh.xs + K2A_WU1;	/* phase-step phasors (see K2aShared) */
 	/* exp(-j (SW[l] - SW[l-1])), l = 1..16: the template steps are 1,7,5,-7,1,3,-3,-7,3,-1,5,-5,-3,-5,-1,7 (x pi/8) */
+#ifdef K2A_SCREEN_FMA
 	constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
 	constexpr float rc[16] = {C1, -C1, -S1, -C1, C1, S1, S1, -C1, S1, C1, -S1, -S1, S1, -S1, C1, -C1};
 	constexpr float rs[16] = {-S1, -S1, -C1, S1, -S1, -C1, C1, S1, -C1, S1, -C1, C1, C1, C1, S1, -S1};
+#endif
 	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
 	const bool prof = p.dbg && (mode == 2 || (mode == 0 && S == 1 && skip_r >= 0)) && tid == 0 && (blockIdx.x & 7) == 0;	/* probe, region scan */
 	long long tq = prof ? clock64() : 0;
@@ -772,6 +774,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 #pragma unroll
 			for (int l = 0; l < 16; ++l)	/* all sixteen LDS reads in flight before the arithmetic */
 				uu[l] = uq[l * LSTR];
+#ifdef K2A_SCREEN_FMA
 			v2f acc = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
 #pragma unroll
 			for (int l = 0; l < 16; l += 2) {
@@ -779,6 +782,27 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				acc1 = k2_rot(acc1, (v2f){uu[l + 1].x, uu[l + 1].y}, rc[l + 1], rs[l + 1]);
 			}
 			acc += acc1;
+#else
+			/* The sixteen template rotations are e^(j pi/8) e^(j k pi/4) with k = 7,4,5,3,7,6,1,3,6,0,5,2,1,2,0,4: the common factor
+			 * does not change |R|, even k are quarter turns (+-1, +-j) and odd k the same times e^(j pi/4) -- so the phasors are
+			 * ADDED into four sums (+-1 and +-j, with and without the eighth turn) and turned once at the end: 16 packed additions
+			 * and a dozen plain operations where the rotation by multiplication took 32 packed multiply-adds. */
+			constexpr int kq[16] = {7, 4, 5, 3, 7, 6, 1, 3, 6, 0, 5, 2, 1, 2, 0, 4};
+			v2f s4[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};	/* [0] +-1, [1] +-j, [2] +-e^(j pi/4), [3] +-j e^(j pi/4) */
+#pragma unroll
+			for (int l = 0; l < 16; ++l) {
+				const v2f u = {uu[l].x, uu[l].y};
+				const int g = ((kq[l] & 1) << 1) | ((kq[l] >> 1) & 1);
+				if (kq[l] & 4)
+					s4[g] -= u;
+				else
+					s4[g] += u;
+			}
+			const v2f pa = {s4[0].x - s4[1].y, s4[0].y + s4[1].x};	/* s4[0] + j s4[1] */
+			const v2f qa = {s4[2].x - s4[3].y, s4[2].y + s4[3].x};
+			constexpr float RH = 0.70710678118654752f;
+			const v2f acc = {__fmaf_rn(qa.x - qa.y, RH, pa.x), __fmaf_rn(qa.x + qa.y, RH, pa.y)};
+#endif
 			const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
 			const long long n_abs = nbase + S * (j - E4);	/* the evaluation's instant */
 			bool pass = i < cnt && !(r2 <= VDL2_SCREEN_R2);
