@@ -656,6 +656,11 @@ __device__ __forceinline__ float k2a_lane_from(int byte_addr, float v)
 	return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
+#ifdef K2A_NOBAR
+#define K2A_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define K2A_SYNC() __syncthreads()
+#endif
 template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int sc, long long dec_base, long long nbase,
 					   int cnt, unsigned rmask, int mode, long long chk_lo, long long chk_hi, int *fail,
 					   K2aPre<S> &pre, long long next_nbase, int next_cnt, int skip_r = -1, int skip_par = 0)
@@ -688,7 +693,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 #if K2A_PREFETCH
 	if (!pre.loaded)
 		k2a_fetch<S>(pre, p, sc, dec_base, nbase, cnt);
-	__syncthreads();
+	K2A_SYNC();
 	K2A_STAMP(12);
 #pragma unroll
 	for (int k = 0; k < K2aPre<S>::NL; ++k)
@@ -715,7 +720,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 #endif
 	pre.tiles++;
 	K2A_STAMP(13);
-	__syncthreads();
+	K2A_SYNC();
 	K2A_STAMP(0);
 	const int npairs = (cnt + PH + 1) / 2;
 	const int wv = tid >> 6, ln = tid & 63;
@@ -755,7 +760,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 			k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
 #endif
 		if (S == 2)
-			__syncthreads();	/* wu[] is xs[]: every wavefront is through with the samples */
+			K2A_SYNC();	/* wu[] is xs[]: every wavefront is through with the samples */
 		K2A_STAMP(2);
 #pragma unroll
 		for (int it = 0; it < NIT; ++it) {
@@ -764,7 +769,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				*reinterpret_cast<float4 *>(&wu[q0]) = hold[it];
 		}
 		K2A_STAMP(3);
-		__syncthreads();
+		K2A_SYNC();
 		/* ---- first screen, of the evaluation that is the `perr` of instant i: j = i + E2; what passes goes to the item list */
 		for (int i0 = 0; i0 < cnt; i0 += K2A_THREADS) {	/* (wave-uniform trip count: k2a_append votes) */
 			const int i = i0 + tid;
@@ -813,7 +818,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		}
 		K2A_STAMP(4);
 		K2A_STAMP(8);
-		__syncthreads();
+		K2A_SYNC();
 		K2A_STAMP(9);
 		if (prof)
 			sh.prof[11] += 1ull;
