@@ -157,6 +157,7 @@ template <int NT> struct MachSharedT {
 	float psym[12];			/* header symbol phases */
 	float2 xt[VDL2_XT];		/* LDS tile of the channel's samples (cluster mode) */
 	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45), zero padded */
+	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];	/* atanf range constants: the table-driven atan2f (vdl2_math.h) has no data-dependent branches */
 	float hsoft[25];		/* descrambled header soft bits */
 	uint8_t vbk[26][32], vbv[26][32];	/* Viterbi back pointers / decided bits */
 	int first;
@@ -233,6 +234,8 @@ template <int NT> __device__ __forceinline__ void mach_init_taps(MachSharedT<NT>
 {
 	for (int i = threadIdx.x; i < 72; i += NT)
 		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+	for (int i = threadIdx.x; i < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE; i += NT)
+		sh.atab[i] = vdl2_atan_tab_entry(i);
 	__syncthreads();
 }
 
@@ -261,7 +264,11 @@ template <int NT, bool XL> __device__ __forceinline__ float mach_fir(const MachS
 			si += v[j].y * m;
 		}
 	}
+#ifdef VDL2_MACH_ATAN_BRANCHY
 	return vdl2_atan2f(si, sr);
+#else
+	return vdl2_atan2f_tab(si, sr, sh.atab);	/* the same result bits (tests/test_math.py, test_gpu_math.py), no divergence between the lanes */
+#endif
 }
 
 template <int NT> __device__ __forceinline__ void mach_load(MachSharedT<NT> &sh, const ChanState *cs)
