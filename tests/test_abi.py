@@ -114,8 +114,9 @@ def test_test_handicaps_exist_only_in_the_test_build(built):
     if rc == 0:
         test.vdl2gpu_destroy(h)
     blob = open(lib.LIB_PATH, "rb").read()
-    assert b"VDL2GPU_PRIM_DROP" not in blob and b"VDL2GPU_SPLIT_SAMPLES" not in blob
-    assert b"VDL2GPU_PRIM_DROP" in open(lib.LIB_TEST_PATH, "rb").read()
+    assert b"VDL2GPU_PRIM_DROP" not in blob and b"VDL2GPU_SPLIT_SAMPLES" not in blob and b"VDL2GPU_TEST_ITEM" not in blob
+    tblob = open(lib.LIB_TEST_PATH, "rb").read()
+    assert b"VDL2GPU_PRIM_DROP" in tblob and b"VDL2GPU_TEST_ITEM_GRID" in tblob and b"VDL2GPU_TEST_ITEM_COMMON" in tblob
     src = open(os.path.join(ROOT, "vdlm2dec_amd", "csrc", "vdl2gpu.hip")).read()
     push = src[src.index("static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t stream_stride_bytes, int memkind, bool wait_copy)\n{"):]
     push = push[:push.index("extern \"C\" int vdl2gpu_sync")]

@@ -711,3 +711,27 @@ def test_a_device_buffer_is_free_once_two_more_pushes_have_been_issued(built, or
             got += rx.poll_ready()
         got += rx.poll()
     assert _gpu_keys(got) == want
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("hooks", [{"VDL2GPU_TEST_ITEM_GRID": "3"}, {"VDL2GPU_TEST_ITEM_GRID": "3", "VDL2GPU_TEST_ITEM_COMMON": "200"}])
+def test_item_list_common_area_and_overflow(built, oracle, monkeypatch, hooks):
+    """The scans hand what passes their first screen to k2x_second through per-workgroup areas of an item list.  With three scan
+    workgroups per channel and the smallest private areas (test build: VDL2GPU_TEST_ITEM_GRID) nearly every item takes the
+    other path -- the common area behind the private ones, one device-scope atomic per wavefront and pass; with a common area of
+    200 items (VDL2GPU_TEST_ITEM_COMMON) the list overflows: the channel's tables count as unusable, k2x_second reads nothing
+    past the first refused group, and the serial machine decodes the channel.  Either way: the oracle's bursts."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    for k, v in hooks.items():
+        monkeypatch.setenv(k, v)
+    spec = synth.random_scenario(2_000_000, S.FO8[:3], 6_000_000, seed=4242, bursts_per_s=10.0, info_max=120)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=3_000_000, testhooks=True) as rx:
+        got = rx.run(raw, block=3_000_000)
+        st = rx.stats()
+    assert _gpu_keys(got) == want and len(want) >= 60
+    if "VDL2GPU_TEST_ITEM_COMMON" in hooks:
+        assert st["serial_samples"] > 100_000, st       # the overflow was noticed and the serial machine took over
+    else:
+        assert st["serial_samples"] < 20_000, st        # the common area is an ordinary path: nothing fell back

@@ -39,6 +39,10 @@ extern "C" void sincosf(float, float *, float *);
 		}                                                                               \
 	} while (0)
 
+#ifdef VDL2GPU_TESTHOOKS
+static int g_test_item_grid = 0, g_test_item_common = 0;	/* read once per vdl2gpu_create (test build only) */
+#endif
+
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
 #define NEVX 15	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain; e[12] = before the verify pass
 			 * (main stream, behind the wait for the resolver); e[13], e[14] = around the resolver (its own stream when hoisted) */
@@ -791,6 +795,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->knob.k1_nsub = env_int("VDL2GPU_K1_NSUB", 0);
 #ifdef VDL2GPU_TESTHOOKS
 	h->prim_drop = env_int("VDL2GPU_PRIM_DROP", 0);
+	g_test_item_grid = env_int("VDL2GPU_TEST_ITEM_GRID", 0);
+	g_test_item_common = env_int("VDL2GPU_TEST_ITEM_COMMON", 0);
 #endif
 	/* A push in which a channel's verify pass fails with no round scheduled costs a serial redo of that channel's whole
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
@@ -1011,7 +1017,16 @@ static void launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st
 	 * (28 per tile and class; the region scan's tiles are sync words: far more pass) plus a sync word's worth; what it does
 	 * not hold goes to the common area */
 	grid.x = std::min<unsigned>(grid.x, VDL2_MAXWG);
-	const unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u) + 128u + 255u) / 256u * 256u;
+	unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u) + 128u + 255u) / 256u * 256u;
+	q.surv_common_cap = 0;	/* (0: whatever the list has left behind the private areas) */
+#ifdef VDL2GPU_TESTHOOKS
+	if (g_test_item_grid > 0) {	/* VDL2GPU_TEST_ITEM_GRID: few scan workgroups with the smallest private areas -- most items take the common area's path */
+		grid.x = std::min<unsigned>(grid.x, (unsigned)g_test_item_grid);
+		want = 256u;
+	}
+	if (g_test_item_common > 0)	/* VDL2GPU_TEST_ITEM_COMMON: a common area of so many items -- the list overflows */
+		q.surv_common_cap = g_test_item_common;
+#endif
 	q.surv_nwg = (int)grid.x;
 	q.surv_pch = (int)std::max(256u, std::min(want, VDL2_ITEM_PRIV / grid.x / 256u * 256u));
 	q.surv_slot = slot;

@@ -299,7 +299,10 @@ __device__ __forceinline__ void k2a_append(K2aShared &sh, const K2Params &p, int
 			const unsigned priv = (unsigned)p.surv_nwg * pch;
 			const unsigned off2 = atomicAdd(p.ctl + CTL_NSURV0 + p.surv_slot * p.nstreams * VDL2_CS + sc, cnt);
 			stride = VDL2_ITEM_CAP - priv;
-			base = (off2 + cnt <= stride) ? priv * K2A_ITEM_WORDS + off2 : 0xffffffffu;
+			const unsigned room = (p.surv_common_cap > 0 && (unsigned)p.surv_common_cap < stride) ? (unsigned)p.surv_common_cap : stride;
+			base = (off2 + cnt <= room) ? priv * K2A_ITEM_WORDS + off2 : 0xffffffffu;
+			if (base == 0xffffffffu)	/* refused: k2x_second must not read the common area from here on (nothing was written there) */
+				atomicMax(p.ctl + CTL_NSURVLIM0 + p.surv_slot * p.nstreams * VDL2_CS + sc, ~off2);
 		}
 	}
 	const int lead = __builtin_ctzll(m);
@@ -380,7 +383,12 @@ void k2x_second(K2Params p)
 	} else {
 		stride = VDL2_ITEM_CAP - priv;
 		unsigned nc = p.ctl[CTL_NSURV0 + p.surv_slot * p.nstreams * VDL2_CS + sc];
-		nc = nc > stride ? stride : nc;
+		{
+			const unsigned lim = ~p.ctl[CTL_NSURVLIM0 + p.surv_slot * p.nstreams * VDL2_CS + sc];
+			nc = nc > lim ? lim : nc;
+		}
+		nc = nc > stride ? stride : nc;	/* (a group that did not fit reserved past the end and wrote nothing: k2a_append; what lies below the first
+						 * such group is complete only if no group was refused -- and then the channel is flagged unusable anyway) */
 		const unsigned off = first - priv;
 		nhere = nc > off ? nc - off : 0;
 		w0 = priv * K2A_ITEM_WORDS + off;

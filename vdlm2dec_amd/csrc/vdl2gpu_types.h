@@ -189,6 +189,7 @@ struct K2Params {
 	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen, worked off by k2x_second (the next kernel on the stream) */
 	unsigned *wcount;	/* [VDL2_SURV_SLOTS][S*8][VDL2_MAXWG] items in each scan workgroup's private area (zeroed by k_push_init) */
 	int surv_pch, surv_nwg;	/* items a private area holds (a multiple of 256), scan workgroups per channel (= private areas) */
+	int surv_common_cap;	/* test hook: the common area holds only so many items (0: all that is left of the list) */
 	int surv_slot;		/* which of the push's scans this is: its item counters are ctl[CTL_NSURV0 + slot * S*8 ...] (VDL2_SURV_*) */
 	int surv_mode;		/* k2x_second: what a detector hit among the survivors means (k2a_emit: 0 candidates, 1 verify, 2 probe) */
 	int surv_skip;		/* k2x_second: hits in the probe's class are in the table already (region scan) */
@@ -217,7 +218,9 @@ enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repa
  * stream of its own), which therefore must not touch what it reads. */
 #define CTL_NSEL1 (CTL_CAND0 + (9 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)
 #define CTL_SELBASE1 (CTL_CAND0 + (10 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)
-#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (11 + VDL2_SURV_SLOTS) * (size_t)(nsc))
+#define CTL_NSURVLIM0 (CTL_CAND0 + (11 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)	/* [VDL2_SURV_SLOTS][S*8] ~(where the first group that the common area
+											 * refused would have begun): 0 = none refused; items below it are complete */
+#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (11 + 2 * VDL2_SURV_SLOTS) * (size_t)(nsc))
 
 struct K3Params {
 	const float2 *src;
