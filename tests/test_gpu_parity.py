@@ -735,3 +735,24 @@ def test_item_list_common_area_and_overflow(built, oracle, monkeypatch, hooks):
         assert st["serial_samples"] > 100_000, st       # the overflow was noticed and the serial machine took over
     else:
         assert st["serial_samples"] < 20_000, st        # the common area is an ordinary path: nothing fell back
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("rounds", [1, 2, 3])
+def test_superseded_repair_selections_leave_no_records_behind(built, oracle, monkeypatch, rounds):
+    """Region scan dropped (test build), so the verify pass finds an unlisted event behind nearly every burst and channels go
+    through several repair rounds and serial redos per push, over many short pushes (the output rings are reused every third
+    push).  A repair round's selection can be superseded by the next round's or by the serial redo: records must be reserved
+    for the FINAL selection only -- reserved-and-never-written records once handed out whatever an earlier push had left in the
+    ring (scripts/soak.py seeds 1006..1051 of round 4).  Every burst the oracle's, none extra."""
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", str(rounds))
+    spec = synth.random_scenario(2_000_000, S.FO8[:3], 7_000_000, seed=1019 + rounds, bursts_per_s=14.0, info_max=120)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=400_000, flags=_lib.F_TEST_NOREGION, testhooks=True) as rx:
+        got = rx.run(raw, block=400_000)
+        st = rx.stats()
+    assert _gpu_keys(got) == want and len(want) >= 80
+    assert st["repairs"] >= 5, st

@@ -727,8 +727,13 @@ void k2c_resolve(K2Params p)
 		/* the output records of the selected bursts, reserved in one piece: K2d's workgroups (one per burst) then need no
 		 * atomic of their own -- a thousand of them asking one device-scope counter for a slot at the same moment took 80 us,
 		 * more than decoding the bursts (the same effect as in k4_frames) */
-		if (s_walk[0] > 0 && p.sel_reserved)
-			p.ctl[(p.round > 0 ? CTL_SELBASE1 : CTL_SELBASE0) + sc] = atomicAdd(p.outc, (unsigned)s_walk[0]);
+		/* Only the FIRST pass reserves here: every record it reserves is written (K2d's first pass decodes every channel's first
+		 * selection, void or not).  A repair round's selection may be superseded by the next round's or by K2f's serial redo --
+		 * records reserved for it would stay unwritten: whatever an earlier push left in the ring there would be handed out
+		 * as bursts [found by scripts/soak.py's dropped-region-scan modes: two rounds, or a round and a redo].  The repaired
+		 * selection's records are reserved by K2f, when it is final. */
+		if (s_walk[0] > 0 && p.sel_reserved && p.round == 0)
+			p.ctl[CTL_SELBASE0 + sc] = atomicAdd(p.outc, (unsigned)s_walk[0]);
 	}
 	__syncthreads();
 	if (steady_end) {
@@ -779,6 +784,12 @@ void k2f_commit(K2Params p)
 		uint32_t *dst = reinterpret_cast<uint32_t *>(cs);
 		for (int i = tid; i < (int)(sizeof(ChanState) / 4); i += K2_NT)
 			dst[i] = src[i];
+		/* a channel the repair rounds re-resolved: its selection is final now -- the records K2d's second pass fills */
+		if (tid == 0 && p.sel_reserved && sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u)) {
+			const unsigned n = p.ctl[CTL_NSEL1 + sc];
+			if (n > 0)
+				p.ctl[CTL_SELBASE1 + sc] = atomicAdd(p.outc, n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n);
+		}
 		return;
 	}
 	MachCtx cx;

@@ -42,7 +42,9 @@
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
 #define K2X_WL 40		/* k2x_second: survivors whose exact phases are in LDS at once (2040 phases: four passes of the workgroup, two phases a lane and pass) */
+#ifndef K2X_NT
 #define K2X_NT 256		/* ... and the items a workgroup takes */
+#endif
 #define K2X_CV 64		/* of which the fit screen of so many runs in ONE wavefront (11 % get that far) */
 #define VDL2_ITEM_CAP 196608	/* evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
 				 * payload symbols alike: 39 000 of a 33 s class-scan).  The list is in two parts: a private area per scan

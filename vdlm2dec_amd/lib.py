@@ -88,6 +88,8 @@ def load(testhooks: bool = False):
     path = LIB_TEST_PATH if testhooks else LIB_PATH
     if not testhooks and os.environ.get("VDL2GPU_LIB"):
         path = os.environ["VDL2GPU_LIB"]      # development: another build of the same library (scripts/dev/abv.sh compares variants on one box)
+    if testhooks and os.environ.get("VDL2GPU_LIB_TEST"):
+        path = os.environ["VDL2GPU_LIB_TEST"]  # development: another -DVDL2GPU_TESTHOOKS build (bisecting with scripts/soak.py)
     if not os.path.exists(path):
         raise Vdl2GpuError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
