@@ -2,8 +2,8 @@
  * vdl2gpu.hip -- host side of libvdl2gpu.so: the C ABI of include/vdl2gpu.h.
  *
  * One handle = one MI355X, three pushes in the pipeline.  vdl2gpu_push() enqueues
- *   front stage (fstream):     [H2D copy] -> K1 channelise -> K2a probe / regions -> K2s sort -> carry for the next push
- *   back stage  (stream):      K2b clusters -> K2c resolve -> K2a verify (K2d payload beside it, on the payload stream)
+ *   front stage (fstream):     [H2D copy] -> K1 channelise -> K2a probe + K2x second stage / regions / region scan + K2x -> K2s sort -> carry for the next push
+ *   back stage  (stream):      K2b clusters -> K2c resolve -> K2a verify + K2x (K2d payload beside it, on the copy stream)
  *   tail        (pay_stream):  repair round (merge, resolve, verify) -> commit -> re-resolved payloads -> export -> counters
  * and returns; the front stage of one push runs beside the back stage of the one before and the tail of the one before that
  * (see vdl2gpu::Back and enqueue_back); plane sets, table sets and output rings exist three times, the slabs four times.
@@ -1017,7 +1017,7 @@ static void launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st
 	 * (28 per tile and class; the region scan's tiles are sync words: far more pass) plus a sync word's worth; what it does
 	 * not hold goes to the common area */
 	grid.x = std::min<unsigned>(grid.x, VDL2_MAXWG);
-	unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u) + 128u + 255u) / 256u * 256u;
+	unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u * (K2A_TS / 1024u)) + 128u + 255u) / 256u * 256u;	/* (42 of a 1024-instant tile pass: 2.7 % x 1.5) */
 	q.surv_common_cap = 0;	/* (0: whatever the list has left behind the private areas) */
 #ifdef VDL2GPU_TESTHOOKS
 	if (g_test_item_grid > 0) {	/* VDL2GPU_TEST_ITEM_GRID: few scan workgroups with the smallest private areas -- most items take the common area's path */
