@@ -871,11 +871,16 @@ def main():
                               "correction of MI355X_MICROARCH.md), replayed from the committed file -- PMC counters cannot be read by the run itself"
                 # the whole step from the same committed passes: every kernel's HBM traffic and vector instructions, launches per step as in the trace
                 sqf = pmf.replace("_hbm", "_sq")
-                sq = json.load(open(os.path.join(ROOT, "profiles", sqf)))["per_launch"]
+                sqj = json.load(open(os.path.join(ROOT, "profiles", sqf)))
+                sq = sqj["per_launch"]
                 per_step = pm.get("launches_per_step", {})
-                hbm = sum((2.0 * pm["FETCH_SIZE_KB_per_launch"].get(k, 0.0) + pm["WRITE_SIZE_KB_per_launch"].get(k, 0.0)) * 1024.0 * per_step.get(k, 1.0)
-                          for k in pm["FETCH_SIZE_KB_per_launch"])
-                vinst = sum(v.get("SQ_INSTS_VALU", 0.0) * per_step.get(k, 1.0) for k, v in sq.items())
+                if "per_step_bytes" in pm and "per_step" in sqj:      # every launch's counters summed, over the pushes of the profiled run
+                    hbm = sum(pm["per_step_bytes"].values())
+                    vinst = sum(v.get("SQ_INSTS_VALU", 0.0) for v in sqj["per_step"].values())
+                else:
+                    hbm = sum((2.0 * pm["FETCH_SIZE_KB_per_launch"].get(k, 0.0) + pm["WRITE_SIZE_KB_per_launch"].get(k, 0.0)) * 1024.0 * per_step.get(k, 1.0)
+                              for k in pm["FETCH_SIZE_KB_per_launch"])
+                    vinst = sum(v.get("SQ_INSTS_VALU", 0.0) * per_step.get(k, 1.0) for k, v in sq.items())
                 floor_ms = vinst * 4 / 1024 / 2.4e9 * 1e3
                 whole_step = {"valu_wave_insts": vinst, "valu_floor_ms": floor_ms, "hbm_traffic_bytes": hbm, "step_over_valu_floor": ms_step / floor_ms if floor_ms > 0 else None,
                               "hbm_traffic_over_algorithmic": hbm / (batch * nstr * sample_bytes) if batch else None,

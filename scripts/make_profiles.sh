@@ -43,8 +43,13 @@ def collect(dirs):
         for c, v in sorted(cs.items()):
             top = [x for x in v if x >= 0.8 * max(v)] if max(v) > 0 else v
             res[k][c] = sum(top) / len(top)
-    return res
-hb = collect(["/tmp/pr_f", "/tmp/pr_w"])
+    # per STEP: everything every launch of a kernel counted, over the pushes of the run (the handle's first push runs as four
+    # parts: the probe's launches minus three) -- what bench.py's roofline.whole_step adds up (a kernel's second launch of a
+    # push, e.g. the repair round's verify pass, is far smaller than its first: launches x the full-size mean overstates it)
+    npush = max(1, max((len(v) for v in vals["k2a_probe"].values()), default=4) - 3) if "k2a_probe" in vals else 1
+    per_step = {k: {c: sum(v) / npush for c, v in cs.items()} for k, cs in vals.items()}
+    return res, per_step
+hb, hb_step = collect(["/tmp/pr_f", "/tmp/pr_w"])
 res = {"FETCH_SIZE_KB_per_launch": {k: v["FETCH_SIZE"] for k, v in hb.items() if "FETCH_SIZE" in v},
        "WRITE_SIZE_KB_per_launch": {k: v["WRITE_SIZE"] for k, v in hb.items() if "WRITE_SIZE" in v},
        "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu --no-ring --no-parity "
@@ -58,9 +63,10 @@ try:
     res["launches_per_step"] = {k: round(v / pushes, 2) for k, v in ks.items() if k.startswith(("k", "void k"))}
 except (OSError, KeyError, ValueError):
     pass
+res["per_step_bytes"] = {k: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for k, v in hb_step.items()}
 json.dump(res, open(out + "/" + R + "_bench_pmc_hbm.json", "w"), indent=1)
-sq = collect(["/tmp/pr_s1", "/tmp/pr_s2", "/tmp/pr_s3"])
-json.dump({"per_launch": sq, "_note": "SQ_* in quad-cycles / instructions summed over the chip, GRBM_GUI_ACTIVE summed over the 8 XCDs; "
+sq, sq_step = collect(["/tmp/pr_s1", "/tmp/pr_s2", "/tmp/pr_s3"])
+json.dump({"per_launch": sq, "per_step": {k: {"SQ_INSTS_VALU": v.get("SQ_INSTS_VALU", 0.0)} for k, v in sq_step.items()}, "_note": "SQ_* in quad-cycles / instructions summed over the chip, GRBM_GUI_ACTIVE summed over the 8 XCDs; "
            "three --pmc passes of the command above"}, open(out + "/" + R + "_bench_pmc_sq.json", "w"), indent=1)
 PY
 $B 2>/dev/null | tail -1 > $OUT/${R}_bench_line.json
