@@ -805,10 +805,17 @@ static int create_impl(vdl2gpu_t *h)
 	 * density is known, 8.4 s -- a saturated channel (250 candidates a second) fills half of the tables in that long. */
 	h->split_unit = ((cfg.flags & VDL2GPU_F_RTL_QUIRK) || h->sdrclk != 500 || h->L != 80) ? 32768 : K1F_PER_IN;
 	h->split_default = (size_t)(36.0 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit;
+	{
+		/* the verify pass maps one workgroup to K2A_VRUN tiles and the item list has room for VDL2_MAXWG private areas: a part
+		 * must not have more tiles than that covers (36 s of air time are 3003 tiles, the bound is 4088) */
+		const double max_frames = ((double)VDL2_MAXWG * K2A_VRUN - 4.0) * 2.0 * K2A_TS - 2.0 * K2A_TS - (double)VDL2_CARRY_FRAMES;
+		const size_t max_part = (size_t)(max_frames * (double)h->sdrclk / 21.0) / h->split_unit * h->split_unit;
+		h->split_default = std::min(h->split_default, max_part);
+	}
 	h->split_samples = std::max(h->split_unit, (size_t)(8.4 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit);
 #ifdef VDL2GPU_TESTHOOKS
 	if (getenv("VDL2GPU_SPLIT_SAMPLES")) {
-		h->split_samples = (size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES"));
+		h->split_samples = std::min((size_t)atoll(getenv("VDL2GPU_SPLIT_SAMPLES")), h->split_default * 4 / 3);	/* (still inside the verify grid's bound) */
 		h->knob.split_fixed = true;
 	}
 #endif
@@ -1037,6 +1044,8 @@ static void launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st
 	case SCAN_REGION: hipLaunchKernelGGL(k2a_region, grid, dim3(K2A_THREADS), 0, st, q); break;
 	default: hipLaunchKernelGGL(k2a_verify, grid, dim3(K2A_THREADS), 0, st, q); break;
 	}
+	/* (a grid of just the private areas' chunks plus a few workgroups walking the common area -- no empty workgroups beyond
+	 * those -- was no faster: 32.9 us against 29.5 per launch) */
 	hipLaunchKernelGGL(k2x_second, dim3(K2X_GRID, grid.y, grid.z), dim3(K2X_NT), 0, st, q);
 }
 
