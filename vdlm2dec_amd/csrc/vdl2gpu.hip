@@ -44,11 +44,12 @@ static int g_test_item_grid = 0, g_test_item_common = 0;	/* read once per vdl2gp
 #endif
 
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
-#define NEVX 15	/* + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain; e[12] = before the verify pass
+#define NEVX 16	/* e[15] = the verify pass (round 0) has ended; + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain; e[12] = before the verify pass
 			 * (main stream, behind the wait for the resolver); e[13], e[14] = around the resolver (its own stream when hoisted) */
 struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
 	uint64_t samples;
+	uint64_t index;		/* which push of the handle (VDL2GPU_STAGE_DUMP) */
 	bool fast;
 	bool staged;
 	int fast_parts;		/* fast-kernel launches of this push (e[8]..e[9]); e[11] = end of the first period's general launch */
@@ -85,46 +86,51 @@ struct vdl2gpu {
 	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
 	unsigned k1_tbase[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* what they hold, per XCD (the same for every role and stream) */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
-	float2 *d_dec[VDL2_NSET] = { nullptr, nullptr, nullptr };	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
+	float2 *d_dec[VDL2_NSET] = {};	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
 							 * reader, the back stage's tail, was ENQUEUED -- with two sets the channeliser had to wait for that tail */
 	StreamState *d_ss = nullptr;
 	ChanState *d_cs = nullptr;
 	ChanCfg *d_cfg = nullptr;
 	uint8_t *d_pn = nullptr;
 	uint8_t *d_pn8 = nullptr;	/* ... by payload byte (K2Params.pn8) */
-	vdl2gpu_burst_t *d_recs[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* output rings, used in turn (push % 3): the calling thread waits for the
+	vdl2gpu_burst_t *d_recs[VDL2_NRING] = {};	/* output rings, used in turn (push % 3): the calling thread waits for the
 									 * ring's previous push only three pushes later -- with two rings it waited for the tail of the push
 									 * before last in every call, and the GPU's front stream waited for the calling thread */
 	unsigned *d_outc = nullptr;	/* [2*ring + {0,1}] = records written, dropped; [8], [9] running totals: serial redos, repairs */
-	bool ring_busy[VDL2_NRING] = { false, false, false };
-	hipEvent_t ring_done[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* the end of the push's tail: its records and counters are on the host */
-	hipEvent_t in_read[VDL2_NRING] = { nullptr, nullptr, nullptr };	/* its channeliser has read the caller's device buffer */
-	bool in_rec[VDL2_NRING] = { false, false, false };
-	uint64_t ring_push[VDL2_NRING] = { 0, 0, 0 };	/* which push filled the ring */
+	bool ring_busy[VDL2_NRING] = {};
+	hipEvent_t ring_done[VDL2_NRING] = {};	/* the end of the push's tail: its records and counters are on the host */
+	hipEvent_t in_read[VDL2_NRING] = {};	/* its channeliser has read the caller's device buffer */
+	bool in_rec[VDL2_NRING] = {};
+	uint64_t ring_push[VDL2_NRING] = {};	/* which push filled the ring */
 	hipStream_t copy_stream = nullptr;
-	unsigned *d_ctl[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* control words, see CTL_* in vdl2gpu_kernels.h */
+	unsigned *d_ctl[VDL2_NSET] = {};	/* control words, see CTL_* in vdl2gpu_kernels.h */
 	size_t ctl_words = 0;
 	unsigned rec_cap = 0;
-	Cand *d_cands[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	Cluster *d_clusters[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	int2 *d_clhead[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	BurstDesc *d_stage[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	unsigned *d_sel_list[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	unsigned *d_sel_list2[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* the repair rounds' selection (K2Params.sel_list2) */
-	int2 *d_regs[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	Seg *d_segs[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	int *d_fail[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	int *d_redo[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	ChanState *d_cs_out[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	int *d_skey[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	unsigned short *d_sidx[VDL2_NSET] = {nullptr, nullptr, nullptr}, *d_prim[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	int *d_seeds[VDL2_NSET] = {nullptr, nullptr, nullptr};
-	unsigned *d_wcount[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* items in the scan workgroups' private areas, per scan of the push */
-	K2aItem *d_items[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* what passed the scans' first screen (k2x_second works it off) */
+	Cand *d_cands[VDL2_NSET] = {};
+	Cluster *d_clusters[VDL2_NSET] = {};
+	int2 *d_clhead[VDL2_NSET] = {};
+	BurstDesc *d_stage[VDL2_NSET] = {};
+	unsigned *d_sel_list[VDL2_NSET] = {};
+	unsigned *d_sel_list2[VDL2_NSET] = {};	/* the repair rounds' selection (K2Params.sel_list2) */
+	int2 *d_regs[VDL2_NSET] = {};
+	Seg *d_segs[VDL2_NSET] = {};
+	int *d_fail[VDL2_NSET] = {};
+	int *d_redo[VDL2_NSET] = {};
+	ChanState *d_cs_out[VDL2_NSET] = {};
+	int *d_skey[VDL2_NSET] = {};
+	unsigned short *d_sidx[VDL2_NSET] = {}, *d_prim[VDL2_NSET] = {};
+	int *d_seeds[VDL2_NSET] = {};
+	unsigned *d_wcount[VDL2_NSET] = {};	/* items in the scan workgroups' private areas, per scan of the push */
+	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (k2x_second works it off) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
-	int k2d_grid = 128;	/* payload workgroups per channel */
+#ifndef VDL2_K2D_GRID
+#define VDL2_K2D_GRID 64
+#endif
+	int k2d_grid = VDL2_K2D_GRID;	/* payload workgroups per channel (VDL2GPU_K2D_GRID): 64 -- half the chip's wavefront slots at the kernel's 119 registers.
+					 * One workgroup per burst is a chain of latencies; 128 per channel held EVERY slot while the verify pass beside it
+					 * waited for them (0.472 against 0.462 ms per step at 64, same box; 32 and 16: 0.468, 0.469) */
 	int force_serial = 0;
 	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
 	int n_cu = 256;
@@ -132,23 +138,25 @@ struct vdl2gpu {
 	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown): an event record between two kernels of the chain
 					 * costs ~3 us, so only every stage_every-th push carries them (the sums are scaled up in harvest) */
 	int stage_every = 4;
+	bool stage_dump = false;	/* VDL2GPU_STAGE_DUMP=1: events on every push, their times printed when the push is collected (harvest_timing) */
+	hipEvent_t ev_origin = nullptr;
 	hipEvent_t k1_done[2] = {nullptr, nullptr};	/* per staging buffer (host input) */
-	hipEvent_t k2_done[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* per table set: the end of the tail of the push that used it */
-	bool k2_rec[VDL2_NSET] = {false, false, false};
+	hipEvent_t k2_done[VDL2_NSET] = {};	/* per table set: the end of the tail of the push that used it */
+	bool k2_rec[VDL2_NSET] = {};
 	hipStream_t pay_stream = nullptr;	/* K2d beside the verify pass; then the push's TAIL (repair rounds, commit, export, counters: see enqueue_back) */
 	hipEvent_t verify_done = nullptr, k2f_done = nullptr;	/* main -> tail: the verify pass has run; tail -> main: the channel states are committed */
 	bool k2f_rec = false;
 	hipStream_t tail_prev = nullptr;	/* the stream the previous push's tail ran on */
 	hipEvent_t k2c_done = nullptr, pay_done = nullptr;
-	unsigned *d_fmask[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* K2f's redo mask of the push in flight, 16 words */
-	bool ring_spec[VDL2_NRING] = {false, false, false};	/* that ring's K2d ran ahead of verify: honour the redo mask */
+	unsigned *d_fmask[VDL2_NSET] = {};	/* K2f's redo mask of the push in flight, 16 words */
+	bool ring_spec[VDL2_NRING] = {};	/* that ring's K2d ran ahead of verify: honour the redo mask */
 	int repair_rounds = 0;		/* adapted floor..4 from how often the serial fallback was needed */
 	int rounds_floor = 1;		/* one (resolver-only) repair round is always scheduled, see enqueue_back */
 	size_t split_samples = 0;	/* pushes longer than this are cut into parts (36 s of air time), see push_checked; halved
 					 * whenever a channel's candidate tables overflow */
 	size_t split_default = 0;
 	unsigned long long last_ovf_push = 0;
-	size_t ring_samples[VDL2_NRING] = {0, 0, 0};	/* samples (per stream) of the push that filled each output ring */
+	size_t ring_samples[VDL2_NRING] = {};	/* samples (per stream) of the push that filled each output ring */
 	double cand_dens[4] = {0, 0, 0, 0};	/* candidates per input sample of the busiest channel, last four parts collected */
 	unsigned cand_dens_n = 0;
 	size_t split_unit = 32768;	/* parts are multiples of this (k1_fast takes whole superperiods; the RTL quirk needs whole blocks) */
@@ -169,16 +177,16 @@ struct vdl2gpu {
 	 * page-locked host memory, which the GPU itself fills at the end of the push -- k_export_records -- so that collecting a
 	 * push's bursts is an index sort and ONE copy per record, into the caller's buffer), bits 0-31 = index there */
 	std::vector<uint64_t> ready_idx;
-	vdl2gpu_burst_t *h_slab[VDL2_NSLAB] = {nullptr, nullptr, nullptr, nullptr}, *d_slab[VDL2_NSLAB] = {nullptr, nullptr, nullptr, nullptr};	/* the slabs (push % 4) and their device addresses:
+	vdl2gpu_burst_t *h_slab[VDL2_NSLAB] = {}, *d_slab[VDL2_NSLAB] = {};	/* the slabs (push % 4) and their device addresses:
 									 * one more than rings, so that a ring collected at the last moment -- by the call that is about to reuse it -- still lies
 									 * untouched in its slab while the caller polls once more, instead of being copied aside at once */
-	int ring_slab[VDL2_NRING] = {0, 0, 0};	/* the slab of the push that filled the ring */
-	size_t slab_lo[VDL2_NSLAB] = {0, 0, 0, 0}, slab_hi[VDL2_NSLAB] = {0, 0, 0, 0};	/* ready_idx[lo, hi): where the handles into each slab lie (a push's are contiguous) */
+	int ring_slab[VDL2_NRING] = {};	/* the slab of the push that filled the ring */
+	size_t slab_lo[VDL2_NSLAB] = {}, slab_hi[VDL2_NSLAB] = {};	/* ready_idx[lo, hi): where the handles into each slab lie (a push's are contiguous) */
 	unsigned slab_cap = 0;
 	size_t ready_pos = 0;
 	/* block path in the pipeline (VDL2GPU_F_FRAMES) */
 	bool frames_on = false;
-	vdl2gpu_frame_t *d_frames[VDL2_NRING] = {nullptr, nullptr, nullptr};	/* byte buffers of compact entries */
+	vdl2gpu_frame_t *d_frames[VDL2_NRING] = {};	/* byte buffers of compact entries */
 	unsigned *d_k4tab = nullptr;	/* GF(256) and FCS tables of the block path */
 	unsigned *d_fcnt = nullptr;	/* [4*ring] frames written, [4*ring+1] dropped, [4*ring+2] bytes used */
 	unsigned frame_cap = 0;	/* bytes of a frame buffer (slots + arena) */
@@ -201,6 +209,7 @@ struct vdl2gpu {
 	struct {
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
 		bool no_tail = false;		/* VDL2GPU_NO_TAIL: everything behind the verify pass stays on the main stream */
+		double table_fill = 0.90;	/* VDL2GPU_TABLE_FILL (percent): how full the busiest channel's candidate table may get before parts are shortened */
 		bool front2 = false;		/* VDL2GPU_FRONT2=1: the second half of the front stage on the copy stream (measured: 0.477 against 0.475 ms, no gain) */
 		bool pay_tail = false;		/* VDL2GPU_PAY_TAIL: the payload decode beside the verify pass on the payload (tail) stream instead of the copy stream */
 		bool k2b_front = false;		/* VDL2GPU_K2B_FRONT: the cluster kernel at the end of the front stage instead of the start of the back stage */
@@ -233,7 +242,7 @@ struct vdl2gpu {
 		size_t pt_index = 0;	/* its PushTiming in `pending` */
 	} back;
 	hipStream_t fstream = nullptr;
-	hipEvent_t f_done[VDL2_NSET] = {nullptr, nullptr, nullptr};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
+	hipEvent_t f_done[VDL2_NSET] = {};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
 	hipEvent_t probe_done = nullptr;	/* front stream -> copy stream: the probe and its second stage have run (VDL2GPU_FRONT2) */
 	hipEvent_t k1_ev = nullptr;	/* channeliser + carry copy of the latest push that kept to the main stream */
 	hipEvent_t f_tail = nullptr;	/* the end of the latest front stage on fstream (carry copy included) */
@@ -551,20 +560,17 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	(void)hipFree(h->d_lo);
 	(void)hipFree(h->d_lo_ext);
 	(void)hipFree(h->d_k1_tickets);
-	(void)hipFree(h->d_dec[0]);
-	(void)hipFree(h->d_dec[1]);
-	(void)hipFree(h->d_dec[2]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_dec[r]);
 	(void)hipFree(h->d_ss);
 	(void)hipFree(h->d_cs);
 	(void)hipFree(h->d_cfg);
 	(void)hipFree(h->d_pn);
 	(void)hipFree(h->d_pn8);
-	(void)hipFree(h->d_recs[0]);
-	(void)hipFree(h->d_recs[1]);
-	(void)hipFree(h->d_recs[2]);
-	(void)hipFree(h->d_frames[0]);
-	(void)hipFree(h->d_frames[1]);
-	(void)hipFree(h->d_frames[2]);
+	for (int r = 0; r < VDL2_NRING; ++r) {
+		(void)hipFree(h->d_recs[r]);
+		(void)hipFree(h->d_frames[r]);
+	}
 	(void)hipFree(h->d_fcnt);
 	(void)hipFree(h->d_k4tab);
 	(void)hipFree(h->d_outc);
@@ -607,6 +613,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipEventDestroy(h->verify_done);
 	if (h->k2f_done)
 		(void)hipEventDestroy(h->k2f_done);
+	if (h->ev_origin)
+		(void)hipEventDestroy(h->ev_origin);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_fmask[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
@@ -686,11 +694,10 @@ static int create_impl(vdl2gpu_t *h)
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
 	h->cap = (VDL2_CARRY_FRAMES + jmax + 64 + 15) / 16 * 16;	/* planes start on 128-byte lines */
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
-	HIPCHK(h, hipMalloc(&h->d_dec[0], dec_bytes));
-	HIPCHK(h, hipMalloc(&h->d_dec[1], dec_bytes));
-	HIPCHK(h, hipMalloc(&h->d_dec[2], dec_bytes));
-	for (int r = 0; r < VDL2_NSET; ++r)
-		HIPCHK(h, hipMemsetAsync(h->d_dec[r], 0, (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2), h->stream));
+	for (int r = 0; r < VDL2_NSET; ++r) {
+		HIPCHK(h, hipMalloc(&h->d_dec[r], dec_bytes));
+		HIPCHK(h, hipMemsetAsync(h->d_dec[r], 0, dec_bytes, h->stream));
+	}
 	HIPCHK(h, hipMalloc(&h->d_lo, (size_t)S * VDL2_CS * L * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_lo_ext, (size_t)S * VDL2_CS * (L + 48) * sizeof(float2)));
 	HIPCHK(h, hipMalloc(&h->d_k1_tickets, (size_t)S * 21 * 8 * sizeof(unsigned)));
@@ -781,6 +788,9 @@ static int create_impl(vdl2gpu_t *h)
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
 	h->stage_every = std::max(1, env_int("VDL2GPU_STAGE_EVERY", h->stage_every));
+	h->stage_dump = env_int("VDL2GPU_STAGE_DUMP", 0) != 0;
+	if (h->stage_dump)
+		h->stage_every = 1;
 	h->k2d_grid = std::max(1, env_int("VDL2GPU_K2D_GRID", h->k2d_grid));
 	h->knob.no_k1_fast = getenv("VDL2GPU_NO_K1_FAST") != nullptr;
 	h->hprof_on = getenv("VDL2GPU_HOST_PROF") != nullptr;
@@ -788,6 +798,7 @@ static int create_impl(vdl2gpu_t *h)
 	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
 	h->knob.pay_tail = env_int("VDL2GPU_PAY_TAIL", 0) != 0;
 	h->knob.front2 = env_int("VDL2GPU_FRONT2", 0) != 0;
+	h->knob.table_fill = std::min(100, std::max(10, env_int("VDL2GPU_TABLE_FILL", 90))) / 100.0;
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
 	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
 	h->knob.k1f_nfam = env_int("VDL2GPU_K1F_NFAM", 0);
@@ -947,6 +958,8 @@ extern "C" int vdl2gpu_create(const vdl2gpu_config_t *cfg, vdl2gpu_t **out)
 	const int rc = create_impl(h);
 	if (rc != VDL2GPU_OK) {
 		std::string e = h->err;
+		if (getenv("VDL2GPU_VERBOSE"))	/* (there is no handle to ask vdl2gpu_last_error() of) */
+			fprintf(stderr, "vdl2gpu_create: %s\n", e.c_str());
 		vdl2gpu_destroy(h);
 		*out = nullptr;
 		return rc;
@@ -972,6 +985,23 @@ static int harvest_timing(vdl2gpu_t *h)
 {
 	for (auto &pt : h->pending) {
 		float d[NEV - 1] = {0};
+		if (h->stage_dump && pt.staged && h->ev_origin) {
+			/* VDL2GPU_STAGE_DUMP=1: where every stage of every push began and ended on the GPU's clock, in us since the handle's
+			 * first push -- a Gantt chart of the pipeline as it runs WITHOUT a profiler (under rocprofv3 the calling thread is
+			 * what the streams wait for).  e0 K1 begins | e1 K1 ends | e10 scan begins | e4 front ends | e2 clusters begin |
+			 * e3 = e13 clusters end | e14 resolver ends | e12 verify begins | e15 verify ends | e5 rounds end | e6 commit..export end | e7 tail ends */
+			static const int order[] = {0, 1, 10, 4, 2, 13, 14, 12, 15, 5, 6, 7};
+			fprintf(stderr, "vdl2gpu stage dump push %llu:", (unsigned long long)pt.index);
+			for (int k : order) {
+				float t = -1.0f;
+				if (hipEventElapsedTime(&t, h->ev_origin, pt.e[k]) != hipSuccess) {
+					(void)hipGetLastError();
+					t = -1.0f;
+				}
+				fprintf(stderr, " e%d=%.1f", k, t * 1e3f);
+			}
+			fprintf(stderr, "\n");
+		}
 		for (int i = 0; i + 1 < NEV; ++i) {	/* the demodulator chain starts at e[10], not where the channeliser ended */
 			if (!pt.staged)
 				break;
@@ -1188,7 +1218,7 @@ static int enqueue_back(vdl2gpu_t *h)
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[2], rs));
 	if (!serial && !h->knob.k2b_front)
-		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[3], rs));
@@ -1225,6 +1255,8 @@ static int enqueue_back(vdl2gpu_t *h)
 	if (!serial)
 		launch_scan(SCAN_VERIFY, k2, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), h->stream, VDL2_SURV_VERIFY, 1, 0, K2A_VRUN);
 	HIPCHK(h, hipGetLastError());
+	if (staged && h->stage_dump)
+		HIPCHK(h, hipEventRecord(pt.e[15], h->stream));
 	/* ---- the TAIL: everything behind the verify pass -- repair rounds, commit, the payloads a round re-resolved, block path,
 	 * export, counters: a chain of one-workgroup-per-channel kernels and a PCIe copy, 0.1 ms while nothing fails and 0.3 ms when
 	 * a channel is repaired (most pushes of ordinary traffic).  On the main stream it stood between this push's verify pass and
@@ -1269,7 +1301,7 @@ static int enqueue_back(vdl2gpu_t *h)
 				per = per > want ? want : per;
 				launch_scan(SCAN_PROBE, k2r, dim3(per, (unsigned)h->C, (unsigned)h->S), ts, VDL2_SURV_FULL, 0, 0, 4 * ((want + per - 1) / per));
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, ts, k2r);
-				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
+				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
 			} else {
 				hipLaunchKernelGGL(k2s_merge, gch, dim3(K2M_NT), 0, ts, k2r);
@@ -1469,6 +1501,11 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	pt.samples = nsamples;
 	pt.fast = false;
 	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
+	pt.index = h->pushes;
+	if (h->stage_dump && !h->ev_origin) {
+		HIPCHK(h, hipEventCreate(&h->ev_origin));
+		HIPCHK(h, hipEventRecord(h->ev_origin, h->stream));
+	}
 	const bool staged = pt.staged;
 	/* The channeliser opens the front stage (fstream; the main stream for a push that takes the serial path). */
 	hipStream_t ks = fs;
@@ -1780,7 +1817,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		if (!serial)
 			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs2, k2);
 		if (!serial && h->knob.k2b_front)
-			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_WAVES), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
+			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
 		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[4], fs2));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
 		HIPCHK(h, hipGetLastError());
@@ -1938,7 +1975,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			dmax = std::max(dmax, x);
 		size_t lim = h->split_default;
 		if (dmax > 0.0)
-			lim = (size_t)std::min((double)h->split_default, std::max(0.0, 0.90 * (double)VDL2_CAND_CAP / dmax - (double)VDL2_CARRY_FRAMES * (double)h->sdrclk / 21.0));
+			lim = (size_t)std::min((double)h->split_default, std::max(0.0, h->knob.table_fill * (double)VDL2_CAND_CAP / dmax - (double)VDL2_CARRY_FRAMES * (double)h->sdrclk / 21.0));
 		h->split_samples = std::max(h->split_unit, lim / h->split_unit * h->split_unit);
 		if (novf)
 			h->last_ovf_push = h->ring_push[ring];

@@ -173,6 +173,9 @@ static_assert(VDL2_CAND_CAP % K2M_NT == 0 && K2S_MERGE <= K2M_NT, "k2s_merge");
 #ifndef K2B_WAVES
 #define K2B_WAVES 3	/* 163 registers: with 4 (128) the compiler spilled 12-20 of them to scratch; the kernel's time does not depend on 3 / 4 / 6 wavefronts per SIMD */
 #endif
+#ifndef K2B_GRIDW
+#define K2B_GRIDW K2B_WAVES	/* wavefronts per SIMD the cluster kernel's (persistent) grid asks for */
+#endif
 __global__ __launch_bounds__(K2B_NT) __attribute__((amdgpu_waves_per_eu(K2B_WAVES, 8)))
 void k2b_clusters(K2Params p)
 {

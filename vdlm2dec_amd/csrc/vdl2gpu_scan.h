@@ -45,6 +45,13 @@
 #ifndef K2X_NT
 #define K2X_NT 256		/* ... and the items a workgroup takes */
 #endif
+#ifndef K2X_ATTR
+/* Five wavefronts per SIMD (96 registers; the compiler parks three of them in scratch around the exact stage's batch loop, stored once per
+ * workgroup that gets that far and re-read once per batch of 40 survivors).  The kernel is a chain of latencies (77 % of its wave cycles
+ * waiting), and what it costs the step is the register space its waiting wavefronts hold while the wide kernels of the other two pushes
+ * look for a slot: at 121 registers / four wavefronts per SIMD the step was 0.483 ms, at 96 / five 0.466 (same box, alternating). */
+#define K2X_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
+#endif
 #define K2X_CV 64		/* of which the fit screen of so many runs in ONE wavefront (11 % get that far) */
 #define VDL2_ITEM_CAP 196608	/* evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
 				 * payload symbols alike: 39 000 of a 33 s class-scan).  The list is in two parts: a private area per scan
@@ -96,11 +103,14 @@ struct alignas(16) K2aShared {
 	float2 xs[K2A_XS_LEN];
 	float smf[72];			/* low-pass taps mflt[] (d8psk.h:28-45) */
 	unsigned it_used, it_limit;	/* items the workgroup has put into its private area; where the first group that did not fit would have begun */
+	unsigned short pend[K2A_THREADS / 64][K2A_TS / (K2A_THREADS / 64)];	/* per wavefront: the evaluations of a tile and sub-phase that passed the
+					 * first screen (instant within the tile | 0x8000: a non-finite phasor), appended as ONE group behind the screen passes */
 	unsigned long long prof[16];	/* diagnostics: stage cycle counters of the workgroup's first lane, added to p.dbg at the end
 					 * (a global atomic per stamp would sit in front of the tile's next s_waitcnt vmcnt) */
 };
 static_assert(K2A_WU1 % 2 == 0 && K2A_XS_LEN >= K2A_XMAX + 8 && (K2A_XMAX / 2 + 4) % 2 == 0, "16-byte reads of xs[] and wu[]");
 static_assert(K2A_TS + K2A_POFF / 2 + 2 <= K2A_XS_LEN && K2A_WU1 >= K2A_TS + K2A_XOFF, "phasor areas");
+static_assert(K2A_TS <= 1024, "pend[] holds an instant within the tile in ten bits");
 #define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
 
 /* Screens for the 17-point fit (the expensive part of the scan).
@@ -364,7 +374,7 @@ struct K2xShared {
  * reference's order from the channel plane, then atan2f, d8psk.c:219-229), exact fits (d8psk.c:257-289) of the evaluation and
  * its two neighbours, detector test (d8psk.c:292).  Survivors are rare since the fourth screen: a handful per sync word and
  * class, one per 20 000 instants of noise. */
-__global__ __launch_bounds__(K2X_NT)
+__global__ __launch_bounds__(K2X_NT) K2X_ATTR
 void k2x_second(K2Params p)
 {
 	__shared__ K2xShared sh;
@@ -780,8 +790,14 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		}
 		K2A_STAMP(3);
 		K2A_SYNC();
-		/* ---- first screen, of the evaluation that is the `perr` of instant i: j = i + E2; what passes goes to the item list */
-		for (int i0 = 0; i0 < cnt; i0 += K2A_THREADS) {	/* (wave-uniform trip count: k2a_append votes) */
+		/* ---- first screen, of the evaluation that is the `perr` of instant i: j = i + E2.  What passes (2.7 % on noise: seven of a
+		 *      wavefront's 256 evaluations) is only NOTED here, two bytes in the wavefront's own queue; the items -- sixteen phasors
+		 *      re-read from wu[], packed, five 16-byte stores, one LDS atomic -- are written behind the passes as one group per
+		 *      wavefront, tile and sub-phase [until round 4 every pass in which anything passed, 83 % of them, ran the whole append:
+		 *      a quarter of a tile's instructions].  The queue is the wavefront's own: LDS operations of one wavefront execute in
+		 *      order, no barrier is needed between its writes and its reads. */
+		unsigned npend = 0;	/* (wave-uniform) */
+		for (int i0 = 0; i0 < cnt; i0 += K2A_THREADS) {	/* (wave-uniform trip count) */
 			const int i = i0 + tid;
 			const int j = (i < cnt ? i : cnt - 1) + E2;
 			const float2 *uq = &wu[PH - E4 + j - 15 * LSTR];
@@ -819,12 +835,29 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 			const v2f acc = {__fmaf_rn(qa.x - qa.y, RH, pa.x), __fmaf_rn(qa.x + qa.y, RH, pa.y)};
 #endif
 			const float r2 = __fmaf_rn(acc.x, acc.x, acc.y * acc.y);
-			const long long n_abs = nbase + S * (j - E4);	/* the evaluation's instant */
 			bool pass = i < cnt && !(r2 <= VDL2_SCREEN_R2);
-			if (mode == 0 && r == skip_r && (int)(n_abs & 1) == skip_par)
+			if (mode == 0 && r == skip_r && (int)((nbase + S * (j - E4)) & 1) == skip_par)
 				pass = false;	/* region scan: that class is the probe's, its hits are in the table already */
-			k2a_append(sh, p, sc, pass, (int)(n_abs - dec_base), r, (mode == 1) ? (int)(chk_lo - dec_base) : 0,
-				   (mode == 1) ? (int)(chk_hi - dec_base) : 0, uu, !(r2 == r2), mode, fail);
+			const unsigned long long m = __ballot(pass);
+			if (m != 0) {
+				if (pass)
+					sh.pend[wv][npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+						(unsigned short)(i | (!(r2 == r2) ? 0x8000 : 0));
+				npend += (unsigned)__popcll(m);
+			}
+		}
+		for (unsigned b = 0; b < npend; b += 64) {	/* (one turn, unless a carrier or a run of sync words lies in the tile) */
+			const bool on = b + (unsigned)ln < npend;
+			const int e = on ? (int)sh.pend[wv][b + (unsigned)ln] : 0;
+			const int j = (e & 0x3ff) + E2;
+			const float2 *uq = &wu[PH - E4 + j - 15 * LSTR];
+			float2 uu[16];
+#pragma unroll
+			for (int l = 0; l < 16; ++l)
+				uu[l] = uq[l * LSTR];
+			const long long n_abs = nbase + S * (j - E4);	/* the evaluation's instant */
+			k2a_append(sh, p, sc, on, (int)(n_abs - dec_base), r, (mode == 1) ? (int)(chk_lo - dec_base) : 0,
+				   (mode == 1) ? (int)(chk_hi - dec_base) : 0, uu, (e & 0x8000) != 0, mode, fail);
 		}
 		K2A_STAMP(4);
 		K2A_STAMP(8);

@@ -9,9 +9,12 @@
 #include "../../include/vdl2gpu.h"
 
 #define VDL2_CS 8		/* channel planes per stream */
-#define VDL2_NSET 3		/* plane sets, table sets and output rings, used in turn (push % 3): three pushes in the pipeline, the oldest in its tail */
+#ifndef VDL2_NSET
+#define VDL2_NSET 3		/* plane sets, table sets and output rings, used in turn (push % VDL2_NSET): so many pushes in the pipeline, the oldest in its tail */
+#endif
 #define VDL2_NRING VDL2_NSET	/* output rings (records, frames, counters) */
-#define VDL2_NSLAB 4		/* page-locked slabs the records are exported to, used in turn */
+#define VDL2_NSLAB (VDL2_NSET + 1)	/* page-locked slabs the records are exported to, used in turn */
+static_assert(VDL2_NSET >= 3 && VDL2_NSET <= 4, "d_outc[] has the per-ring counters in front of the running totals at [8]; three bits of a record handle name its slab");
 #define VDL2_HIST 160		/* frames of history kept: 17-tap FIR + 17 symbols x 8 + slack */
 #define VDL2_NPH 68		/* NBPH*D8DWN, vdlm2.h:54-55 */
 #define VDL2_STEADY 68		/* evaluations after which the detector forgot the last burst */
