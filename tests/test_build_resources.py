@@ -56,3 +56,15 @@ def test_the_critical_kernels_touch_no_scratch(resources):
     for k, r in resources.items():
         if any(n in k for n in ("k2b_clusters", "k2c_resolve", "k2f_commit")):
             assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
+
+
+def test_scan_kernels_keep_their_wavefronts(resources):
+    """Round 4: the scan kernels at six wavefronts per SIMD (80 registers, no scratch); the sparse stages at five -- 96 registers, of
+    which the compiler parks three around the exact stage's batch loop (16 bytes: build() allows exactly that): a latency-bound
+    kernel's cost to the step is the register space its waiting wavefronts hold."""
+    for k in ("_Z9k2a_probe8K2Params", "_Z10k2a_verify8K2Params"):
+        r = resources[k]
+        assert r["VGPRs"] <= 80 and r["Occupancy [waves/SIMD]"] >= 6 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
+        assert r["LDS Size [bytes/block]"] * 6 <= 160 * 1024, (k, r)
+    r = resources["_Z10k2x_second8K2Params"]
+    assert r["VGPRs"] <= 96 and r["Occupancy [waves/SIMD]"] >= 5 and r["ScratchSize [bytes/lane]"] <= 16, r

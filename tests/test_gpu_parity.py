@@ -756,3 +756,37 @@ def test_superseded_repair_selections_leave_no_records_behind(built, oracle, mon
         st = rx.stats()
     assert _gpu_keys(got) == want and len(want) >= 80
     assert st["repairs"] >= 5, st
+
+
+def test_stage_dump_is_a_gantt_chart_of_the_pipeline(built, oracle, tmp_path):
+    """VDL2GPU_STAGE_DUMP=1: every push prints where its stages began and ended on the GPU's clock (the pipeline's Gantt chart
+    without a profiler, scripts/dev/stage_gantt.py) -- ordered in time within a push, and the bursts are the oracle's all the same."""
+    import re
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import scenarios as S\n"
+        "from vdlm2dec_amd import synth\n"
+        "from vdlm2dec_amd.demod import Receiver, plan_channels\n"
+        "spec = synth.random_scenario(2_000_000, S.FO8, 3 << 21, seed=91, bursts_per_s=6.0, info_max=120)\n"
+        "raw = synth.synth_stream(spec, 'cs16')\n"
+        "with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt='cs16', max_push=1 << 21) as rx:\n"
+        "    got = rx.run(raw, block=1 << 21)\n"
+        "print('KEYS', sorted((b.chn, b.nbrow, b.nlbyte, bytes(b.data).hex()) for b in got))\n"
+    ) % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ, VDL2GPU_STAGE_DUMP="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [dict((int(k), float(v)) for k, v in re.findall(r"e(\d+)=(-?[\d.]+)", ln))
+            for ln in r.stderr.splitlines() if ln.startswith("vdl2gpu stage dump push")]
+    assert len(rows) >= 3, r.stderr[-2000:]
+    for e in rows:
+        chain = [e[k] for k in (0, 1, 10, 4, 2, 13, 14, 12, 15, 5, 6, 7)]
+        assert all(t >= 0.0 for t in chain), e
+        assert chain == sorted(chain), e                 # a push's stages follow each other
+    spec = synth.random_scenario(2_000_000, S.FO8, 3 << 21, seed=91, bursts_per_s=6.0, info_max=120)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(k[:3] + (bytes(k[3]).hex(),) for k in (b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC)))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("KEYS ")][0]
+    assert eval(line[5:]) == want
