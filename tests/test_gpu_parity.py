@@ -773,6 +773,7 @@ def test_stage_dump_is_a_gantt_chart_of_the_pipeline(built, oracle, tmp_path):
         "raw = synth.synth_stream(spec, 'cs16')\n"
         "with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt='cs16', max_push=1 << 21) as rx:\n"
         "    got = rx.run(raw, block=1 << 21)\n"
+        "    rx.sync()\n"
         "print('KEYS', sorted((b.chn, b.nbrow, b.nlbyte, bytes(b.data).hex()) for b in got))\n"
     ) % (os.path.dirname(HERE), HERE)
     env = dict(os.environ, VDL2GPU_STAGE_DUMP="1")

@@ -1502,10 +1502,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	pt.fast = false;
 	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
 	pt.index = h->pushes;
-	if (h->stage_dump && !h->ev_origin) {
-		HIPCHK(h, hipEventCreate(&h->ev_origin));
-		HIPCHK(h, hipEventRecord(h->ev_origin, h->stream));
-	}
 	const bool staged = pt.staged;
 	/* The channeliser opens the front stage (fstream; the main stream for a push that takes the serial path). */
 	hipStream_t ks = fs;
@@ -1523,6 +1519,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	}
 	if (staged_in)
 		HIPCHK(h, hipStreamWaitEvent(ks, h->raw_copied[stg], 0));
+	if (staged && h->stage_dump && !h->ev_origin) {	/* the origin of the dump's times: in front of the first push's first event, on its stream */
+		HIPCHK(h, hipEventCreate(&h->ev_origin));
+		HIPCHK(h, hipEventRecord(h->ev_origin, ks));
+	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[0], ks));
 	{
