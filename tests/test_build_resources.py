@@ -59,12 +59,33 @@ def test_the_critical_kernels_touch_no_scratch(resources):
 
 
 def test_scan_kernels_keep_their_wavefronts(resources):
-    """Round 4: the scan kernels at six wavefronts per SIMD (80 registers, no scratch); the sparse stages at five -- 96 registers, of
-    which the compiler parks three around the exact stage's batch loop (16 bytes: build() allows exactly that): a latency-bound
-    kernel's cost to the step is the register space its waiting wavefronts hold."""
-    for k in ("_Z9k2a_probe8K2Params", "_Z10k2a_verify8K2Params"):
+    """The scan kernels at six wavefronts per SIMD (80 registers).  Since round 5 a scan workgroup takes what passed its first screen
+    through the sparse stages itself, behind its last tile (k2a_tail): those stages may park loop invariants in scratch (bounded:
+    build() checks the size), the tile loop may not touch it (next test)."""
+    import __graft_entry__ as g
+    for k, regs, waves in (("_Z9k2a_probe8K2Params", 80, 6), ("_Z10k2a_verify8K2Params", 80, 6), ("_Z10k2a_region8K2Params", 96, 5)):
         r = resources[k]
-        assert r["VGPRs"] <= 80 and r["Occupancy [waves/SIMD]"] >= 6 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
-        assert r["LDS Size [bytes/block]"] * 6 <= 160 * 1024, (k, r)
-    r = resources["_Z10k2x_second8K2Params"]
-    assert r["VGPRs"] <= 96 and r["Occupancy [waves/SIMD]"] >= 5 and r["ScratchSize [bytes/lane]"] <= 16, r
+        assert r["VGPRs"] <= regs and r["Occupancy [waves/SIMD]"] >= waves and r["ScratchSize [bytes/lane]"] <= g.SCAN_TAIL_SCRATCH, (k, r)
+        assert r["LDS Size [bytes/block]"] * waves <= 160 * 1024, (k, r)
+    assert not any("k2x_second" in k for k in resources)      # four launches a push until round 4
+
+
+def test_scan_tile_loops_touch_no_scratch(tmp_path):
+    """The ISA of the scan kernels: every scratch access lies behind the marker k2a_tail() plants where it reads the kernel's
+    parameters again -- i.e. in the sparse stages a workgroup runs once, not in the tile loop it runs eight times."""
+    import subprocess
+    import __graft_entry__ as g
+    asm = tmp_path / "vdl2gpu.s"
+    flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-S", "--cuda-device-only", "-w",
+                           os.path.join(g.CSRC, "vdl2gpu.hip"), "-o", str(asm)])
+    text = asm.read_text().splitlines()
+    for kern in ("_Z9k2a_probe8K2Params", "_Z10k2a_verify8K2Params", "_Z10k2a_region8K2Params"):
+        start = text.index(next(ln for ln in text if ln.startswith(kern + ":")))
+        end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
+        body = text[start:end]
+        marks = [i for i, ln in enumerate(body) if "kernarg again" in ln]
+        scratch = [i for i, ln in enumerate(body) if ln.strip().startswith(("scratch_", "buffer_store", "buffer_load"))]
+        assert marks, kern
+        # what the compiler parks for the tail it may park in the straight-line code right in front of the marker (behind the loop's exit)
+        assert not [i for i in scratch if i < marks[0] - 32], (kern, "scratch access inside the tile loop")

@@ -120,8 +120,7 @@ struct vdl2gpu {
 	int *d_skey[VDL2_NSET] = {};
 	unsigned short *d_sidx[VDL2_NSET] = {}, *d_prim[VDL2_NSET] = {};
 	int *d_seeds[VDL2_NSET] = {};
-	unsigned *d_wcount[VDL2_NSET] = {};	/* items in the scan workgroups' private areas, per scan of the push */
-	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (k2x_second works it off) */
+	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (worked off by the scan workgroups themselves; the common area by the next kernel) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
@@ -651,8 +650,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipFree(h->d_seeds[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_items[r]);
-	for (int r = 0; r < VDL2_NSET; ++r)
-		(void)hipFree(h->d_wcount[r]);
 	(void)hipFree(h->d_dbg);
 	(void)hipFree(h->d_headtap);
 	(void)hipFree(h->d_headtap_n);
@@ -780,10 +777,6 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
-	for (int r = 0; r < VDL2_NSET; ++r) {
-		HIPCHK(h, hipMalloc(&h->d_wcount[r], (size_t)VDL2_SURV_SLOTS * S * VDL2_CS * VDL2_MAXWG * sizeof(unsigned)));
-		HIPCHK(h, hipMemsetAsync(h->d_wcount[r], 0, (size_t)VDL2_SURV_SLOTS * S * VDL2_CS * VDL2_MAXWG * sizeof(unsigned), h->stream));
-	}
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
@@ -1045,9 +1038,20 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking);
 static int enqueue_back(vdl2gpu_t *h);
 static void spill_slab(vdl2gpu_t *h, int slab);
 
-/* A scan kernel and, right behind it on the same stream, the sparse stages over what passed its first screen (k2x_second). */
+/* A scan kernel.  Its workgroups work what passes their first screen off themselves, behind their last tile (k2a_tail); what
+ * their private areas of the item list did not hold is left in the list's common area for the one-workgroup-per-channel kernel
+ * that follows on the stream -- `drain` says where that is (put into that kernel's parameters with scan_drain()). */
 enum { SCAN_PROBE, SCAN_REGION, SCAN_VERIFY };
-static void launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st, int slot, int mode, int skip, unsigned tiles_per_wg)
+struct ScanDrain { int slot = -1, mode = 0, skip = 0, pch = 0, nwg = 0; };
+static void scan_drain(K2Params &q, const ScanDrain &d)
+{
+	q.drain_slot = d.slot;
+	q.drain_mode = d.mode;
+	q.drain_skip = d.skip;
+	q.drain_pch = d.pch;
+	q.drain_nwg = d.nwg;
+}
+static ScanDrain launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st, int slot, int mode, int skip, unsigned tiles_per_wg)
 {
 	K2Params q = k2;
 	/* a scan workgroup's private part of the item list: one and a half times what its tiles yield at the first screen's 2.7 %
@@ -1069,14 +1073,19 @@ static void launch_scan(int which, const K2Params &k2, dim3 grid, hipStream_t st
 	q.surv_slot = slot;
 	q.surv_mode = mode;
 	q.surv_skip = skip;
+	q.drain_slot = -1;
 	switch (which) {
 	case SCAN_PROBE: hipLaunchKernelGGL(k2a_probe, grid, dim3(K2A_THREADS), 0, st, q); break;
 	case SCAN_REGION: hipLaunchKernelGGL(k2a_region, grid, dim3(K2A_THREADS), 0, st, q); break;
 	default: hipLaunchKernelGGL(k2a_verify, grid, dim3(K2A_THREADS), 0, st, q); break;
 	}
-	/* (a grid of just the private areas' chunks plus a few workgroups walking the common area -- no empty workgroups beyond
-	 * those -- was no faster: 32.9 us against 29.5 per launch) */
-	hipLaunchKernelGGL(k2x_second, dim3(K2X_GRID, grid.y, grid.z), dim3(K2X_NT), 0, st, q);
+	ScanDrain d;
+	d.slot = slot;
+	d.mode = mode;
+	d.skip = skip;
+	d.pch = q.surv_pch;
+	d.nwg = q.surv_nwg;
+	return d;
 }
 
 template <int FMT> static void launch_k1(const K1Params &p, dim3 grid, size_t smem, hipStream_t st)
@@ -1252,8 +1261,9 @@ static int enqueue_back(vdl2gpu_t *h)
 	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[12], h->stream));
+	ScanDrain vdrain;	/* the verify pass whose common area the next one-workgroup-per-channel kernel of the tail has to drain */
 	if (!serial)
-		launch_scan(SCAN_VERIFY, k2, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), h->stream, VDL2_SURV_VERIFY, 1, 0, K2A_VRUN);
+		vdrain = launch_scan(SCAN_VERIFY, k2, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), h->stream, VDL2_SURV_VERIFY, 1, 0, K2A_VRUN);
 	HIPCHK(h, hipGetLastError());
 	if (staged && h->stage_dump)
 		HIPCHK(h, hipEventRecord(pt.e[15], h->stream));
@@ -1295,25 +1305,36 @@ static int enqueue_back(vdl2gpu_t *h)
 			k2r.full_round = (rr == h->repair_rounds && h->repair_rounds >= 2) ? 1 : 0;
 			k2r.mini_round = k2r.full_round ? 0 : 1;
 			if (k2r.full_round) {
+				scan_drain(k2r, vdrain);
 				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, ts, k2r);	/* (resets the channel's tables) */
+				scan_drain(k2r, ScanDrain());
 				const unsigned want = tiles;
 				unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
 				per = per > want ? want : per;
-				launch_scan(SCAN_PROBE, k2r, dim3(per, (unsigned)h->C, (unsigned)h->S), ts, VDL2_SURV_FULL, 0, 0, 4 * ((want + per - 1) / per));
+				const ScanDrain pdrain = launch_scan(SCAN_PROBE, k2r, dim3(per, (unsigned)h->C, (unsigned)h->S), ts, VDL2_SURV_FULL, 0, 0, 4 * ((want + per - 1) / per));
+				scan_drain(k2r, pdrain);
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, ts, k2r);
+				scan_drain(k2r, ScanDrain());
 				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
+				vdrain = ScanDrain();	/* (nothing is verified behind a complete round) */
 			} else {
+				scan_drain(k2r, vdrain);
 				hipLaunchKernelGGL(k2s_merge, gch, dim3(K2M_NT), 0, ts, k2r);
+				scan_drain(k2r, ScanDrain());
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
-				launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
+				vdrain = launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
 			}
 		}
 		HIPCHK(h, hipGetLastError());
 	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[5], ts));
-	hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, ts, k2);
+	{
+		K2Params k2f = k2;
+		scan_drain(k2f, vdrain);
+		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, ts, k2f);
+	}
 	HIPCHK(h, hipEventRecord(h->k2f_done, ts));
 	h->k2f_rec = true;
 	if (h->ring_spec[ring]) {
@@ -1722,9 +1743,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		ki.nsc = h->S * VDL2_CS;
 		ki.fmask = h->d_fmask[par];
 		ki.fcnt = h->frames_on ? h->d_fcnt + 4 * ring : nullptr;
-		ki.wcount = h->d_wcount[par];
-		ki.wcount_words = VDL2_SURV_SLOTS * h->S * VDL2_CS * VDL2_MAXWG;
-		hipLaunchKernelGGL(k_push_init, dim3((unsigned)std::min(64, 1 + ki.wcount_words / 16384)), dim3(1024), 0, fs, ki);
+		hipLaunchKernelGGL(k_push_init, dim3(1), dim3(1024), 0, fs, ki);
 	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[10], fs));
@@ -1786,9 +1805,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.prim = h->d_prim[par];
 		k2.seeds = h->d_seeds[par];
 		k2.items = h->d_items[par];
-		k2.wcount = h->d_wcount[par];
+		k2.drain_slot = -1;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)h->S);
+		ScanDrain pdrain, rdrain;
 		if (!serial) {
 			{
 				/* as many workgroups as are resident at once, each walking its share of the channel's tiles */
@@ -1800,7 +1820,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				 * stage on two streams (below) that copy is not on this stream */
 				if (fs2 != fs && h->last_two_streams)
 					HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
-				launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : 2, 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
+				pdrain = launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : 2, 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
 			}
 			/* FRONT, second half (VDL2GPU_FRONT2=1; off by default: same step time either way): regions, region scan, sort and the carry copy -- one-workgroup-
 			 * per-channel kernels and two short wide ones, 80 us of mostly idle GPU -- go to the copy stream, so that the NEXT push's
@@ -1810,12 +1830,19 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				HIPCHK(h, hipEventRecord(h->probe_done, fs));
 				HIPCHK(h, hipStreamWaitEvent(fs2, h->probe_done, 0));
 			}
-			hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs2, k2);
-			launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)h->S), fs2, VDL2_SURV_REGION, 0, 1, 2);
+			{
+				K2Params k2d = k2;	/* (k2r_regions works the probe's common area off first, k2s_sort the region scan's) */
+				scan_drain(k2d, pdrain);
+				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs2, k2d);
+			}
+			rdrain = launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)h->S), fs2, VDL2_SURV_REGION, 0, 1, 2);
 			HIPCHK(h, hipGetLastError());
 		}
-		if (!serial)
-			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs2, k2);
+		if (!serial) {
+			K2Params k2d = k2;
+			scan_drain(k2d, rdrain);
+			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs2, k2d);
+		}
 		if (!serial && h->knob.k2b_front)
 			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
 		if (staged)

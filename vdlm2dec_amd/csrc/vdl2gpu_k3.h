@@ -32,8 +32,6 @@ void k3_carry(K3Params p)
 /* one launch instead of four memsets */
 __global__ void k_push_init(KInitParams p)
 {
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.wcount_words; i += gridDim.x * blockDim.x)
-		p.wcount[i] = 0u;
 	if (blockIdx.x)
 		return;
 	for (int i = threadIdx.x; i < p.ctl_words; i += blockDim.x)

@@ -23,6 +23,7 @@ void k2s_sort(K2Params p)
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial)
 		return;
+	k2x_drain<K2S_NT>(*reinterpret_cast<K2xWork *>(ws.tmp), p, sc);	/* the common area of the scan in front (region scan; a complete scan) */
 	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
 		return;
 	int ncand = (int)p.ctl[CTL_CAND0 + sc];
@@ -86,10 +87,14 @@ __global__ __launch_bounds__(K2M_NT)
 void k2s_merge(K2Params p)
 {
 	__shared__ unsigned long long knew[K2S_MERGE];
+	__shared__ K2xWork xw;
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
-	if (p.force_serial || p.fail[sc] >= VDL2_VERIFIED)
+	if (p.force_serial)
+		return;
+	k2x_drain<K2M_NT>(xw, p, sc);	/* the common area of the verify pass in front: what it finds there fails the channel like any other hit */
+	if (p.fail[sc] >= VDL2_VERIFIED)
 		return;
 	const int ncand = (int)p.ctl[CTL_CAND0 + sc];
 	unsigned *ovf = p.ctl + CTL_CAND0 + p.nstreams * VDL2_CS + sc;
@@ -778,10 +783,12 @@ __global__ __launch_bounds__(K2_NT)
 void k2f_commit(K2Params p)
 {
 	__shared__ MachSharedT<K2_NT> sh;
+	__shared__ K2xWork xw;
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	ChanState *cs = p.cs + sc;
+	k2x_drain<K2_NT>(xw, p, sc);	/* the common area of the last verify pass */
 	if (p.fail[sc] >= VDL2_VERIFIED) {
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.cs_out + sc);
 		uint32_t *dst = reinterpret_cast<uint32_t *>(cs);

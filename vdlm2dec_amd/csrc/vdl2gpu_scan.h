@@ -41,26 +41,16 @@
 #define K2A_POFF 132		/* samples of phase history before the tile: 128 + 4 */
 #define K2A_XOFF (K2A_POFF + 16)
 #define K2A_XMAX (2 * K2A_TS + K2A_XOFF)
-#define K2X_WL 40		/* k2x_second: survivors whose exact phases are in LDS at once (2040 phases: four passes of the workgroup, two phases a lane and pass) */
-#ifndef K2X_NT
-#define K2X_NT 256		/* ... and the items a workgroup takes */
-#endif
-#ifndef K2X_ATTR
-/* Five wavefronts per SIMD (96 registers; the compiler parks three of them in scratch around the exact stage's batch loop, stored once per
- * workgroup that gets that far and re-read once per batch of 40 survivors).  The kernel is a chain of latencies (77 % of its wave cycles
- * waiting), and what it costs the step is the register space its waiting wavefronts hold while the wide kernels of the other two pushes
- * look for a slot: at 121 registers / four wavefronts per SIMD the step was 0.483 ms, at 96 / five 0.466 (same box, alternating). */
-#define K2X_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
-#endif
+#define K2X_WL 40		/* sparse stages (k2x_chunk): survivors whose exact phases are in LDS at once (2040 phases) */
+#define K2X_NT 256		/* ... and the items of a chunk: a lane each */
 #define K2X_CV 64		/* of which the fit screen of so many runs in ONE wavefront (11 % get that far) */
 #define VDL2_ITEM_CAP 196608	/* evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
 				 * payload symbols alike: 39 000 of a 33 s class-scan).  The list is in two parts: a private area per scan
-				 * workgroup (p.surv_pch items each, filled through an LDS counter; their counts in p.wcount) and behind
+				 * workgroup (p.surv_pch items each, filled through an LDS counter and worked off by the workgroup itself behind its last tile: k2a_tail) and behind
 				 * them a common area for what a workgroup's own area does not hold (one device-scope atomic per wavefront
 				 * and pass: slow, rare) */
 #define VDL2_ITEM_PRIV 131072	/* ... of which private areas at most */
 #define VDL2_MAXWG 512		/* scan workgroups per channel at most (private areas of >= 256 items) */
-#define K2X_GRID (VDL2_ITEM_CAP / K2X_NT)
 #define VDL2_REG_CAP 4096	/* probe-hit regions per channel per push (noise alone seeds ~100 per million 84 kS/s samples) */
 #ifndef VDL2_REG_PAD
 #define VDL2_REG_PAD 40
@@ -82,10 +72,10 @@ struct K2aDef {			/* an evaluation that needs the exact fit */
 	int lo, hi;		/* verify: only hits in [lo, hi) count */
 };
 
-/* An evaluation that passed the first screen, as the scan hands it to k2x_second: five 16-byte words -- {n, r | odd << 8, lo, hi}
+/* An evaluation that passed the first screen, as the scan's tile loop hands it to the sparse stages (k2x_chunk): five 16-byte words -- {n, r | odd << 8, lo, hi}
  * and its sixteen phase-step phasors (oldest first) as 2 x 16-bit fixed point (1 / 32767: 2e-5 rad, v_cvt_pknorm_i16_f32) --,
  * 80 bytes instead of 144 (the lists are written by one kernel and read by the next: 25 MB per class-scan of a 33 s push).
- * An item with a non-finite phasor carries the `odd` flag instead (k2x_second then looks at it exactly).  Within an area of the
+ * An item with a non-finite phasor carries the `odd` flag instead (the exact stage then looks at it).  Within an area of the
  * list (a scan workgroup's private area, or the common area) word w of item i lies at (w * area_items + i): consecutive items
  * -- a wavefront's lanes, on either side -- are consecutive in memory. */
 #define K2A_ITEM_WORDS 5
@@ -147,7 +137,7 @@ static_assert(K2A_TS <= 1024, "pend[] holds an instant within the tile in ten bi
  * (51 filters and 51 atan2f per survivor: a third of the probe's and the verify pass's vector instructions) are computed
  * around sync words only. */
 #define VDL2_FIT_MARGIN 0.25f
-#define VDL2_NB_MARGIN 0.1f	/* k2x_second's fifth screen: what two approximate fit errors must differ by to be ordered */
+#define VDL2_NB_MARGIN 0.1f	/* the sparse stages' fifth screen: what two approximate fit errors must differ by to be ordered */
 __device__ __forceinline__ float k2_fast_angle(float y, float x)
 {
 	const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
@@ -173,7 +163,7 @@ __device__ __forceinline__ v2f k2_rot(v2f acc, v2f u, float cx, float cy)
 
 
 /* detector test of one instant (d8psk.c:292) and what a hit means in each scan mode */
-__device__ __forceinline__ void k2a_emit(const K2Params &p, int sc, long long dec_base, long long n, int r, int mode,
+template <class PR> __device__ __forceinline__ void k2a_emit(PR p, int sc, long long dec_base, long long n, int r, int mode,
 						  long long chk_lo, long long chk_hi, int *fail, int skip_r, int skip_par,
 						  float p2err, float perr, float err, float pfr, unsigned *cntp, unsigned *ovf, Cand *cl)
 {
@@ -255,17 +245,6 @@ __device__ __forceinline__ void k2a_tables(K2aShared &sh)
 	__syncthreads();
 }
 
-/* at the end of a scan workgroup: how much of its private area holds items */
-__device__ __forceinline__ void k2a_finish(K2aShared &sh, const K2Params &p, int sc)
-{
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		unsigned n = sh.it_used < sh.it_limit ? sh.it_used : sh.it_limit;
-		n = n < (unsigned)p.surv_pch ? n : (unsigned)p.surv_pch;
-		p.wcount[((size_t)p.surv_slot * p.nstreams * VDL2_CS + sc) * VDL2_MAXWG + blockIdx.x] = n;
-	}
-}
-
 template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const K2Params &p, int sc, long long dec_base, long long nbase, int cnt)
 {
 	const float2 *x = p.dec + (size_t)sc * p.cap + (nbase - K2A_XOFF - dec_base);
@@ -279,17 +258,19 @@ template <int S> __device__ __forceinline__ void k2a_fetch(K2aPre<S> &pre, const
 	pre.loaded = true;
 }
 
-/* The scan kernels do the DENSE part only: filter, phasors and the first screen at every instant of a tile, all four
- * wavefronts of a workgroup in step.  What passes the first screen (2.7 % of the instants) leaves the kernel as an item --
- * instant, class and the sixteen phase-step phasors it was screened on -- in the channel's item list, and k2x_second, the next
- * kernel on the stream, takes the lists through the sparse stages with every lane busy: second and third screen, the fit
- * screen, then for the few survivors exact phases, exact fits and the detector test.  [Until round 4 the sparse stages ran
- * inside the tile loop: one wavefront of four worked on 27 items of 64 lanes while the other three waited at the barrier --
- * a third of the probe's time -- and the exact work's registers capped the scan kernels at four wavefronts per SIMD.]
+/* The tile loop of a scan kernel does the DENSE part only: filter, phasors and the first screen at every instant of a tile, all
+ * four wavefronts of a workgroup in step.  What passes the first screen (2.7 % of the instants) is put aside as an item --
+ * instant, class and the sixteen phase-step phasors it was screened on -- in the workgroup's private area of the channel's item
+ * list, and behind its last tile the workgroup takes its area through the sparse stages with every lane busy (k2a_tail ->
+ * k2x_chunk): second and third screen, the fit screen, then for the few survivors exact phases, exact fits and the detector
+ * test.  [Until round 4 the sparse stages ran inside the tile loop: one wavefront of four worked on 27 items of 64 lanes while
+ * the other three waited at the barrier -- a third of the probe's time -- and the exact work's live registers on top of the
+ * tile loop's capped the scan kernels at four wavefronts per SIMD; round 4 ran them as a kernel of its own behind every scan:
+ * four more launches a push, 30 us each as they ran.  Behind the tile loop the exact work has the registers to itself.]
  * mode 0: append candidates; mode 1: report hits in [chk_lo, chk_hi) to *fail and append them; mode 2: probe (candidates + seeds). */
 
 /* The lanes of a wavefront whose evaluation passed the first screen append their items: one atomic per wavefront and pass,
- * the items in lane order (= time order: k2x_second finds an evaluation's neighbours next to it). */
+ * the items in lane order (= time order: k2x_chunk finds an evaluation's neighbours next to it). */
 __device__ __forceinline__ void k2a_append(K2aShared &sh, const K2Params &p, int sc, bool pass, int n_rel, int r, int lo, int hi, const float2 (&uu)[16], bool odd, int mode, int *fail)
 {
 	const unsigned long long m = __ballot(pass);
@@ -313,7 +294,7 @@ __device__ __forceinline__ void k2a_append(K2aShared &sh, const K2Params &p, int
 			stride = VDL2_ITEM_CAP - priv;
 			const unsigned room = (p.surv_common_cap > 0 && (unsigned)p.surv_common_cap < stride) ? (unsigned)p.surv_common_cap : stride;
 			base = (off2 + cnt <= room) ? priv * K2A_ITEM_WORDS + off2 : 0xffffffffu;
-			if (base == 0xffffffffu)	/* refused: k2x_second must not read the common area from here on (nothing was written there) */
+			if (base == 0xffffffffu)	/* refused: the drain must not read the common area from here on (nothing was written there) */
 				atomicMax(p.ctl + CTL_NSURVLIM0 + p.surv_slot * p.nstreams * VDL2_CS + sc, ~off2);
 		}
 	}
@@ -354,60 +335,43 @@ __device__ __forceinline__ float k2x_fit(const v2f (&v)[16])
 	return sqq - sq * sq * (1.0f / 17.0f) - sql * sql * (1.0f / 408.0f);
 }
 
-struct K2xShared {
+/* LDS of the sparse stages.  It overlays a scan workgroup's K2aShared once the workgroup's tiles are done (the scan works its own
+ * items off itself: k2a_tail), or lies in the LDS of the one-workgroup-per-channel kernel that follows a scan on its stream and
+ * drains the scan's common area (k2x_drain). */
+struct alignas(8) K2xWork {
 	float smf[72];
 	float atab[VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE];
-	K2aDef dl[K2X_NT];		/* the workgroup's survivors of all screens */
+	K2aDef dl[K2X_NT];		/* the chunk's survivors of all screens */
 	int it_n[K2X_NT + 2];		/* the items' instants, ... */
 	int it_st[K2X_NT + 2];		/* ... sub-phase | status << 4 (0: cannot fire, 1: fit error known approximately, 2: must be looked at exactly), ... */
 	float it_ea[K2X_NT + 2];	/* ... approximate fit errors */
-	float2 cv[K2X_CV][17];		/* rotated phasors of the items that passed the second and third screen (row padded: a lane per row) */
-	int cidx[K2X_CV];		/* ... whose they are */
+	union {				/* (never live together: a block barrier lies between the fit screen's last read and the exact stage's first write) */
+		float2 cv[K2X_CV][17];		/* rotated phasors of the items that passed the second and third screen (row padded: a lane per row) */
+		float sph[K2X_WL][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
+	} u;
+	int cidx[K2X_CV];		/* ... whose the rows of cv[] are */
 	int nc;
 	int ns;
-	float sph[K2X_WL][3][17];	/* exact phases of one batch of survivors: evaluation before / at / after */
-	float we[3][K2X_WL], wf[K2X_WL];	/* their exact fit errors, and the slope at the middle one */
+	int tabs;			/* smf[] and atab[] are in place (a workgroup loads them when its first chunk reaches the exact stage) */
+	float we[3][K2X_WL], wf[K2X_WL];	/* exact fit errors of a batch, and the slope at the middle evaluation */
 };
 
-/* K2x: a workgroup takes 256 items of a channel's list, a lane each through the second, third and fourth screen (dense: the
- * list holds nothing else), then the workgroup together through the exact stage for the survivors: exact phases (FIR in the
- * reference's order from the channel plane, then atan2f, d8psk.c:219-229), exact fits (d8psk.c:257-289) of the evaluation and
- * its two neighbours, detector test (d8psk.c:292).  Survivors are rare since the fourth screen: a handful per sync word and
- * class, one per 20 000 instants of noise. */
-__global__ __launch_bounds__(K2X_NT) K2X_ATTR
-void k2x_second(K2Params p)
+/* The sparse stages over one chunk of at most K2X_NT (256) consecutive items of an area of a channel's item list, by the first
+ * 256 threads of a workgroup of NT (every thread of the workgroup makes the call: block barriers inside): a lane each through
+ * the second, third and fourth screen (dense: the list holds nothing else), the fifth screen between neighbours, then together
+ * through the exact stage for the survivors: exact phases (FIR in the reference's order from the channel plane, then atan2f,
+ * d8psk.c:219-229), exact fits (d8psk.c:257-289) of the evaluation and its two neighbours, detector test (d8psk.c:292).
+ * Survivors are rare since the fourth screen: a handful per sync word and class, one per 20 000 instants of noise.
+ *   w0, stride   16-byte word index of the chunk's first item's word 0 in the channel's list; words from word to word of an item
+ *   U            exact phases a lane works on at once (1 in the scan kernels, whose register budget is the tile loop's)
+ * [Round 4 ran this as a kernel of its own behind every scan, four launches of 6144 workgroups a push most of which found
+ * nothing and 30 us each as they ran; a scan workgroup's own area holds a chunk or two, and the workgroup is there anyway.] */
+template <int NT, int U, class PR>
+__device__ void k2x_chunk(K2xWork &sh, PR p, int sc, int mode, int skip, unsigned w0, unsigned stride, unsigned nhere)
 {
-	__shared__ K2xShared sh;
+	static_assert(NT >= K2X_NT && (U == 1 || U == 2), "k2x_chunk");
 	const int tid = threadIdx.x;
-	const int c = blockIdx.y, s = blockIdx.z;
-	const int sc = s * VDL2_CS + c;
-	const int mode = p.surv_mode;
-	/* this workgroup's 256 items: part of a scan workgroup's private area, or of the common area behind them */
-	const unsigned pch = (unsigned)p.surv_pch, priv = (unsigned)p.surv_nwg * pch;
-	const unsigned first = blockIdx.x * K2X_NT;
-	unsigned nhere, w0, stride;	/* items of this workgroup; 16-byte word index of its first item's word 0; words from word to word */
-	if (first < priv) {
-		const unsigned wg = first / pch, off = first - wg * pch;
-		const unsigned cnt = p.wcount[((size_t)p.surv_slot * p.nstreams * VDL2_CS + sc) * VDL2_MAXWG + wg];
-		nhere = cnt > off ? cnt - off : 0;
-		w0 = wg * pch * K2A_ITEM_WORDS + off;
-		stride = pch;
-	} else {
-		stride = VDL2_ITEM_CAP - priv;
-		unsigned nc = p.ctl[CTL_NSURV0 + p.surv_slot * p.nstreams * VDL2_CS + sc];
-		{
-			const unsigned lim = ~p.ctl[CTL_NSURVLIM0 + p.surv_slot * p.nstreams * VDL2_CS + sc];
-			nc = nc > lim ? lim : nc;
-		}
-		nc = nc > stride ? stride : nc;	/* (a group that did not fit reserved past the end and wrote nothing: k2a_append; what lies below the first
-						 * such group is complete only if no group was refused -- and then the channel is flagged unusable anyway) */
-		const unsigned off = first - priv;
-		nhere = nc > off ? nc - off : 0;
-		w0 = priv * K2A_ITEM_WORDS + off;
-	}
-	if (nhere == 0)
-		return;
-	nhere = nhere > K2X_NT ? K2X_NT : nhere;
+	const bool act = NT == K2X_NT || tid < K2X_NT;
 	if (tid == 0) {
 		sh.ns = 0;
 		sh.nc = 0;
@@ -425,7 +389,7 @@ void k2x_second(K2Params p)
 	int st = 0;
 	float erra = 0.0f;
 	K2aDef d{};
-	const bool have = (unsigned)tid < nhere;
+	const bool have = act && (unsigned)tid < nhere;
 	if (have) {
 		const float4 *src = reinterpret_cast<const float4 *>(p.items) + (size_t)sc * VDL2_ITEM_CAP * K2A_ITEM_WORDS + w0 + tid;
 		float4 raw[K2A_ITEM_WORDS];
@@ -460,13 +424,13 @@ void k2x_second(K2Params p)
 			st = 2;		/* a non-finite phasor: the exact stage decides */
 		else if (!(r2 <= VDL2_SCREEN_R22) && !(r3 <= VDL2_SCREEN_R32)) {
 			/* fourth screen: the fit itself on approximate step angles (see k2_fast_angle) -- for the first K2X_CV of the
-			 * workgroup in one wavefront behind the barrier, a lane each; for more than that (a list of sync words) here */
+			 * chunk in one wavefront behind the barrier, a lane each; for more than that (a list of sync words) here */
 			const int slot = atomicAdd(&sh.nc, 1);
 			if (slot < K2X_CV) {
 				sh.cidx[slot] = tid;
 #pragma unroll
 				for (int l = 0; l < 16; ++l)
-					sh.cv[slot][l] = make_float2(v[l].x, v[l].y);
+					sh.u.cv[slot][l] = make_float2(v[l].x, v[l].y);
 				st = 3;	/* (pending) */
 			} else {
 				erra = k2x_fit(v);
@@ -474,9 +438,11 @@ void k2x_second(K2Params p)
 			}
 		}
 	}
-	sh.it_n[tid] = have ? d.n : 0x7fffffff;
-	sh.it_st[tid] = d.r | (st << 4);
-	sh.it_ea[tid] = erra;
+	if (act) {
+		sh.it_n[tid] = have ? d.n : 0x7fffffff;
+		sh.it_st[tid] = d.r | (st << 4);
+		sh.it_ea[tid] = erra;
+	}
 	__syncthreads();
 	{
 		const int nc = sh.nc < K2X_CV ? sh.nc : K2X_CV;
@@ -484,7 +450,7 @@ void k2x_second(K2Params p)
 			v2f v[16];
 #pragma unroll
 			for (int l = 0; l < 16; ++l) {
-				const float2 t = sh.cv[tid][l];
+				const float2 t = sh.u.cv[tid][l];
 				v[l] = (v2f){t.x, t.y};
 			}
 			const float e = k2x_fit(v);
@@ -494,8 +460,10 @@ void k2x_second(K2Params p)
 		}
 	}
 	__syncthreads();
-	st = sh.it_st[tid] >> 4;
-	erra = sh.it_ea[tid];
+	if (act) {
+		st = sh.it_st[tid] >> 4;
+		erra = sh.it_ea[tid];
+	}
 	if (st == 1) {
 		/* Fifth screen: the detector's own test on the approximate errors of NEIGHBOURING evaluations.  A scan wavefront's items
 		 * are in the list in time order, so the evaluation one step later (n + 2: the `err` to this evaluation's `perr`) is
@@ -530,15 +498,21 @@ void k2x_second(K2Params p)
 #ifdef K2X_NO_EXACT
 	return;
 #endif
-	if (nd == 0)
+	if (nd == 0)	/* (block-uniform) */
 		return;
-	for (int i = tid; i < 72; i += K2X_NT)	/* (the tables of the exact stage: only now, one workgroup in ten gets here) */
-		sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
-	if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
-		sh.atab[tid] = vdl2_atan_tab_entry(tid);
-	__syncthreads();
+	if (!sh.tabs) {	/* (block-uniform; the tables of the exact stage: only now, one chunk in ten gets here) */
+		if (act) {
+			for (int i = tid; i < 72; i += K2X_NT)
+				sh.smf[i] = (i < 65) ? d_tab(c_mflt, i) : 0.0f;
+			if (tid < VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE)
+				sh.atab[tid] = vdl2_atan_tab_entry(tid);
+		}
+		__syncthreads();
+		if (tid == 0)
+			sh.tabs = 1;
+	}
 	const long long dec_base = p.dec_base;
-	const int skip_r = p.surv_skip ? p.probe_r : -1, skip_par = p.probe_par;
+	const int skip_r = skip ? p.probe_r : -1, skip_par = p.probe_par;
 	int *fail = p.fail + sc;
 	const float2 *x0 = p.dec + (size_t)sc * p.cap;	/* x0[n] = sample at stream-relative time n */
 	unsigned *cntp = p.ctl + CTL_CAND0 + sc;
@@ -546,61 +520,126 @@ void k2x_second(K2Params p)
 	Cand *cl = p.cands + (size_t)sc * VDL2_CAND_CAP;
 	for (int b0 = 0; b0 < nd; b0 += K2X_WL) {
 		const int nb = (nd - b0 < K2X_WL) ? nd - b0 : K2X_WL;
-		/* two phases per lane and pass, their loads and dependent chains (17 taps, then the atan2f's divisions and polynomial)
+		/* U phases per lane and pass, their loads and dependent chains (17 taps, then the atan2f's divisions and polynomial)
 		 * interleaved: the stage is a chain of latencies, not of throughput */
-		for (int t0 = tid; t0 < 51 * nb; t0 += 2 * K2X_NT) {
-			float2 xv[2][17];
-			int rr[2], slot[2], ww[2], ll[2];
+		for (int t0 = act ? tid : 51 * nb; t0 < 51 * nb; t0 += U * K2X_NT) {
+			float2 xv[U][17];
+			int rr[U], slot[U], ww[U], ll[U];
 #pragma unroll
-			for (int u = 0; u < 2; ++u) {
+			for (int u = 0; u < U; ++u) {
 				const int t = t0 + u * K2X_NT < 51 * nb ? t0 + u * K2X_NT : t0;	/* (the odd one out repeats its partner) */
 				slot[u] = t / 51;
 				const int rem = t - 51 * slot[u];
 				ww[u] = rem / 17;
 				ll[u] = rem - 17 * ww[u];
-				const K2aDef d = sh.dl[b0 + slot[u]];
-				rr[u] = d.r;
-				const float2 *x = x0 + (d.n + (ww[u] - 1) * 2 - 8 * (16 - ll[u]) - 16);
+				const K2aDef dd = sh.dl[b0 + slot[u]];
+				rr[u] = dd.r;
+				const float2 *x = x0 + (dd.n + (ww[u] - 1) * 2 - 8 * (16 - ll[u]) - 16);
 #pragma unroll
 				for (int j = 0; j < 17; ++j)
 					xv[u][j] = x[j];
 			}
-			v2f acc[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+			v2f acc[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				acc[u] = (v2f){0.0f, 0.0f};
 #pragma unroll
 			for (int j = 0; j < 16; ++j) {
 #pragma unroll
-				for (int u = 0; u < 2; ++u) {
+				for (int u = 0; u < U; ++u) {
 					const float m = sh.smf[rr[u] + 4 * j];
 					acc[u] += (v2f){xv[u][j].x, xv[u][j].y} * (v2f){m, m};
 				}
 			}
 #pragma unroll
-			for (int u = 0; u < 2; ++u)
+			for (int u = 0; u < U; ++u)
 				if (rr[u] == 0) {	/* mflt[r + 64] exists only for r == 0 */
 					const float m = sh.smf[64];
 					acc[u] += (v2f){xv[u][16].x, xv[u][16].y} * (v2f){m, m};
 				}
-			const float ph0 = vdl2_atan2f_tab(acc[0].y, acc[0].x, sh.atab), ph1 = vdl2_atan2f_tab(acc[1].y, acc[1].x, sh.atab);
-			sh.sph[slot[0]][ww[0]][ll[0]] = ph0;
-			if (t0 + K2X_NT < 51 * nb)
-				sh.sph[slot[1]][ww[1]][ll[1]] = ph1;
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const float ph = vdl2_atan2f_tab(acc[u].y, acc[u].x, sh.atab);
+				if (u == 0 || t0 + u * K2X_NT < 51 * nb)
+					sh.u.sph[slot[u]][ww[u]][ll[u]] = ph;
+			}
 		}
 		__syncthreads();
-		for (int kk = tid; kk < 3 * nb; kk += K2X_NT) {
+		for (int kk = act ? tid : 3 * nb; kk < 3 * nb; kk += K2X_NT) {
 			const int slot = kk / 3, w = kk - 3 * slot;
 			float fr;
-			sh.we[w][slot] = k2_sync_metric<1>(&sh.sph[slot][w][0], &fr);
+			sh.we[w][slot] = k2_sync_metric<1>(&sh.u.sph[slot][w][0], &fr);
 			if (w == 1)
 				sh.wf[slot] = fr;
 		}
 		__syncthreads();
-		for (int kk = tid; kk < nb; kk += K2X_NT) {
-			const K2aDef d = sh.dl[b0 + kk];
-			k2a_emit(p, sc, dec_base, dec_base + d.n + 2, d.r, mode, dec_base + d.lo, dec_base + d.hi, fail, skip_r, skip_par,
+		for (int kk = act ? tid : nb; kk < nb; kk += K2X_NT) {
+			const K2aDef dd = sh.dl[b0 + kk];
+			k2a_emit<PR>(p, sc, dec_base, dec_base + dd.n + 2, dd.r, mode, dec_base + dd.lo, dec_base + dd.hi, fail, skip_r, skip_par,
 				 sh.we[0][kk], sh.we[1][kk], sh.we[2][kk], sh.wf[kk], cntp, ovf, cl);
 		}
 		__syncthreads();
 	}
+}
+
+/* Behind a scan workgroup's last tile: the sparse stages over what the workgroup itself put into its private area of the item
+ * list, in chunks of 256 (a workgroup of the probe walks eight tiles and lists 220 items: one chunk).  The items were written
+ * and are read by the same workgroup: a block barrier orders them.  K2xWork takes the place of the tile loop's LDS. */
+static_assert(sizeof(K2xWork) <= sizeof(K2aShared), "the sparse stages' LDS overlays the tile loop's");
+/* The tail reads the kernel's parameters AGAIN, from the kernarg segment, behind a point the compiler cannot move loads across:
+ * as fields of the by-value `p` they are loaded at the kernel's entry and the dozen pointers and switches only the tail uses
+ * would be held in scalar registers through the tile loop, which has none to spare (46-69 scalar and 23-47 vector registers
+ * spilled when the tail took `p`; none this way).  K2Params is the kernels' only parameter: it lies at offset 0. */
+typedef const __attribute__((address_space(4))) K2Params K2ParamsK;
+__device__ __forceinline__ K2ParamsK &k2_kernarg_again()
+{
+	unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("; kernarg again" : "+s"(ka) : : "memory");
+	return *(K2ParamsK *)ka;
+}
+__device__ __forceinline__ void k2a_tail(K2aShared &sh, int sc)
+{
+	__syncthreads();
+	K2ParamsK &p = k2_kernarg_again();
+	unsigned n = sh.it_used < sh.it_limit ? sh.it_used : sh.it_limit;
+	n = n < (unsigned)p.surv_pch ? n : (unsigned)p.surv_pch;
+	__syncthreads();	/* (everybody has read the counters the overlay is about to cover) */
+	K2xWork &w = *reinterpret_cast<K2xWork *>(&sh);
+	if (threadIdx.x == 0)
+		w.tabs = 0;
+	const unsigned base = blockIdx.x * (unsigned)p.surv_pch * K2A_ITEM_WORDS;
+	for (unsigned off = 0; off < n; off += K2X_NT)
+		k2x_chunk<K2A_THREADS, 1, K2ParamsK &>(w, p, sc, p.surv_mode, p.surv_skip, base + off, (unsigned)p.surv_pch, n - off < K2X_NT ? n - off : K2X_NT);
+}
+
+/* What the scan workgroups' private areas did not hold lies in the list's common area (k2a_append: a stretch where far more
+ * than 2.7 % pass -- a carrier, a run of sync words; a test build's handicaps): the one-workgroup-per-channel kernel that
+ * follows the scan on its stream works it off before it looks at the scan's results (a kernel boundary lies between the
+ * writes and these reads: no fence).  p.drain_* name the scan (set by the host on the consumer's launch: enqueue_scan_drain);
+ * nothing to do as a rule: one word read. */
+template <int NT> __device__ void k2x_drain(K2xWork &w, const K2Params &p, int sc)
+{
+	if (p.drain_slot < 0)
+		return;
+	const unsigned pch = (unsigned)p.drain_pch, priv = (unsigned)p.drain_nwg * pch;
+	const unsigned stride = VDL2_ITEM_CAP - priv;
+	unsigned nc = p.ctl[CTL_NSURV0 + p.drain_slot * p.nstreams * VDL2_CS + sc];
+	{
+		const unsigned lim = ~p.ctl[CTL_NSURVLIM0 + p.drain_slot * p.nstreams * VDL2_CS + sc];
+		nc = nc > lim ? lim : nc;
+	}
+	nc = nc > stride ? stride : nc;	/* (a group that did not fit reserved past the end and wrote nothing: k2a_append; what lies below the first
+					 * such group is complete only if no group was refused -- and then the channel is flagged unusable anyway) */
+	if (nc == 0)	/* (block-uniform) */
+		return;
+	if (threadIdx.x == 0)
+		w.tabs = 0;
+	for (unsigned off = 0; off < nc; off += K2X_NT)
+		k2x_chunk<NT, 1, const K2Params &>(w, p, sc, p.drain_mode, p.drain_skip, priv * K2A_ITEM_WORDS + off, stride, nc - off < K2X_NT ? nc - off : K2X_NT);
+	/* what the chunks found went into the channel's counters by atomics (performed in the L2) while this CU's L1 may hold the
+	 * counters' lines from the reads above: drop them before the caller looks at the counters (rare path: the price is fine) */
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	__syncthreads();
 }
 
 /* Filtered samples of the tile instants q0 (even) and q0 + 1, sub-phase taps mf[] (d8psk.c:219-228), for
@@ -896,7 +935,7 @@ void k2a_probe(K2Params p)
 			const int nt1 = n1 < avail_end ? (int)((avail_end - n1 < K2A_TS) ? (avail_end - n1) : K2A_TS) : 0;
 			k2a_tile<1>(sh, p, sc, dec_base, n0, nt, 0xfu, 0, 0, 0, nullptr, pre, n1, nt1);
 		}
-		k2a_finish(sh, p, sc);
+		k2a_tail(sh, sc);
 		return;
 	}
 	/* ONE class everywhere: sub-phase probe_r at the instants of scan_lo's parity -- any class finds the bursts; which
@@ -914,7 +953,7 @@ void k2a_probe(K2Params p)
 		const int nt1 = n1 < avail_end ? (int)(left1 < K2A_TS ? left1 : K2A_TS) : 0;
 		k2a_tile<2>(sh, p, sc, dec_base, n0, nt, rmask, 2, 0, 0, nullptr, pre, n1, nt1);
 	}
-	k2a_finish(sh, p, sc);
+	k2a_tail(sh, sc);
 	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
 		atomicAdd(p.dbg + 32 + threadIdx.x, sh.prof[threadIdx.x]);
 }
@@ -928,7 +967,7 @@ void k2a_probe(K2Params p)
 #define WGS_NBK 2048
 #define WGS_MAXB 48
 struct WgSortShared {
-	unsigned long long tmp[VDL2_CAND_CAP];
+	unsigned long long tmp[VDL2_CAND_CAP];	/* (k2r_regions, k2s_sort: K2xWork lies here while the kernel drains a scan's common area) */
 	unsigned start[WGS_NBK + 1], cur[WGS_NBK];
 	unsigned part[64];
 	unsigned maxb;
@@ -1036,6 +1075,7 @@ template <int NT> __device__ void wg_sort_u64(unsigned long long *keys, WgSortSh
 	__syncthreads();
 }
 
+static_assert(sizeof(K2xWork) <= sizeof(unsigned long long) * VDL2_CAND_CAP, "K2xWork overlays WgSortShared.tmp");
 /* ---- regions around the probe's hits (one workgroup per channel) */
 #define K2R_NT 1024
 __global__ __launch_bounds__(K2R_NT)
@@ -1047,6 +1087,8 @@ void k2r_regions(K2Params p)
 	const int tid = threadIdx.x;
 	const int c = blockIdx.x, s = blockIdx.y;
 	const int sc = s * VDL2_CS + c;
+	/* the common area of the scan in front: the probe's (round 0), the previous round's verify pass's (complete round) */
+	k2x_drain<K2R_NT>(*reinterpret_cast<K2xWork *>(ws.tmp), p, sc);
 	if (p.force_serial || p.full_scan)
 		return;
 	if (p.round > 0 && p.fail[sc] >= VDL2_VERIFIED)
@@ -1114,7 +1156,11 @@ void k2r_regions(K2Params p)
 	}
 }
 
-__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A_WPE, 8)))
+#ifndef K2A_WPE_REGION
+#define K2A_WPE_REGION 5	/* the region scan filters a tile once per sub-phase and skips the probe's class: at 80 registers the compiler
+				 * spilled four of them inside the tile loop (12 bytes of scratch); at 96 none */
+#endif
+__global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A_WPE_REGION, 8)))
 void k2a_region(K2Params p)
 {
 	__shared__ K2aShared sh;
@@ -1150,7 +1196,7 @@ void k2a_region(K2Params p)
 	const long long t1 = prof ? clock64() : 0;
 	if (prof)
 		sh.prof[12] += (unsigned long long)(t1 - t0);		/* all tiles */
-	k2a_finish(sh, p, sc);
+	k2a_tail(sh, sc);
 	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
 		atomicAdd(p.dbg + 48 + threadIdx.x, sh.prof[threadIdx.x]);
 }
@@ -1230,7 +1276,7 @@ void k2a_verify(K2Params p)
 		k2a_tile<2>(sh, p, sc, dec_base, dec_base + it.x, (it.y - it.x + 1) / 2, 1u << it.z, 1, dec_base + it.x, dec_base + it.y,
 			    p.fail + sc, pre, dec_base + nx.x, (nx.y - nx.x + 1) / 2);
 	}
-	k2a_finish(sh, p, sc);
+	k2a_tail(sh, sc);
 }
 
 #endif

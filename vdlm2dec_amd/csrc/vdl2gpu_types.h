@@ -189,13 +189,17 @@ struct K2Params {
 	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
 	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
-	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen, worked off by k2x_second (the next kernel on the stream) */
-	unsigned *wcount;	/* [VDL2_SURV_SLOTS][S*8][VDL2_MAXWG] items in each scan workgroup's private area (zeroed by k_push_init) */
+	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen: a private area per scan workgroup (worked off by that workgroup behind
+				 * its last tile), a common area behind them (worked off by the next kernel on the stream) */
 	int surv_pch, surv_nwg;	/* items a private area holds (a multiple of 256), scan workgroups per channel (= private areas) */
 	int surv_common_cap;	/* test hook: the common area holds only so many items (0: all that is left of the list) */
 	int surv_slot;		/* which of the push's scans this is: its item counters are ctl[CTL_NSURV0 + slot * S*8 ...] (VDL2_SURV_*) */
-	int surv_mode;		/* k2x_second: what a detector hit among the survivors means (k2a_emit: 0 candidates, 1 verify, 2 probe) */
-	int surv_skip;		/* k2x_second: hits in the probe's class are in the table already (region scan) */
+	int surv_mode;		/* sparse stages: what a detector hit among the survivors means (k2a_emit: 0 candidates, 1 verify, 2 probe) */
+	int surv_skip;		/* sparse stages: hits in the probe's class are in the table already (region scan) */
+	/* the one-workgroup-per-channel kernel behind a scan drains that scan's common area first (k2x_drain): which scan, and how its list was laid out */
+	int drain_slot;		/* VDL2_SURV_* of the scan in front of this launch, -1: nothing to drain */
+	int drain_mode, drain_skip;	/* that scan's surv_mode, surv_skip */
+	int drain_pch, drain_nwg;	/* ... surv_pch, surv_nwg */
 	unsigned long long *dbg;	/* diagnostics: cycle counters */
 	HeadTap *headtap;	/* diagnostics: every trigger any kernel of the push handled (nullptr: off) */
 	unsigned *headtap_n;
@@ -251,8 +255,6 @@ struct KInitParams {		/* per-push reset of the demodulator's control words */
 	int nsc;
 	unsigned *fmask;	/* 16 words */
 	unsigned *fcnt;		/* 4 words: this ring's block-path counters, or nullptr */
-	unsigned *wcount;	/* the scans' private-area counts */
-	int wcount_words;
 };
 
 /* ---- constant data tables (d8psk.h:20-249) as bit patterns ------------- */
