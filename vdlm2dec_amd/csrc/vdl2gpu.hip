@@ -44,7 +44,7 @@ static int g_test_item_grid = 0, g_test_item_common = 0;	/* read once per vdl2gp
 #endif
 
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
-#define NEVX 16	/* e[15] = the verify pass (round 0) has ended; + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain; e[12] = before the verify pass
+#define NEVX 24	/* e[15] = the verify pass (round 0) has ended; + e[8], e[9] bracket the k1_fast launch alone; e[10] = start of the demodulator chain; e[12] = before the verify pass
 			 * (main stream, behind the wait for the resolver); e[13], e[14] = around the resolver (its own stream when hoisted) */
 struct PushTiming {
 	hipEvent_t e[NEVX];	/* before K1, after K1, after K2a, after K2b, after K2c+K2d, after K3 */
@@ -132,7 +132,8 @@ struct vdl2gpu {
 					 * waited for them (0.472 against 0.462 ms per step at 64, same box; 32 and 16: 0.468, 0.469) */
 	int force_serial = 0;
 	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
-	int n_cu = 256;
+	int n_cu = 256;		/* CUs the wide kernels' streams may use (all of them minus reserve_cus) */
+	int n_cu_all = 256, reserve_cus = 0;
 	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
 	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown): an event record between two kernels of the chain
 					 * costs ~3 us, so only every stage_every-th push carries them (the sums are scaled up in harvest) */
@@ -682,11 +683,31 @@ static int create_impl(vdl2gpu_t *h)
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k2a_probe, K2A_THREADS, 0) == hipSuccess && occ > 0)
 			h->probe_occ = occ;
 	}
+	/* Reserved CUs.  Every wide kernel here sizes itself to the whole GPU and holds its slots until it is through (the channeliser's
+	 * ticketed workgroups, the probe's and the cluster kernel's persistent ones), so a one-workgroup-per-channel kernel of ANOTHER
+	 * push -- the resolver wants a CU's whole LDS, the repair round's kernels follow each other -- finds no CU until one of them
+	 * ends: the repair round (12 + 50 + 40 us of kernels alone) took 315 us of every period, and the chain resolver -> verify pass ->
+	 * round -> commit -> next push's resolver was as long as the period.  The streams that carry the wide kernels (front, main,
+	 * records) are created with a CU mask that leaves `reserve_cus` CUs out (mask bit i is CU i / 8 of XCD i % 8: the lowest bits are
+	 * one CU of every XCD); the state stream is unmasked: its narrow kernels find the reserved CUs empty. */
+	h->reserve_cus = 0;
+	if (const char *e = getenv("VDL2GPU_RESERVE_CUS"))
+		h->reserve_cus = std::max(0, std::min(atoi(e), h->n_cu / 2));
+	auto wide_stream = [&](hipStream_t *st, int prio) -> hipError_t {
+		if (h->reserve_cus <= 0)
+			return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+		std::vector<uint32_t> mask((size_t)(h->n_cu + 31) / 32, 0u);
+		for (int i = h->reserve_cus; i < h->n_cu; ++i)
+			mask[(size_t)i / 32] |= 1u << (i % 32);
+		return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+	};
 	{
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+		HIPCHK(h, wide_stream(&h->stream, prio_hi));
 	}
+	h->n_cu_all = h->n_cu;
+	h->n_cu -= h->reserve_cus;	/* (what the wide kernels' grids are sized by) */
 	const int S = h->S, L = h->L;
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
 	h->cap = (VDL2_CARRY_FRAMES + jmax + 64 + 15) / 16 * 16;	/* planes start on 128-byte lines */
@@ -708,7 +729,7 @@ static int create_impl(vdl2gpu_t *h)
 	}
 	HIPCHK(h, hipMalloc(&h->d_outc, 16 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 16 * sizeof(unsigned), h->stream));
-	HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+	HIPCHK(h, wide_stream(&h->copy_stream, 0));
 	/* (HIP multiplexes its streams onto four hardware queues: a fifth stream shares one with another, and kernels that
 	 * were meant to run side by side then run one behind the other -- this handle makes exactly main, copy, resolver, payload;
 	 * host input adds one for its copies, which may share a queue with the record read-back) */
@@ -723,7 +744,7 @@ static int create_impl(vdl2gpu_t *h)
 	{
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, prio_lo));	/* the back stage (main stream, high priority) is the shorter one: it goes first */
+		HIPCHK(h, wide_stream(&h->fstream, prio_lo));	/* the back stage (main stream, high priority) is the shorter one: it goes first */
 	}
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->f_done[r], hipEventDisableTiming));
@@ -983,7 +1004,10 @@ static int harvest_timing(vdl2gpu_t *h)
 			 * first push -- a Gantt chart of the pipeline as it runs WITHOUT a profiler (under rocprofv3 the calling thread is
 			 * what the streams wait for).  e0 K1 begins | e1 K1 ends | e10 scan begins | e4 front ends | e2 clusters begin |
 			 * e3 = e13 clusters end | e14 resolver ends | e12 verify begins | e15 verify ends | e5 rounds end | e6 commit..export end | e7 tail ends */
-			static const int order[] = {0, 1, 10, 4, 2, 13, 14, 12, 15, 5, 6, 7};
+			/* (VDL2GPU_STAGE_DUMP only) e23 resolver begins (the previous push's commit has been seen) | e16 tail begins (the verify pass has
+			 * been seen on the tail's stream) | e17 merge ends | e18 round's resolver ends | e5 rounds end | e20 commit ends | e21 second
+			 * payload pass ends | e22 export ends */
+			static const int order[] = {0, 1, 10, 4, 2, 13, 23, 14, 12, 15, 16, 17, 18, 5, 20, 21, 22, 6, 7};
 			fprintf(stderr, "vdl2gpu stage dump push %llu:", (unsigned long long)pt.index);
 			for (int k : order) {
 				float t = -1.0f;
@@ -1235,6 +1259,8 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(pt.e[13], rs));
 	if (h->k2f_rec)		/* the channel states the resolver starts from are committed on the previous push's tail */
 		HIPCHK(h, hipStreamWaitEvent(rs, h->k2f_done, 0));
+	if (staged && h->stage_dump)
+		HIPCHK(h, hipEventRecord(pt.e[23], rs));
 	hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
@@ -1282,6 +1308,8 @@ static int enqueue_back(vdl2gpu_t *h)
 	if (h->tail_prev && h->tail_prev != ts && h->k2_rec[(par + VDL2_NSET - 1) % VDL2_NSET])	/* tails follow each other (running totals, StreamState) */
 		HIPCHK(h, hipStreamWaitEvent(ts, h->k2_done[(par + VDL2_NSET - 1) % VDL2_NSET], 0));
 	h->tail_prev = ts;
+	if (staged && h->stage_dump)
+		HIPCHK(h, hipEventRecord(pt.e[16], ts));
 	if (!h->full_scan && !serial) {
 		/* Repair rounds.  The verify pass has appended what it found to the failing channel's table (candidates without
 		 * clusters): a round re-sorts the table, re-resolves the channel -- the resolver replays the new candidates with the
@@ -1321,8 +1349,12 @@ static int enqueue_back(vdl2gpu_t *h)
 			} else {
 				scan_drain(k2r, vdrain);
 				hipLaunchKernelGGL(k2s_merge, gch, dim3(K2M_NT), 0, ts, k2r);
+				if (staged && h->stage_dump && rr == 1)
+					HIPCHK(h, hipEventRecord(pt.e[17], ts));
 				scan_drain(k2r, ScanDrain());
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
+				if (staged && h->stage_dump && rr == 1)
+					HIPCHK(h, hipEventRecord(pt.e[18], ts));
 				vdrain = launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
 			}
 		}
@@ -1337,6 +1369,8 @@ static int enqueue_back(vdl2gpu_t *h)
 	}
 	HIPCHK(h, hipEventRecord(h->k2f_done, ts));
 	h->k2f_rec = true;
+	if (staged && h->stage_dump)
+		HIPCHK(h, hipEventRecord(pt.e[20], ts));
 	if (h->ring_spec[ring]) {
 		if (ts != ps)
 			HIPCHK(h, hipStreamWaitEvent(ts, h->pay_done, 0));	/* the export needs the first pass's records, K3 publishes the record count */
@@ -1352,6 +1386,8 @@ static int enqueue_back(vdl2gpu_t *h)
 		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2p);
 	}
 	HIPCHK(h, hipGetLastError());
+	if (staged && h->stage_dump)
+		HIPCHK(h, hipEventRecord(pt.e[21], ts));
 	if (h->frames_on) {
 		/* block path on the records where they lie (vdlm2.c:84-161).  In the chain, not beside it:
 		 * a latency-bound kernel like this one and the next push's scan slow each other down by
@@ -1397,6 +1433,8 @@ static int enqueue_back(vdl2gpu_t *h)
 			ke.cap = std::min(h->slab_cap, h->rec_cap);
 			hipLaunchKernelGGL(k_export_records, dim3((unsigned)h->n_cu), dim3(256), 0, ts, ke);
 			HIPCHK(h, hipGetLastError());
+			if (staged && h->stage_dump)
+				HIPCHK(h, hipEventRecord(pt.e[22], ts));
 		}
 		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, ts, k3);
 		HIPCHK(h, hipGetLastError());
@@ -1775,7 +1813,12 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.rec_cap = h->rec_cap;
 		k2.dec_base = dec_base;
 		k2.scan_lo = dec_base + VDL2_HIST;	/* the scan starts at the first carried frame that has its history */
+#if VDL2_PROBE_STRIDE == 2
 		k2.probe_r = 0;				/* the one class scanned everywhere: fixed, not the class the channel is in */
+#else
+		k2.probe_r = -1;			/* no class is scanned everywhere: the probe only finds the bursts (every fourth sample of sub-phase 0), the
+							 * region scan lists every class around them, the verify pass covers every stretch the chain idles through */
+#endif
 		k2.probe_par = (int)((dec_base + VDL2_HIST) & 1);
 		k2.force_serial = serial ? 1 : 0;
 		k2.sel_reserved = (!h->full_scan && !serial && h->S * VDL2_CS <= 512) ? 1 : 0;	/* (enqueue_back's `spec`) */
@@ -1820,7 +1863,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				 * stage on two streams (below) that copy is not on this stream */
 				if (fs2 != fs && h->last_two_streams)
 					HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
-				pdrain = launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : 2, 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
+				pdrain = launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : (VDL2_PROBE_STRIDE == 2 ? 2 : 3), 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
 			}
 			/* FRONT, second half (VDL2GPU_FRONT2=1; off by default: same step time either way): regions, region scan, sort and the carry copy -- one-workgroup-
 			 * per-channel kernels and two short wide ones, 80 us of mostly idle GPU -- go to the copy stream, so that the NEXT push's

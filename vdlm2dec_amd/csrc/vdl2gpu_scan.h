@@ -102,6 +102,18 @@ static_assert(K2A_WU1 % 2 == 0 && K2A_XS_LEN >= K2A_XMAX + 8 && (K2A_XMAX / 2 + 
 static_assert(K2A_TS + K2A_POFF / 2 + 2 <= K2A_XS_LEN && K2A_WU1 >= K2A_TS + K2A_XOFF, "phasor areas");
 static_assert(K2A_TS <= 1024, "pend[] holds an instant within the tile in ten bits");
 #define K2A_XODD (K2A_XMAX / 2 + 4)	/* 8-byte elements: an odd multiple of 64 bytes away, so the two halves use disjoint banks */
+/* S = 4 (the probe since round 5: every FOURTH sample, one sub-phase -- it only has to FIND the bursts, see k2a_probe): a tile is
+ * 512 instants (the same 2048 samples as an S = 2 tile), its samples lie de-interleaved by (index mod 4) in four runs of K2A_XQ4
+ * elements (tap j = 4 m + t of instant q is element q + m of run t: unit stride across lanes for every tap), 64 bytes apart
+ * modulo the banks' 256. */
+#define K2A_TS4 (K2A_TS / 2)
+#ifndef VDL2_PROBE_STRIDE
+#define VDL2_PROBE_STRIDE 2	/* samples between the probe's instants: 2 = one class completely (round 4), 4 = every second instant of it, seeds only */
+#endif
+#define K2A_XQ4 552
+static_assert(4 * K2A_XQ4 <= K2A_XS_LEN && K2A_XQ4 % 32 == 8 && (4 * (K2A_TS4 - 1) + 1 + K2A_XOFF + 3) / 4 <= K2A_XQ4 &&
+	      K2A_TS4 + K2A_POFF / 4 - 2 + 6 <= K2A_XQ4, "S = 4 sample runs: a tile's samples, and the six elements a lane pair reads of each run");
+template <int S> struct K2aTs { static constexpr int v = (S == 4) ? K2A_TS4 : K2A_TS; };
 
 /* Screens for the 17-point fit (the expensive part of the scan).
  * With Pr[] the unwrapped, template-corrected phases the reference fits a line to (d8psk.c:257-289)
@@ -167,11 +179,13 @@ template <class PR> __device__ __forceinline__ void k2a_emit(PR p, int sc, long 
 						  long long chk_lo, long long chk_hi, int *fail, int skip_r, int skip_par,
 						  float p2err, float perr, float err, float pfr, unsigned *cntp, unsigned *ovf, Cand *cl)
 {
-	if (mode == 2 && perr < VDL2_SEED_ERR && err > perr) {
+	if (mode >= 2 && perr < VDL2_SEED_ERR && err > perr) {
 		const unsigned kk = atomicAdd(p.ctl + CTL_NSEED0 + sc, 1u);
 		if (kk < VDL2_CAND_CAP)	/* surplus seeds are simply dropped: K2a-verify covers what they would have */
 			p.seeds[(size_t)sc * VDL2_CAND_CAP + kk] = (int)(n - dec_base);
 	}
+	if (mode == 3)	/* the probe: it finds the bursts, it lists no candidates (it looks at every second instant of its class only) */
+		return;
 	if (!(perr < 4.0f && err > perr))
 		return;
 	if (mode == 0 || mode == 2) {
@@ -227,7 +241,7 @@ template <class PR> __device__ __forceinline__ void k2a_emit(PR p, int sc, long 
  * same workgroup are loaded once the current tile's filter pass is through (its sample registers are free then), so that
  * the memory latency (several thousand cycles under load) is hidden behind the current tile's screens. */
 template <int S> struct K2aPre {
-	static constexpr int NL = (S * (K2A_TS - 1) + 1 + K2A_XOFF + K2A_THREADS - 1) / K2A_THREADS;
+	static constexpr int NL = (S * (K2aTs<S>::v - 1) + 1 + K2A_XOFF + K2A_THREADS - 1) / K2A_THREADS;
 	float2 v[NL];
 	bool loaded;
 	int tiles;		/* tiles this workgroup has done: which of its wavefronts takes the sparse pass rotates */
@@ -385,7 +399,7 @@ __device__ void k2x_chunk(K2xWork &sh, PR p, int sc, int mode, int skip, unsigne
 	constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
 	constexpr float rc[16] = {C1, -C1, -S1, -C1, C1, S1, S1, -C1, S1, C1, -S1, -S1, S1, -S1, C1, -C1};
 	constexpr float rs[16] = {-S1, -S1, -C1, S1, -S1, -C1, C1, S1, -C1, S1, -C1, C1, C1, C1, S1, -S1};
-	const float fit_limit = mode == 2 ? VDL2_SEED_ERR + VDL2_FIT_MARGIN : 4.0f + VDL2_FIT_MARGIN;
+	const float fit_limit = mode >= 2 ? VDL2_SEED_ERR + VDL2_FIT_MARGIN : 4.0f + VDL2_FIT_MARGIN;
 	int st = 0;
 	float erra = 0.0f;
 	K2aDef d{};
@@ -651,7 +665,25 @@ template <int S> __device__ __forceinline__ void k2a_fir2(const K2aShared &sh, i
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	acc0 = (v2f){0.0f, 0.0f};
 	acc1 = (v2f){0.0f, 0.0f};
-	if (S == 2) {
+	if (S == 4) {
+		/* instant q, tap j = 4 m + t: element q + m of run t; the neighbouring instant q + 1 one element on (q0 is even: 16-byte reads) */
+		v2f x[4][6];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			const v4f *pt = reinterpret_cast<const v4f *>(&sh.xs[t * K2A_XQ4 + q0]);
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				const v4f e = pt[i];
+				x[t][2 * i] = e.xy;
+				x[t][2 * i + 1] = e.zw;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 17; ++j) {
+			acc0 = __builtin_elementwise_fma(x[j & 3][j >> 2], (v2f){mf[j], mf[j]}, acc0);
+			acc1 = __builtin_elementwise_fma(x[j & 3][(j >> 2) + 1], (v2f){mf[j], mf[j]}, acc1);
+		}
+	} else if (S == 2) {
 		/* instant q, tap j: even j = 2m -> even sample q + m, odd j = 2m + 1 -> odd sample q + m */
 		const v4f *pe = reinterpret_cast<const v4f *>(&sh.xs[q0]);
 		const v4f *po = reinterpret_cast<const v4f *>(&sh.xs[K2A_XODD + q0]);
@@ -733,9 +765,10 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	constexpr int KH = LSTR / 2;
 	constexpr int PPW = 64 - KH;				/* pairs a wavefront owns per round */
 	constexpr int PPI = (K2A_THREADS / 64) * PPW;		/* ... the workgroup */
-	constexpr int NIT = ((K2A_TS + PH + 1) / 2 + PPI - 1) / PPI;
+	constexpr int TSS = K2aTs<S>::v;	/* instants of a full tile */
+	constexpr int NIT = ((TSS + PH + 1) / 2 + PPI - 1) / PPI;
 	static_assert(K2A_POFF == S * PH, "phase history must be a whole number of instants");
-	float2 *const wu = (S == 2) ? sh.xs : sh.xs + K2A_WU1;	/* phase-step phasors (see K2aShared) */
+	float2 *const wu = (S != 1) ? sh.xs : sh.xs + K2A_WU1;	/* phase-step phasors (see K2aShared) */
 	/* exp(-j (SW[l] - SW[l-1])), l = 1..16: the template steps are 1,7,5,-7,1,3,-3,-7,3,-1,5,-5,-3,-5,-1,7 (x pi/8) */
 #ifdef K2A_SCREEN_FMA
 	constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
@@ -743,12 +776,12 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 	constexpr float rs[16] = {-S1, -S1, -C1, S1, -S1, -C1, C1, S1, -C1, S1, -C1, C1, C1, C1, S1, -S1};
 #endif
 	const int nx = S * (cnt - 1) + 1 + K2A_XOFF;
-	const bool prof = p.dbg && (mode == 2 || (mode == 0 && S == 1 && skip_r >= 0)) && tid == 0 && (blockIdx.x & 7) == 0;	/* probe, region scan */
+	const bool prof = p.dbg && (mode >= 2 || (mode == 0 && S == 1 && !p.full_scan && !p.full_round)) && tid == 0 && (blockIdx.x & 7) == 0;	/* probe, region scan */
 	long long tq = prof ? clock64() : 0;
 #define K2A_STAMP(slot) do { if (prof) { const long long tn = clock64(); sh.prof[slot] += (unsigned long long)(tn - tq); tq = tn; } } while (0)
 	/* park slots: sample i = tid + k * K2A_THREADS of the tile goes to xs[pbase + k * pstep] */
-	const int pbase = (S == 2) ? (tid & 1) * K2A_XODD + (tid >> 1) : tid;
-	constexpr int pstep = (S == 2) ? K2A_THREADS / 2 : K2A_THREADS;
+	const int pbase = (S == 4) ? (tid & 3) * K2A_XQ4 + (tid >> 2) : ((S == 2) ? (tid & 1) * K2A_XODD + (tid >> 1) : tid);
+	constexpr int pstep = K2A_THREADS / S;
 #if K2A_PREFETCH
 	if (!pre.loaded)
 		k2a_fetch<S>(pre, p, sc, dec_base, nbase, cnt);
@@ -803,7 +836,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 				continue;
 			}
 			int q0 = 2 * (pw + ln - KH);
-			q0 = q0 < 0 ? 0 : (q0 > K2A_TS + PH - 2 ? K2A_TS + PH - 2 : q0);	/* keeps the reads inside xs[]; what a clamped lane computes is not stored */
+			q0 = q0 < 0 ? 0 : (q0 > TSS + PH - 2 ? TSS + PH - 2 : q0);	/* keeps the reads inside xs[]; what a clamped lane computes is not stored */
 			v2f acc[2];
 			k2a_fir2<S>(sh, q0, mf, acc[0], acc[1]);
 			const v2f w0 = k2a_unit(acc[0]), w1 = k2a_unit(acc[1]);
@@ -818,7 +851,7 @@ template <int S> __device__ void k2a_tile(K2aShared &sh, const K2Params &p, int 
 		if (next_cnt > 0 && !pre.loaded)	/* the next tile's samples: in flight during this tile's screens */
 			k2a_fetch<S>(pre, p, sc, dec_base, next_nbase, next_cnt);
 #endif
-		if (S == 2)
+		if (S != 1)
 			K2A_SYNC();	/* wu[] is xs[]: every wavefront is through with the samples */
 		K2A_STAMP(2);
 #pragma unroll
@@ -938,8 +971,10 @@ void k2a_probe(K2Params p)
 		k2a_tail(sh, sc);
 		return;
 	}
+#if VDL2_PROBE_STRIDE == 2
 	/* ONE class everywhere: sub-phase probe_r at the instants of scan_lo's parity -- any class finds the bursts; which
-	 * stretches the chain relied on in OTHER classes is what the verify pass re-scans */
+	 * stretches the chain relied on in OTHER classes is what the verify pass re-scans (round 4's probe: its class is a complete
+	 * table, the region scan skips it and the verify pass the stretches the chain idles through in it) */
 	K2aPre<2> pre;
 	pre.loaded = false;
 	pre.tiles = 0;
@@ -953,6 +988,27 @@ void k2a_probe(K2Params p)
 		const int nt1 = n1 < avail_end ? (int)(left1 < K2A_TS ? left1 : K2A_TS) : 0;
 		k2a_tile<2>(sh, p, sc, dec_base, n0, nt, rmask, 2, 0, 0, nullptr, pre, n1, nt1);
 	}
+#else
+	/* The probe FINDS the bursts: sub-phase 0 at every FOURTH sample from scan_lo on, and what it hands on are seeds -- where the
+	 * fit error of that class dips below VDL2_SEED_ERR (k2a_emit, mode 3) --, around which the region scan looks at every class
+	 * at every instant.  A burst fires the detector in all eight classes within a few samples and its screen sum stays within
+	 * 0.5 of the maximum two samples off (scripts/dev/probe_rate.py), so half the instants of one class find it as well as all of
+	 * them did: half the filter and screen work of round 4's probe, which looked at every second sample and whose class was a
+	 * complete table in exchange -- now the region scan lists the probe's class too and the verify pass covers the stretches
+	 * the chain idles through in it (an eighth more of either).  What the probe misses the verify pass finds, as ever. */
+	K2aPre<4> pre;
+	pre.loaded = false;
+	pre.tiles = 0;
+	const long long step = 4LL * gridDim.x * K2A_TS4;
+	for (long long n0 = p.scan_lo + 4LL * blockIdx.x * K2A_TS4; n0 < avail_end; n0 += step) {
+		const long long left = (avail_end - n0 + 3) / 4;
+		const int nt = (int)(left < K2A_TS4 ? left : K2A_TS4);
+		const long long n1 = n0 + step;
+		const long long left1 = (avail_end - n1 + 3) / 4;
+		const int nt1 = n1 < avail_end ? (int)(left1 < K2A_TS4 ? left1 : K2A_TS4) : 0;
+		k2a_tile<4>(sh, p, sc, dec_base, n0, nt, 1u, 3, 0, 0, nullptr, pre, n1, nt1);
+	}
+#endif
 	k2a_tail(sh, sc);
 	if (p.dbg && threadIdx.x < 16 && sh.prof[threadIdx.x])
 		atomicAdd(p.dbg + 32 + threadIdx.x, sh.prof[threadIdx.x]);
