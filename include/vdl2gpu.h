@@ -314,6 +314,9 @@ int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t 
 int vdl2gpu_debug_lo(vdl2gpu_t *h, int stream, int ch, float *out, int max_complex);
 /* Trigger candidates of the last push's sync scan, 6 x int32 each {nrel, r, p2err, perr, err, pfr bits}. */
 int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, int max_cands);
+/* ... and what follows each of them (one int2 per candidate: where the idle search resumes, relative to the push's planes; status |
+ * sub-phase << 2 | descriptors << 4 | triggers << 8 | rejects << 16 | bursts << 24) */
+int vdl2gpu_debug_clheads(vdl2gpu_t *h, int stream, int ch, int *out, int max_cands);
 /* Verify pass of the last push: first unexpected detector hit per (stream, channel slot), and the
  * idle segments the resolver asked to have verified {lo, hi, r, pad}. */
 int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n);

@@ -120,6 +120,7 @@ struct vdl2gpu {
 	int *d_skey[VDL2_NSET] = {};
 	unsigned short *d_sidx[VDL2_NSET] = {}, *d_prim[VDL2_NSET] = {};
 	int *d_seeds[VDL2_NSET] = {};
+	uint8_t *d_cinfo[VDL2_NSET] = {};	/* per sorted candidate: class, primary, first of its burst (k2s_sort -> k2s_fix) */
 	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (worked off by the scan workgroups themselves; the common area by the next kernel) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
@@ -209,6 +210,8 @@ struct vdl2gpu {
 	struct {
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
 		bool no_tail = false;		/* VDL2GPU_NO_TAIL: everything behind the verify pass stays on the main stream */
+		bool reach = false;		/* VDL2GPU_REACH=1: clusters only for the classes the chain can meet a burst in (K2sReach: 4.8 per burst instead
+						 * of 7.9, a second short cluster launch; measured: nothing at the headline, 2-7 % on busy channels) */
 		double table_fill = 0.90;	/* VDL2GPU_TABLE_FILL (percent): how full the busiest channel's candidate table may get before parts are shortened */
 		bool front2 = false;		/* VDL2GPU_FRONT2=1: the second half of the front stage on the copy stream (measured: 0.477 against 0.475 ms, no gain) */
 		bool pay_tail = false;		/* VDL2GPU_PAY_TAIL: the payload decode beside the verify pass on the payload (tail) stream instead of the copy stream */
@@ -613,6 +616,7 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipEventDestroy(h->verify_done);
 	if (h->k2f_done)
 		(void)hipEventDestroy(h->k2f_done);
+
 	if (h->ev_origin)
 		(void)hipEventDestroy(h->ev_origin);
 	for (int r = 0; r < VDL2_NSET; ++r)
@@ -649,6 +653,8 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipFree(h->d_prim[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_seeds[r]);
+	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_cinfo[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_items[r]);
 	(void)hipFree(h->d_dbg);
@@ -756,6 +762,7 @@ static int create_impl(vdl2gpu_t *h)
 	HIPCHK(h, hipEventCreateWithFlags(&h->pay_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->verify_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2f_done, hipEventDisableTiming));
+
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_fmask[r], 16 * sizeof(unsigned)));
 	for (int r = 0; r < VDL2_NSET; ++r)
@@ -797,6 +804,8 @@ static int create_impl(vdl2gpu_t *h)
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	for (int r = 0; r < VDL2_NSET; ++r)
+		HIPCHK(h, hipMalloc(&h->d_cinfo[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP));
+	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
@@ -810,6 +819,7 @@ static int create_impl(vdl2gpu_t *h)
 	h->hprof_on = getenv("VDL2GPU_HOST_PROF") != nullptr;
 	h->knob.k2b_front = env_int("VDL2GPU_K2B_FRONT", 0) != 0;
 	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
+	h->knob.reach = env_int("VDL2GPU_REACH", 0) != 0;
 	h->knob.pay_tail = env_int("VDL2GPU_PAY_TAIL", 0) != 0;
 	h->knob.front2 = env_int("VDL2GPU_FRONT2", 0) != 0;
 	h->knob.table_fill = std::min(100, std::max(10, env_int("VDL2GPU_TABLE_FILL", 90))) / 100.0;
@@ -1250,13 +1260,21 @@ static int enqueue_back(vdl2gpu_t *h)
 	 * balanced with it here: FRONT = channeliser + scan, BACK = clusters + resolver + verify */
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[2], rs));
-	if (!serial && !h->knob.k2b_front)
+	if (!serial && k2.reach_on) {
+		/* the front stage made the clusters of the classes the chain was PREDICTED to meet each burst in (k2s_sort, K2sReach);
+		 * with their real exits known, the few that have become reachable without a cluster: one narrow kernel and a short
+		 * second launch of the cluster kernel (0.3 clusters per burst) */
+		hipLaunchKernelGGL(k2s_fix, gch, dim3(K2S_NT), 0, rs, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
+	} else if (!serial && !h->knob.k2b_front)
 		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[3], rs));
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[13], rs));
+	const dim3 vgrid0((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S);
+	ScanDrain vdrain;	/* the verify pass whose common area the next one-workgroup-per-channel kernel of the tail has to drain */
 	if (h->k2f_rec)		/* the channel states the resolver starts from are committed on the previous push's tail */
 		HIPCHK(h, hipStreamWaitEvent(rs, h->k2f_done, 0));
 	if (staged && h->stage_dump)
@@ -1287,9 +1305,8 @@ static int enqueue_back(vdl2gpu_t *h)
 	}
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[12], h->stream));
-	ScanDrain vdrain;	/* the verify pass whose common area the next one-workgroup-per-channel kernel of the tail has to drain */
 	if (!serial)
-		vdrain = launch_scan(SCAN_VERIFY, k2, dim3((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S), h->stream, VDL2_SURV_VERIFY, 1, 0, K2A_VRUN);
+		vdrain = launch_scan(SCAN_VERIFY, k2, vgrid0, h->stream, VDL2_SURV_VERIFY, 1, 0, K2A_VRUN);
 	HIPCHK(h, hipGetLastError());
 	if (staged && h->stage_dump)
 		HIPCHK(h, hipEventRecord(pt.e[15], h->stream));
@@ -1367,6 +1384,7 @@ static int enqueue_back(vdl2gpu_t *h)
 		scan_drain(k2f, vdrain);
 		hipLaunchKernelGGL(k2f_commit, gch, dim3(K2_NT), 0, ts, k2f);
 	}
+
 	HIPCHK(h, hipEventRecord(h->k2f_done, ts));
 	h->k2f_rec = true;
 	if (staged && h->stage_dump)
@@ -1846,6 +1864,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.skey = h->d_skey[par];
 		k2.sidx = h->d_sidx[par];
 		k2.prim = h->d_prim[par];
+		k2.cinfo = h->d_cinfo[par];
+		k2.reach_on = (!serial && !h->full_scan && h->knob.reach) ? 1 : 0;
 		k2.seeds = h->d_seeds[par];
 		k2.items = h->d_items[par];
 		k2.drain_slot = -1;
@@ -1886,7 +1906,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			scan_drain(k2d, rdrain);
 			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs2, k2d);
 		}
-		if (!serial && h->knob.k2b_front)
+		if (!serial && (h->knob.k2b_front || k2.reach_on))
 			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
 		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[4], fs2));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
@@ -2615,6 +2635,25 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 
 /* verify result of the last push per (stream, channel slot): stream-relative position of the first
  * detector hit the tables lacked, or >= 0x7f000000 when the push verified */
+/* diagnostics: the cluster heads (cl_pack) of the last push's candidates, in vdl2gpu_debug_cands()'s order */
+extern "C" int vdl2gpu_debug_clheads(vdl2gpu_t *h, int stream, int ch, int *out, int max_cands)
+{
+	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out)
+		return VDL2GPU_EINVAL;
+	HLOCK(h);
+	int rc = vdl2gpu_sync(h);
+	if (rc)
+		return rc;
+	const int sc = stream * VDL2_CS + ch;
+	unsigned n = 0;
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) % VDL2_NSET] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	n = std::min<unsigned>(n, VDL2_CAND_CAP);
+	n = std::min<unsigned>(n, (unsigned)max_cands);
+	if (n)
+		HIPCHK(h, hipMemcpy(out, h->d_clhead[(h->pushes - 1) % VDL2_NSET] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
 extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
 {
 	if (!h || !out || n < h->S * VDL2_CS)

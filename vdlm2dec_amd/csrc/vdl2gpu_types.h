@@ -188,6 +188,8 @@ struct K2Params {
 	int *skey;		/* [S*8][CAND_CAP] candidates sorted by time: nrel*4 + r */
 	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
+	uint8_t *cinfo;		/* [S*8][CAND_CAP] by sorted rank: class | primary << 3 | first of its burst << 4 (k2s_sort -> k2s_fix, see K2sReach) */
+	int reach_on;		/* clusters only for the candidates whose class the chain can be in (K2sReach); 0: for every primary (round 4) */
 	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
 	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen: a private area per scan workgroup (worked off by that workgroup behind
 				 * its last tile), a common area behind them (worked off by the next kernel on the stream) */

@@ -248,6 +248,12 @@ class Receiver:
         n = self._check(self.L.vdl2gpu_debug_cands(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
         return buf[:n].copy()
 
+    def debug_clheads(self, stream: int, ch: int, max_cands: int = 4096) -> np.ndarray:
+        """(n_s_rel, packed) per candidate of the last push, in debug_cands()'s order: where and how the idle search resumes."""
+        buf = np.zeros((max_cands, 2), np.int32)
+        n = self._check(self.L.vdl2gpu_debug_clheads(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
+        return buf[:n].copy()
+
     def debug_heads(self, max_entries: int = 1 << 16) -> np.ndarray:
         """Header soft bits of every trigger of the last push (needs flags=lib.F_DEBUG_HEADS): structured array
         (nstar, sc, clk0, p2err, perr, err, pfr, soft[25])."""

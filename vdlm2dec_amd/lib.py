@@ -31,7 +31,7 @@ EXPORTS = (
     "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_inflight", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "vdl2gpu_decode_blocks", "vdl2gpu_poll_frames", "vdl2gpu_poll_frames_ready", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
     "vdl2gpu_choose_fc_rtl", "vdl2gpu_choose_fc_air",
-    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs", "vdl2gpu_debug_heads",
+    "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_clheads", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs", "vdl2gpu_debug_heads",
 )
 
 
@@ -165,6 +165,8 @@ def load(testhooks: bool = False):
     L.vdl2gpu_debug_segs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_cands.restype = C.c_int
     L.vdl2gpu_debug_cands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.vdl2gpu_debug_clheads.restype = C.c_int
+    L.vdl2gpu_debug_clheads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_heads.restype = C.c_int
     L.vdl2gpu_debug_heads.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.vdl2gpu_debug_counters.restype = C.c_int
