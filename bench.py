@@ -704,6 +704,7 @@ def main():
 
     fence()
     host_s[0] = host_s[1] = 0.0
+    rx.host_profile(reset=True)
     t0 = time.perf_counter()
     t_steps = []
     for _ in range(args.steps):
@@ -713,6 +714,7 @@ def main():
     rx.sync()
     fence()
     dt = time.perf_counter() - t0
+    hprof = rx.host_profile()
     rec1 = nrec
     last_timed_tile = npush[0] * ntiles            # exclusive
     tm = rx.timing(reset=True)
@@ -945,9 +947,13 @@ def main():
                                            "candidates", "repairs", "serial_redos", "serial_samples", "overflowed")},
             "parity": parity,
             "host_ms_per_step": {"in_push": host_s[0] / args.steps * 1e3, "in_poll_ready": host_s[1] / args.steps * 1e3,
-                                 "note": "wall time of the calling thread inside vdl2gpu_push (enqueues the step's ~20 launches) and inside "
-                                         "vdl2gpu_poll_ready (record read-back); the GPU works meanwhile -- the step is host-bound if their sum "
-                                         "approaches ms_per_step"},
+                                 "enqueue": hprof["enqueue"] / args.steps * 1e3, "wait_for_ring": hprof["wait_for_ring"] / args.steps * 1e3,
+                                 "wait_input": hprof["wait_input"] / args.steps * 1e3, "spill": hprof["spill"] / args.steps * 1e3,
+                                 "note": "wall time of the calling thread inside vdl2gpu_push and inside vdl2gpu_poll_ready (record read-back). "
+                                         "in_push = enqueue (the step's launches and event operations: what the thread must do) + wait_for_ring "
+                                         "(blocked until the GPU has finished the push three back, whose ring, tables and planes this push reuses: "
+                                         "the GPU is the slower side) + wait_input + spill, from vdl2gpu_get_host_profile(); the step is host-bound "
+                                         "only if `enqueue` + in_poll_ready approach ms_per_step"},
         }
         if gathered is not None:
             out["gather"] = gathered

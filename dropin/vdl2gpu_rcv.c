@@ -44,7 +44,8 @@ static channel_t g_ch[MAXNBCHANNELS];
  * the trigger is being processed; out.c prints that stamp with every message.  Here bursts come back one or more blocks
  * later, so the wall time of every push is kept (first input sample, timeval) and a burst gets the stamp of the push
  * its trigger sample (vdl2gpu_burst_t.trig_sample) arrived in.  The longest burst spans 33 blocks at 2 MS/s. */
-#define NSTAMP 256
+#define NSTAMP 1024	/* >= BATCH_BLOCKS hand-offs per push x (three pushes in the pipeline + the slot being filled) + the 33 blocks of the longest
+			 * burst + slack: a burst collected that many hand-offs after its trigger block still finds that block's stamp */
 static struct { unsigned long long first; struct timeval tv; } g_stamp[NSTAMP];
 static unsigned long long g_npush, g_nsamples;
 
@@ -73,6 +74,7 @@ static volatile int g_ready;	/* channels initialised so far (channel 0 must be f
  * vdl2gpu_poll(), one pipeline drain per 32768 samples: the CPU reference's own 133 MS/s]; vdl2gpu_rcv_flush() -- for the
  * program's shutdown path, next to stopVdlm2() (main.c:106-110) -- commits what is collected and waits for the rest. */
 #define BATCH_BLOCKS 64
+_Static_assert(NSTAMP >= BATCH_BLOCKS * 5 + 64, "the stamp ring must reach back over the pushes in flight");
 #define LIVE_GAP_NS 1000000	/* hand-offs at least this far apart are a live source: committed at once (a block is 16.4 ms of air time
 				 * at 2 MS/s, 3.3 ms at 10 MS/s); closer together the source is a replay and the slot fills first */
 static vdl2gpu_t *g_h;
@@ -162,6 +164,17 @@ void vdl2gpu_rcv_flush(void)
 	pthread_mutex_unlock(&g_mu);
 }
 
+static void flush_at_exit(void)
+{
+	if (pthread_mutex_trylock(&g_mu) == 0) {	/* (a thread caught in the middle of a hand-off keeps the lock: then nothing can be flushed safely) */
+		if (g_h) {
+			commit_slot();
+			deliver(g_h, 1);
+		}
+		pthread_mutex_unlock(&g_mu);
+	}
+}
+
 void *rcv_thread(void *arg)
 {
 	thread_param_t *param = (thread_param_t *) arg;
@@ -217,6 +230,10 @@ void *rcv_thread(void *arg)
 		pthread_mutex_lock(&g_mu);
 		g_h = h;
 		pthread_mutex_unlock(&g_mu);
+		/* the reference's main.c never calls vdl2gpu_rcv_flush(): what a fast source left in the slot being filled and what
+		 * the pipeline still holds is decoded and handed over when the program exits (a maintainer who adds the call next
+		 * to stopVdlm2() gets it earlier: INTEGRATION.md) */
+		atexit(flush_at_exit);
 	}
 
 	pthread_barrier_wait(&Bar1);
@@ -243,6 +260,12 @@ void *rcv_thread(void *arg)
 			if (g_slot) {
 				memcpy(g_slot + g_fill * SAMPLE_BYTES, (const void *)Cbuff, (RTLINBUFSZ / 2) * SAMPLE_BYTES);
 				g_fill += RTLINBUFSZ / 2;
+			} else {
+				/* no slot: the block still goes in, by the copying call (stamp_push() has counted its samples: dropping it
+				 * would shift every later burst's time stamp) */
+				const int rc = vdl2gpu_push(h, (const void *)Cbuff, RTLINBUFSZ / 2, 0, VDL2GPU_MEM_HOST);
+				if (rc)
+					fprintf(stderr, "vdl2gpu_push: %s (%s)\n", vdl2gpu_strerror(rc), vdl2gpu_last_error(h));
 			}
 			pthread_mutex_unlock(&g_mu);
 		}

@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define VDL2GPU_ABI_VERSION 5	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_*; 4: vdl2gpu_stats_t.repairs; 5: vdl2gpu_inflight, the handle lock ("Threads") */
+#define VDL2GPU_ABI_VERSION 6	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_*; 4: vdl2gpu_stats_t.repairs; 5: vdl2gpu_inflight, the handle lock ("Threads");
+				 * 6: vdl2gpu_get_host_profile, vdl2gpu_debug_clheads */
 #define VDL2GPU_MAXCH 8		/* MAXNBCHANNELS vdlm2.h:26 */
 #define VDL2GPU_MAXROWS 8	/* bursts with more rows are rejected, d8psk.c:103 */
 #define VDL2GPU_ROWLEN 255
@@ -229,6 +230,12 @@ int vdl2gpu_inflight(vdl2gpu_t *h);
 
 int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out);
 int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset);
+/* Where the calling thread's time inside vdl2gpu_push() went (host bookkeeping: no pipeline drain), seconds summed since the last
+ * reset: out8[0] waiting for the device buffer of the push before last; [1] enqueueing the channeliser; [2] collecting the output
+ * ring this push reuses (mostly WAITING for the push three back to finish: the GPU is the slower side then); [3] enqueueing the rest
+ * of the front stage; [4] moving uncollected records out of the slab's way; [5] enqueueing the back stage and the tail; [6] (part of
+ * [2] and of the polling calls) waiting for a ring's completion event; [7] the pushes counted.  Replaces nothing of the reference. */
+int vdl2gpu_get_host_profile(vdl2gpu_t *h, double *out8, int reset);
 const char *vdl2gpu_last_error(vdl2gpu_t *h);
 const char *vdl2gpu_strerror(int code);
 

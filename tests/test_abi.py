@@ -20,7 +20,7 @@ def test_exports_every_declared_symbol(built):
     assert declared == set(lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vdl2gpu_abi_version() == 5
+    assert L.vdl2gpu_abi_version() == 6
 
 
 def test_struct_layouts_match_header(built):

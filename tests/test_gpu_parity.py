@@ -203,6 +203,35 @@ def test_channeliser_push_sizes_around_its_tickets(built, oracle, fmt, nch):
         assert len(g) == len(d) and np.array_equal(d.view(np.uint32), g.view(np.uint32)), (fmt, nch, c)
 
 
+@pytest.mark.parametrize("rate,fmt", [(10_000_000, "cs16"), (6_000_000, "cu8"), (5_000_000, "cs16")])
+def test_period_parallel_channeliser_whole_and_ragged_pushes(built, oracle, rate, fmt):
+    """k1_pp (5 / 6 / 10 MS/s) takes whole periods of the dump schedule (4 * SDRCLK samples = 84 outputs); a push that starts on a
+    schedule boundary and is a whole number of periods is ONE launch since round 5 (no general-kernel launch at either end, the
+    kernel leaves the stream state itself), any other push runs its first and last period through the general kernel.  Both kinds
+    back to back, so that carried windows meet whole pushes: the 84 kS/s planes must be the oracle's bit for bit."""
+    per = 4 * (rate // 4000)
+    fos = (S.FO8_10MS if rate == 10_000_000 else S.FO8)[:8]
+    sizes = [per * 8, per * 5, per * 64, per * 6 + 17, per * 9 - 17, per * 4, per * 130, per * 7 + 1, per * 12 - 1, per * 66]
+    n = sum(sizes)
+    rng = np.random.default_rng(rate // 1000)
+    raw = rng.integers(-3000, 3000, 2 * n, dtype=np.int16) if fmt == "cs16" else rng.integers(0, 256, 2 * n, dtype=np.uint8)
+    with _rx(rate, fos, fmt, max_push=1 << 22, keep_dec=True) as rx:
+        decs = {c: [] for c in (0, 7)}
+        pos = 0
+        for k in sizes:
+            rx.push(raw[2 * pos:2 * (pos + k)])
+            for c in decs:
+                decs[c].append(rx.debug_dec(0, c))
+            pos += k
+        rx.poll()
+    for c, parts in decs.items():
+        ch = oracle.OracleChannel(rate, fos[c], S.FC + fos[c], tap_dec=True)
+        ch.feed(raw, fmt)
+        d, g = ch.dec(), np.concatenate(parts)
+        ch.close()
+        assert len(g) == len(d) and np.array_equal(d.view(np.uint32), g.view(np.uint32)), (rate, fmt, c)
+
+
 @pytest.mark.parametrize("fmt", ["cs16", "cu8"])
 def test_long_pushes_are_cut_into_parts(built, oracle, monkeypatch, fmt):
     """A push longer than ~36 s of air time is cut into equal parts inside the library (the tables hold what a busy
@@ -528,6 +557,28 @@ def test_many_streams_batch(built, oracle):
         want = sorted(b.key() for b in oracle.run_oracle(raws[s][:n], "cs16", specs[s].rate, specs[s].fo, S.FC))
         mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
         assert mine == want and len(want) >= 6, s
+
+
+def test_more_than_512_channel_slots_take_the_repaired_selection(built, oracle):
+    """A handle with more than 64 streams has channel slots the 16-word repair mask does not reach (slot = stream * 8 + channel):
+    the payload decode there is one pass behind the commit and must still take the selection a repair round re-resolved, and
+    nothing of the resolver's for a channel K2f redid serially (round 4's build decoded the stale first selection for slots >= 512:
+    ADVICE r4).  66 streams of one channel each, region scan dropped so that nearly every burst needs a repair; streams 0, 63, 64,
+    65 against the oracle."""
+    from vdlm2dec_amd import lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    spec = synth.random_scenario(2_000_000, S.FO8[:1], 1 << 20, seed=93, bursts_per_s=25.0, info_max=60)
+    raw1 = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw1, "cs16", spec.rate, spec.fo, S.FC))
+    nstr = 66
+    raw = np.stack([raw1] * nstr)
+    with Receiver(spec.rate, [plan_channels(S.FC, spec.fo)] * nstr, fmt="cs16", max_push=1 << 19, flags=lib.F_TEST_NOREGION) as rx:
+        got = rx.run(raw)
+        st = rx.stats()
+    assert st["repairs"] + st["serial_redos"] > 0 and len(want) >= 8
+    for s in (0, 63, 64, 65):
+        mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
+        assert mine == want, s
 
 
 def test_ingest_ring_equals_push(built, oracle):

@@ -98,7 +98,11 @@ struct vdl2gpu {
 									 * before last in every call, and the GPU's front stream waited for the calling thread */
 	unsigned *d_outc = nullptr;	/* [2*ring + {0,1}] = records written, dropped; [8], [9] running totals: serial redos, repairs */
 	bool ring_busy[VDL2_NRING] = {};
-	hipEvent_t ring_done[VDL2_NRING] = {};	/* the end of the push's tail: its records and counters are on the host */
+	hipEvent_t ring_done2[VDL2_NRING][2] = {};	/* the end of the push's tail: its records and counters are on the host.  Two events per ring, used in
+						 * turn (ring_ev[]): a collector that waits for one with the handle lock released (wait_harvest) would
+						 * otherwise wait on an event the producer may re-record for the push three later */
+	int ring_ev[VDL2_NRING] = {};		/* which of the two the ring's current push recorded */
+#define ring_done(r) ring_done2[r][h->ring_ev[r]]
 	hipEvent_t in_read[VDL2_NRING] = {};	/* its channeliser has read the caller's device buffer */
 	bool in_rec[VDL2_NRING] = {};
 	uint64_t ring_push[VDL2_NRING] = {};	/* which push filled the ring */
@@ -204,12 +208,14 @@ struct vdl2gpu {
 	std::string err;
 	double hprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* VDL2GPU_HOST_PROF: seconds of the calling thread in the segments of push_impl (printed at destroy) */
 	bool hprof_on = false;
+	uint64_t hprof_push0 = 0;	/* pushes at the last reset of hprof[] */
 	/* Environment knobs, read ONCE in create_impl (INTEGRATION.md lists them): push_impl never calls getenv.
 	 * The test handicaps (VDL2GPU_PRIM_DROP, VDL2GPU_SPLIT_SAMPLES, VDL2GPU_F_TEST_NOREGION) exist only in the
 	 * library built with -DVDL2GPU_TESTHOOKS (libvdl2gpu_test.so, which the tests load). */
 	struct {
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
 		bool no_tail = false;		/* VDL2GPU_NO_TAIL: everything behind the verify pass stays on the main stream */
+		bool no_whole_pp = false;	/* VDL2GPU_NO_WHOLE_PP: 5/6/10 MS/s pushes always run their first and last period through the general channeliser (round 4) */
 		bool reach = false;		/* VDL2GPU_REACH=1: clusters only for the classes the chain can meet a burst in (K2sReach: 4.8 per burst instead
 						 * of 7.9, a second short cluster launch; measured: nothing at the headline, 2-7 % on busy channels) */
 		double table_fill = 0.90;	/* VDL2GPU_TABLE_FILL (percent): how full the busiest channel's candidate table may get before parts are shortened */
@@ -586,8 +592,9 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		if (h->k2_done[r])
 			(void)hipEventDestroy(h->k2_done[r]);
 	for (int r = 0; r < VDL2_NRING; ++r) {
-		if (h->ring_done[r])
-			(void)hipEventDestroy(h->ring_done[r]);
+		for (int k = 0; k < 2; ++k)
+			if (h->ring_done2[r][k])
+				(void)hipEventDestroy(h->ring_done2[r][k]);
 		if (h->in_read[r])
 			(void)hipEventDestroy(h->in_read[r]);
 	}
@@ -744,7 +751,8 @@ static int create_impl(vdl2gpu_t *h)
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->k2_done[r], hipEventDisableTiming));
 	for (int r = 0; r < VDL2_NRING; ++r) {
-		HIPCHK(h, hipEventCreateWithFlags(&h->ring_done[r], hipEventDisableTiming));
+		for (int k = 0; k < 2; ++k)
+			HIPCHK(h, hipEventCreateWithFlags(&h->ring_done2[r][k], hipEventDisableTiming));
 		HIPCHK(h, hipEventCreateWithFlags(&h->in_read[r], hipEventDisableTiming));
 	}
 	{
@@ -820,6 +828,7 @@ static int create_impl(vdl2gpu_t *h)
 	h->knob.k2b_front = env_int("VDL2GPU_K2B_FRONT", 0) != 0;
 	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
 	h->knob.reach = env_int("VDL2GPU_REACH", 0) != 0;
+	h->knob.no_whole_pp = getenv("VDL2GPU_NO_WHOLE_PP") != nullptr;
 	h->knob.pay_tail = env_int("VDL2GPU_PAY_TAIL", 0) != 0;
 	h->knob.front2 = env_int("VDL2GPU_FRONT2", 0) != 0;
 	h->knob.table_fill = std::min(100, std::max(10, env_int("VDL2GPU_TABLE_FILL", 90))) / 100.0;
@@ -1461,7 +1470,8 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(pt.e[7], ts));
 	HIPCHK(h, hipEventRecord(h->k2_done[par], ts));
 	h->k2_rec[par] = true;
-	HIPCHK(h, hipEventRecord(h->ring_done[ring], ts));
+	h->ring_ev[ring] ^= 1;
+	HIPCHK(h, hipEventRecord(h->ring_done(ring), ts));
 	return VDL2GPU_OK;
 }
 
@@ -1491,8 +1501,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	/* include/vdl2gpu.h: a device buffer must stay unchanged "until the second push after this one has been issued": that push
 	 * is this call, for the buffer of the push before last (with two output rings the wait for that push's ring implied it) */
 	auto hnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	double hp_t = h->hprof_on ? hnow() : 0.0;
-	auto hp = [&](int k) { if (h->hprof_on) { const double t = hnow(); h->hprof[k] += t - hp_t; hp_t = t; } };
+	double hp_t = hnow();	/* (always on: six clock reads a push; vdl2gpu_get_host_profile() hands the sums out, VDL2GPU_HOST_PROF prints them at destroy) */
+	auto hp = [&](int k) { const double t = hnow(); h->hprof[k] += t - hp_t; hp_t = t; };
 	if (h->in_rec[(h->pushes + 1) % VDL2_NRING])
 		HIPCHK(h, hipEventSynchronize(h->in_read[(h->pushes + 1) % VDL2_NRING]));
 	hp(0);
@@ -1628,9 +1638,12 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		bool fast = (per_in % h->L == 0 && periods >= 4 && !h->quirk && !h->knob.no_k1_fast &&
 			     std::min(K1P_CH, h->maxwin) <= h->L);	/* k1_pp steps its LO index by a piece (<= a chunk, <= a window) and wraps it once */
 		K1PParams kp{};
+		/* a push that starts on a window boundary of the schedule (nothing carried in) and is a whole number of periods (nothing
+		 * carried out) needs no general launch at either end: the period-parallel kernel takes all of it (as k1_fast does below) */
+		const bool whole_pp = k1.c0 == 0 && nsamples % (size_t)per_in == 0 && J == periods * K1P_PER_OUT && !h->knob.no_whole_pp;
 		if (fast) {
 			auto wend_abs = [&](long long j) { return ((j + 1) * (long long)h->sdrclk - k1.c0 + 20) / 21 - 1; };
-			kp.per_lo = 1;
+			kp.per_lo = whole_pp ? 0 : 1;
 			kp.sbase0 = wend_abs(K1P_PER_OUT * kp.per_lo - 1) + 1;
 			/* 16-byte pieces: a period's first sample sits d samples above a 16-byte boundary, the same d for
 			 * every period (a period is a whole number of 16-byte pieces) and every stream */
@@ -1638,6 +1651,14 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			if ((a0 % 16) % h->sample_bytes || (h->S > 1 && stride % 16) || ((size_t)per_in * h->sample_bytes) % 16)
 				fast = false;
 			kp.d = (int)((a0 % 16) / h->sample_bytes);
+			if (whole_pp && kp.d != 0) {	/* (the kernel reads a period from the 16-byte boundary below its first sample: that would lie in front of the buffer) */
+				kp.per_lo = 1;
+				kp.sbase0 = wend_abs(K1P_PER_OUT * kp.per_lo - 1) + 1;
+				const uintptr_t a1 = (uintptr_t)src + (uintptr_t)kp.sbase0 * h->sample_bytes;
+				if ((a1 % 16) % h->sample_bytes)
+					fast = false;
+				kp.d = (int)((a1 % 16) / h->sample_bytes);
+			}
 		}
 		const long long nsp = periods / 4;	/* superperiods of 4 periods = 336 outputs = 21 lines of the planes */
 		const bool fast2m = fast && h->sdrclk == 500 && h->L == 80 && nsp >= 3 && !h->knob.k1_pp &&
@@ -1701,17 +1722,22 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			if (!whole)
 				generic((nsp - 1) * K1F_PER_OUT, J);
 		} else if (fast) {
-			generic(0, K1P_PER_OUT - 1);
+			const bool whole = kp.per_lo == 0;
+			if (!whole)
+				generic(0, K1P_PER_OUT - 1);
 			if (staged)
 				(void)hipEventRecord(pt.e[11], ks);
 			pt.fast = true;
+			kp.edge_state = whole ? 1 : 0;
+			kp.parity = k1.parity;
+			kp.J = J;
 			kp.raw = src;
 			kp.stream_stride = stride;
 			kp.nbch = h->C;
 			kp.per_in = per_in;
 			kp.L = h->L;
 			kp.ph0 = (int)(((long long)k1.no0 + kp.sbase0) % h->L);
-			kp.per_n = (int)(periods - 2);
+			kp.per_n = (int)(whole ? periods : periods - 2);
 			kp.lo_ext = h->d_lo_ext;
 			kp.lo_stride = h->L + 48;
 			kp.dec = k1.dec;
@@ -1763,7 +1789,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			if (staged)
 				(void)hipEventRecord(pt.e[9], ks);
 			pt.fast_parts = 1;
-			generic((periods - 1) * K1P_PER_OUT, J);
+			if (!whole)
+				generic((periods - 1) * K1P_PER_OUT, J);
 		} else
 			generic(0, J);
 		HIPCHK(h, hipGetLastError());
@@ -2030,7 +2057,7 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 	if (!h->ring_busy[ring])
 		return 0;
 	if (!blocking) {
-		const hipError_t q = hipEventQuery(h->ring_done[ring]);
+		const hipError_t q = hipEventQuery(h->ring_done(ring));
 		if (q == hipErrorNotReady)
 			return 1;
 		if (q != hipSuccess) {
@@ -2038,10 +2065,9 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			return VDL2GPU_EHIP;
 		}
 	}
-	const double hq0 = h->hprof_on ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
-	HIPCHK(h, hipEventSynchronize(h->ring_done[ring]));
-	if (h->hprof_on)
-		h->hprof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - hq0;
+	const double hq0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	HIPCHK(h, hipEventSynchronize(h->ring_done(ring)));
+	h->hprof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - hq0;
 	const unsigned c0 = h->h_pin_cnt[32 * ring], c1 = h->h_pin_cnt[32 * ring + 1];
 	const unsigned n = std::min(c0, h->rec_cap);
 	h->overflowed += c1;
@@ -2284,7 +2310,7 @@ static int wait_harvest(vdl2gpu_t *h, std::unique_lock<std::recursive_mutex> &lk
 		if (rc < 0)
 			return rc;
 		if (rc == 1) {
-			hipEvent_t ev = h->ring_done[r];
+			hipEvent_t ev = h->ring_done(r);
 			lk.unlock();
 			const hipError_t e = hipEventSynchronize(ev);
 			lk.lock();
@@ -2436,7 +2462,7 @@ extern "C" int vdl2gpu_inflight(vdl2gpu_t *h)
 	int n = 0;
 	for (int r = 0; r < VDL2_NRING; ++r)
 		if (h->ring_busy[r]) {
-			const hipError_t q = hipEventQuery(h->ring_done[r]);
+			const hipError_t q = hipEventQuery(h->ring_done(r));
 			if (q == hipErrorNotReady)
 				++n;
 			else if (q != hipSuccess) {
@@ -2511,6 +2537,27 @@ extern "C" int vdl2gpu_get_stats(vdl2gpu_t *h, vdl2gpu_stats_t *out)
 	return VDL2GPU_OK;
 }
 
+/* Where the calling thread's time inside vdl2gpu_push() went, in seconds, summed over the pushes since the last reset (no pipeline
+ * drain: it is host bookkeeping): out[0] waiting for the device buffer of the push before last, [1] enqueueing the channeliser,
+ * [2] collecting the output ring this push will reuse (mostly: WAITING for the push three back to finish -- the GPU is the slower
+ * side then), [3] enqueueing the rest of the front stage, [4] moving uncollected records out of the slab's way, [5] enqueueing the
+ * back stage and the tail, [6] of [2] and of the polling calls: waiting for a ring's completion event, [7] pushes counted. */
+extern "C" int vdl2gpu_get_host_profile(vdl2gpu_t *h, double *out8, int reset)
+{
+	if (!h || !out8)
+		return VDL2GPU_EINVAL;
+	HLOCK(h);
+	for (int i = 0; i < 7; ++i)
+		out8[i] = h->hprof[i];
+	out8[7] = (double)(h->pushes - h->hprof_push0);
+	if (reset) {
+		for (int i = 0; i < 7; ++i)
+			h->hprof[i] = 0.0;
+		h->hprof_push0 = h->pushes;
+	}
+	return VDL2GPU_OK;
+}
+
 extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset)
 {
 	if (!h || !out)
@@ -2542,9 +2589,11 @@ extern "C" int vdl2gpu_get_timing(vdl2gpu_t *h, vdl2gpu_timing_t *out, int reset
 /* ----------------------------------------------------------------- diagnostics */
 extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *out, int64_t max_complex)
 {
-	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out || !h->pushes)
+	if (!h || stream < 0 || stream >= h->S || ch < 0 || ch >= h->C || !out)
 		return VDL2GPU_EINVAL;
 	HLOCK(h);
+	if (!h->pushes)
+		return VDL2GPU_EINVAL;
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;

@@ -328,6 +328,14 @@ void k1_pp(K1PParams p)
 	const long long fill = VDL2_CARRY_FRAMES;
 	const bool active = c < p.nbch;
 	const char *raw = (const char *)p.raw + (size_t)s * p.stream_stride + (size_t)p.sbase0 * B;	/* first sample of period per_lo */
+	if (p.edge_state && blockIdx.x == 0 && tid < VDL2_CS) {	/* what k1_channelise leaves at a push's two ends (see k1_fast) */
+		StreamState *ss = p.ss + s;
+		if (tid == 0) {
+			ss->last_fill = VDL2_CARRY_FRAMES;
+			ss->last_J = p.J;
+		}
+		ss->acc[p.parity ^ 1][tid] = make_float2(0.0f, 0.0f);	/* the push ends on a window boundary: nothing carried */
+	}
 
 	/* loader role: NPT pieces (period lp, piece lj) */
 	const char *lptr[NPT];

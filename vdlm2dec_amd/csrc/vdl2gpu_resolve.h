@@ -1040,6 +1040,7 @@ void k2f_commit(K2Params p)
 		cs->n_redo += 1;
 		atomicAdd(p.outc_total_redo, 1u);
 		p.ctl[CTL_NSEL1 + sc] = 0;	/* K2d: nothing of the resolver's for this channel (it is masked: K2d reads the repair rounds' selection) ... */
+		p.redo[sc] = 1;			/* (... also where the mask does not reach: K2d's one pass behind the commit asks this word) */
 		if (p.fmask && sc < 512)	/* ... and if K2d ran ahead of the verify pass, the host drops what it made of it */
 			atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
 	}
@@ -1067,7 +1068,10 @@ void k2d_payload(K2Params p)
 	const bool masked = sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u);
 	if (p.sel_mode == 1 && !masked)
 		return;
-	const bool alt = p.sel_mode == 1 || (p.sel_mode == 2 && masked);	/* which of the two selections (see CTL_NSEL1) */
+	/* which of the two selections (see CTL_NSEL1).  The one pass behind the commit (sel_mode 2: the only mode of handles with
+	 * more than 512 channel slots, whose channels the 16-word mask does not cover) asks the channel's own word: a repair round
+	 * that re-resolved it (K2c) or K2f's serial redo set redo[sc] */
+	const bool alt = p.sel_mode == 1 || (p.sel_mode == 2 && p.redo[sc] != 0);
 	unsigned n = p.ctl[(alt ? CTL_NSEL1 : CTL_NSEL0) + sc];
 	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
 	const unsigned *sel = (alt ? p.sel_list2 : p.sel_list) + (size_t)sc * VDL2_SEL_CAP;

@@ -134,6 +134,10 @@ struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs)
 	float2 *dec;
 	long long cap;
 	StreamState *ss;
+	int edge_state;		/* the launch covers the whole push (it starts and ends on a window boundary of the schedule): it also leaves the
+				 * stream state the general kernel would (last_fill, last_J, an empty carry in acc[parity ^ 1]) */
+	int parity;
+	long long J;
 	int wend[84];		/* last sample of each window, relative to the period's first sample */
 };
 

@@ -248,6 +248,14 @@ class Receiver:
         n = self._check(self.L.vdl2gpu_debug_cands(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
         return buf[:n].copy()
 
+    def host_profile(self, reset: bool = False) -> dict:
+        """seconds of the calling thread inside vdl2gpu_push since the last reset: `enqueue` (launches and event operations) and
+        `wait_for_ring` (blocked until the GPU has finished the push whose output ring, tables and planes this one reuses)"""
+        buf = (C.c_double * 8)()
+        self._check(self.L.vdl2gpu_get_host_profile(self.h, buf, int(reset)))
+        v = list(buf)
+        return {"wait_input": v[0], "enqueue": v[1] + v[3] + v[5], "wait_for_ring": v[2], "spill": v[4], "event_wait": v[6], "pushes": int(v[7])}
+
     def debug_clheads(self, stream: int, ch: int, max_cands: int = 4096) -> np.ndarray:
         """(n_s_rel, packed) per candidate of the last push, in debug_cands()'s order: where and how the idle search resumes."""
         buf = np.zeros((max_cands, 2), np.int32)

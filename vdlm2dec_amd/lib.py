@@ -28,7 +28,7 @@ F_DEBUG_HEADS = 64
 EXPORTS = (
     "vdl2gpu_abi_version", "vdl2gpu_create", "vdl2gpu_destroy", "vdl2gpu_push", "vdl2gpu_sync",
     "vdl2gpu_ring_init", "vdl2gpu_ring_acquire", "vdl2gpu_ring_commit",
-    "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_inflight", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_last_error",
+    "vdl2gpu_poll", "vdl2gpu_poll_ready", "vdl2gpu_pending", "vdl2gpu_inflight", "vdl2gpu_get_stats", "vdl2gpu_get_timing", "vdl2gpu_get_host_profile", "vdl2gpu_last_error",
     "vdl2gpu_strerror", "vdl2gpu_burst_to_msgblk", "vdl2gpu_decode_blocks", "vdl2gpu_poll_frames", "vdl2gpu_poll_frames_ready", "reversebits", "vdl2gpu_lo_table", "vdl2gpu_plan",
     "vdl2gpu_choose_fc_rtl", "vdl2gpu_choose_fc_air",
     "vdl2gpu_debug_dec", "vdl2gpu_debug_lo", "vdl2gpu_debug_atan2f", "vdl2gpu_debug_counters", "vdl2gpu_debug_cands", "vdl2gpu_debug_clheads", "vdl2gpu_debug_fail", "vdl2gpu_debug_segs", "vdl2gpu_debug_heads",
@@ -128,6 +128,8 @@ def load(testhooks: bool = False):
     L.vdl2gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(StatsT)]
     L.vdl2gpu_get_timing.restype = C.c_int
     L.vdl2gpu_get_timing.argtypes = [C.c_void_p, C.POINTER(TimingT), C.c_int]
+    L.vdl2gpu_get_host_profile.restype = C.c_int
+    L.vdl2gpu_get_host_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.vdl2gpu_last_error.restype = C.c_char_p
     L.vdl2gpu_last_error.argtypes = [C.c_void_p]
     L.vdl2gpu_strerror.restype = C.c_char_p
