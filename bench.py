@@ -71,6 +71,18 @@ CONFIGS = {
 }
 
 
+def source_key() -> str:
+    """sha256 over the sources libvdl2gpu.so is built from (what __graft_entry__.build_hip watches): the key a committed PMC profile
+    carries (scripts/make_profiles.sh) -- bench.py quotes a profile's traffic only for the tree it was measured on"""
+    import hashlib
+    csrc = os.path.join(ROOT, "vdlm2dec_amd", "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h", ".inc"))] + [os.path.join(ROOT, "include", "vdl2gpu.h")]
+    hsh = hashlib.sha256()
+    for f in files:
+        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def synth_default():
     from vdlm2dec_amd import synth
     return synth.DEFAULT_FO_8CH
@@ -864,13 +876,18 @@ def main():
                                     "and the final drain that `value` (exactly --steps steps between two fences, the contract's figure) contains"}
         traffic, traffic_src, whole_step = None, None, None
         try:
-            pmf = [f for f in ("r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            pmf = [f for f in ("r05_bench_pmc_hbm.json", "r04_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
-            if args.config == 2 and not args.tiles and args.fmt == "cs16" and not args.rate and not args.streams:
+            key_now = source_key()
+            if pm.get("source_key") != key_now:
+                # a stale replay is worse than none: the counters of another build say nothing about this one's traffic
+                traffic_src = (f"profiles/{pmf} was measured on sources {pm.get('source_key')} (commit {pm.get('head')}), this run is {key_now}: "
+                               "not quoted -- regenerate with scripts/make_profiles.sh")
+            elif args.config == 2 and not args.tiles and args.fmt == "cs16" and not args.rate and not args.streams:
                 fk = [k for k in pm["FETCH_SIZE_KB_per_launch"] if kname in k][0]
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"][fk] + pm["WRITE_SIZE_KB_per_launch"][fk]) * 1024.0
-                traffic_src = f"profiles/{pmf}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command (2 x FETCH_SIZE + WRITE_SIZE per launch, the gfx950 " \
-                              "correction of MI355X_MICROARCH.md), replayed from the committed file -- PMC counters cannot be read by the run itself"
+                traffic_src = f"profiles/{pmf} (commit {pm.get('head')}, sources {key_now} = this run's): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command " \
+                              "(2 x FETCH_SIZE + WRITE_SIZE per launch, the gfx950 correction of MI355X_MICROARCH.md), replayed from the committed file -- PMC counters cannot be read by the run itself"
                 # the whole step from the same committed passes: every kernel's HBM traffic and vector instructions, launches per step as in the trace
                 sqf = pmf.replace("_hbm", "_sq")
                 sqj = json.load(open(os.path.join(ROOT, "profiles", sqf)))

@@ -8,7 +8,7 @@
 #   (round 2's micro-benchmarks and k1_fast ablations -- profiles/r02_valu_rate.txt, r02_clock_rate.txt, r02_k1_ablation.txt --
 #    describe kernels this round did not change; WITH_BER=1 adds the Es/N0 sweep)
 cd "$(dirname "$0")/.."
-R=${R:-r04}
+R=${R:-r05}
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles
 mkdir -p $OUT
@@ -64,6 +64,13 @@ try:
 except (OSError, KeyError, ValueError):
     pass
 res["per_step_bytes"] = {k: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for k, v in hb_step.items()}
+# which build these counters belong to: bench.py quotes them only when its own sources hash to the same key (R_HEAD: the commit, handed in by
+# whoever starts the script -- the GPU box has no .git)
+import os
+sys.path.insert(0, os.getcwd())
+import bench
+res["source_key"] = bench.source_key()
+res["head"] = os.environ.get("R_HEAD", "unknown")
 json.dump(res, open(out + "/" + R + "_bench_pmc_hbm.json", "w"), indent=1)
 sq, sq_step = collect(["/tmp/pr_s1", "/tmp/pr_s2", "/tmp/pr_s3"])
 json.dump({"per_launch": sq, "per_step": {k: {"SQ_INSTS_VALU": v.get("SQ_INSTS_VALU", 0.0)} for k, v in sq_step.items()}, "_note": "SQ_* in quad-cycles / instructions summed over the chip, GRBM_GUI_ACTIVE summed over the 8 XCDs; "

@@ -559,6 +559,31 @@ def test_many_streams_batch(built, oracle):
         assert mine == want and len(want) >= 6, s
 
 
+@pytest.mark.parametrize("knob", ["VDL2GPU_STREAM_GROUPS", "VDL2GPU_REACH", "VDL2GPU_K2B_FRONT", "VDL2GPU_RESERVE_CUS"])
+def test_opt_in_arrangements_equal_the_oracle(built, oracle, monkeypatch, knob):
+    """Round 5's measured-and-not-adopted arrangements stay exact: a multi-stream push worked off stream group by stream group
+    (a pass of the pipeline per stream), clusters only for the classes the chain can meet a burst in (k2s_sort's reachable sets,
+    k2s_fix and a second cluster launch), the cluster kernel in the front stage, CU-masked streams for the wide kernels.  Three
+    streams, several pushes in the pipeline, ragged push lengths."""
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv(knob, "16" if knob == "VDL2GPU_RESERVE_CUS" else "1")
+    specs = [synth.random_scenario(2_000_000, S.FO8, 1 << 21, seed=700 + i, bursts_per_s=12.0, info_max=120) for i in range(3)]
+    raws = [synth.synth_stream(sp, "cs16") for sp in specs]
+    raw = np.stack(raws)
+    got = []
+    with Receiver(2_000_000, [plan_channels(S.FC, sp.fo) for sp in specs], fmt="cs16", max_push=1 << 20) as rx:
+        pos = 0
+        for k in (600_000, 400_001, 500_000, 597_151):
+            rx.push(raw[:, 2 * pos:2 * (pos + k)])
+            got += rx.poll_ready()
+            pos += k
+        got += rx.poll()
+    for s in range(3):
+        want = sorted(b.key() for b in oracle.run_oracle(raws[s], "cs16", specs[s].rate, specs[s].fo, S.FC))
+        mine = sorted((b.chn, b.nbrow, b.nlbyte, b.data) for b in got if b.stream == s)
+        assert mine == want and len(want) >= 20, (knob, s)
+
+
 def test_more_than_512_channel_slots_take_the_repaired_selection(built, oracle):
     """A handle with more than 64 streams has channel slots the 16-word repair mask does not reach (slot = stream * 8 + channel):
     the payload decode there is one pass behind the commit and must still take the selection a repair round re-resolved, and

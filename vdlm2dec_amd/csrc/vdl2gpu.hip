@@ -84,7 +84,17 @@ struct vdl2gpu {
 	std::vector<char> ring_inflight;
 	float2 *d_lo = nullptr;
 	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
-	unsigned k1_tbase[8] = {0, 0, 0, 0, 0, 0, 0, 0};	/* what they hold, per XCD (the same for every role and stream) */
+	std::vector<unsigned> k1_tbase;	/* [S][8] what they hold, per stream and XCD (the same for every role; the same for every stream between two calls) */
+	/* Stream groups.  A push of S > 1 streams is worked off group by group, each group a pass of its own through the pipeline
+	 * (its own table / plane set and output ring, like a part of a long push): eight streams in one pass wrote 1.4 GB of planes
+	 * between the channeliser and the scans that read them -- out of the 256 MB Infinity Cache and back from HBM --, and were
+	 * 10 % slower than eight single-stream pushes; a group is what fits (one stream of a 67 MS push: 180 MB).  Fixed for the
+	 * handle's life: a stream's carry goes to the plane set its NEXT pass will use, ngroups sets on ((3 does not divide ngroups). */
+	int ngroups = 1;		/* passes per push */
+	int grp_sbase = 0, grp_scount = 0;	/* the streams of the pass being enqueued (push_checked -> push_impl) */
+	bool grp_last = true;		/* ... it is the push's last: stream time advances behind it */
+	uint64_t tstep = 0;		/* pushes counted in stream time (every stream has seen so many) */
+	std::vector<int> last_set;	/* [S] the table / plane set of the stream's last pass (the debug calls read it) */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
 	float2 *d_dec[VDL2_NSET] = {};	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
 							 * reader, the back stage's tail, was ENQUEUED -- with two sets the channeliser had to wait for that tail */
@@ -248,6 +258,7 @@ struct vdl2gpu {
 		int par = 0, ring = 0, slab = 0;
 		bool staged = false, serial = false, two_streams = false;
 		unsigned tiles = 0;
+		int sbase = 0, scount = 1;	/* the streams of the pass */
 		size_t pt_index = 0;	/* its PushTiming in `pending` */
 	} back;
 	hipStream_t fstream = nullptr;
@@ -722,6 +733,18 @@ static int create_impl(vdl2gpu_t *h)
 	h->n_cu_all = h->n_cu;
 	h->n_cu -= h->reserve_cus;	/* (what the wide kernels' grids are sized by) */
 	const int S = h->S, L = h->L;
+	h->k1_tbase.assign((size_t)S * 8, 0u);
+	h->last_set.assign((size_t)S, 0);
+	h->grp_scount = S;
+	{
+		/* one stream per pass -- unless 3 divided the number of passes (the stream's next pass must find its carry in ANOTHER set
+		 * of the three): then the first pass takes two streams.  Opt-in (VDL2GPU_STREAM_GROUPS=1): once the scans worked their items off
+		 * themselves (round 5) eight streams in one pass ran at eight times the single-stream rate anyway (148 against 146 GS/s). */
+		const char *e = getenv("VDL2GPU_STREAM_GROUPS");
+		h->ngroups = (S > 1 && e && atoi(e) != 0) ? (S % 3 == 0 ? S - 1 : S) : 1;
+		if (h->ngroups % 3 == 0)
+			h->ngroups = 1;
+	}
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
 	h->cap = (VDL2_CARRY_FRAMES + jmax + 64 + 15) / 16 * 16;	/* planes start on 128-byte lines */
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
@@ -1152,8 +1175,27 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 	 * (other rates; VDL2GPU_F_RTL_QUIRK needs whole blocks anyway); any cut gives the same bursts. */
 	int rc = VDL2GPU_OK;
 	const size_t lim = h ? h->split_samples : 0;
+	/* a part of the push (all of it as a rule), stream group by stream group (vdl2gpu::ngroups) */
+	auto passes = [&](const void *q, size_t n) -> int {
+		if (!h)
+			return push_impl(h, q, n, stream_stride_bytes, memkind, wait_copy);
+		const int ng = h->ngroups, S = h->S;
+		int sb = 0, r = VDL2GPU_OK;
+		for (int g = 0; g < ng && r == VDL2GPU_OK; ++g) {
+			const int cnt = (g == 0) ? S - (ng - 1) : 1;	/* one stream per pass; the first takes what is left over */
+			h->grp_sbase = sb;
+			h->grp_scount = cnt;
+			h->grp_last = g == ng - 1;
+			r = push_impl(h, q, n, stream_stride_bytes, memkind, wait_copy);
+			sb += cnt;
+		}
+		h->grp_sbase = 0;
+		h->grp_scount = S;
+		h->grp_last = true;
+		return r;
+	};
 	if (!h || !iq || lim == 0 || nsamples <= lim)
-		rc = push_impl(h, iq, nsamples, stream_stride_bytes, memkind, wait_copy);
+		rc = passes(iq, nsamples);
 	else {
 		if (nsamples > h->cfg.max_push)
 			return VDL2GPU_EINVAL;
@@ -1161,7 +1203,7 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 		const size_t unit = h->split_unit;
 		const size_t part = ((nsamples + parts - 1) / parts + unit - 1) / unit * unit;
 		for (size_t off = 0; off < nsamples && rc == VDL2GPU_OK; off += part)
-			rc = push_impl(h, (const char *)iq + off * h->sample_bytes, std::min(part, nsamples - off), stream_stride_bytes, memkind, wait_copy);
+			rc = passes((const char *)iq + off * h->sample_bytes, std::min(part, nsamples - off));
 	}
 	if (rc == VDL2GPU_EHIP)
 		h->failed = true;	/* part of the push may be enqueued: nothing after it can be trusted */
@@ -1260,8 +1302,9 @@ static int enqueue_back(vdl2gpu_t *h)
 	const int par = h->back.par, ring = h->back.ring;
 	const bool staged = h->back.staged, serial = h->back.serial;
 	const unsigned tiles = h->back.tiles;
+	const int GS = h->back.scount;	/* the streams of this pass */
 	PushTiming &pt = h->pending[h->back.pt_index];
-	const dim3 gch((unsigned)h->C, (unsigned)h->S);
+	const dim3 gch((unsigned)h->C, (unsigned)GS);
 	hipStream_t rs = h->stream;
 	if (h->back.two_streams)
 		HIPCHK(h, hipStreamWaitEvent(rs, h->f_done[par], 0));
@@ -1274,15 +1317,15 @@ static int enqueue_back(vdl2gpu_t *h)
 		 * with their real exits known, the few that have become reachable without a cluster: one narrow kernel and a short
 		 * second launch of the cluster kernel (0.3 clusters per burst) */
 		hipLaunchKernelGGL(k2s_fix, gch, dim3(K2S_NT), 0, rs, k2);
-		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
 	} else if (!serial && !h->knob.k2b_front)
-		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
+		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[3], rs));
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[13], rs));
-	const dim3 vgrid0((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S);
+	const dim3 vgrid0((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)GS);
 	ScanDrain vdrain;	/* the verify pass whose common area the next one-workgroup-per-channel kernel of the tail has to drain */
 	if (h->k2f_rec)		/* the channel states the resolver starts from are committed on the previous push's tail */
 		HIPCHK(h, hipStreamWaitEvent(rs, h->k2f_done, 0));
@@ -1309,7 +1352,7 @@ static int enqueue_back(vdl2gpu_t *h)
 	hipStream_t ps = (h->knob.pay_tail || h->knob.front2) ? h->pay_stream : h->copy_stream;	/* (four hardware queues: the copy stream has one job) */
 	if (spec) {
 		HIPCHK(h, hipStreamWaitEvent(ps, h->k2c_done, 0));
-		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ps, k2);
+		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * GS)), dim3(K2D_NT), 0, ps, k2);
 		HIPCHK(h, hipEventRecord(h->pay_done, ps));
 	}
 	if (staged)
@@ -1353,7 +1396,7 @@ static int enqueue_back(vdl2gpu_t *h)
 		 * last round is a complete one: that re-makes the failing channels' clusters, whose descriptors the decode may be reading) */
 		if (spec && h->repair_rounds >= 2 && ts != ps)
 			HIPCHK(h, hipStreamWaitEvent(ts, h->pay_done, 0));
-		const dim3 vgrid((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)h->S);
+		const dim3 vgrid((tiles / 2 + 1 + K2A_VRUN - 1) / K2A_VRUN, (unsigned)h->C, (unsigned)GS);
 		for (int rr = 1; rr <= h->repair_rounds; ++rr) {
 			k2r.round = rr;
 			k2r.full_round = (rr == h->repair_rounds && h->repair_rounds >= 2) ? 1 : 0;
@@ -1365,11 +1408,11 @@ static int enqueue_back(vdl2gpu_t *h)
 				const unsigned want = tiles;
 				unsigned per = (unsigned)h->n_cu;	/* few channels fail: each may use the whole GPU (the others' workgroups leave at once) */
 				per = per > want ? want : per;
-				const ScanDrain pdrain = launch_scan(SCAN_PROBE, k2r, dim3(per, (unsigned)h->C, (unsigned)h->S), ts, VDL2_SURV_FULL, 0, 0, 4 * ((want + per - 1) / per));
+				const ScanDrain pdrain = launch_scan(SCAN_PROBE, k2r, dim3(per, (unsigned)h->C, (unsigned)GS), ts, VDL2_SURV_FULL, 0, 0, 4 * ((want + per - 1) / per));
 				scan_drain(k2r, pdrain);
 				hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, ts, k2r);
 				scan_drain(k2r, ScanDrain());
-				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
+				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
 				vdrain = ScanDrain();	/* (nothing is verified behind a complete round) */
 			} else {
@@ -1405,12 +1448,12 @@ static int enqueue_back(vdl2gpu_t *h)
 			K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
 			k2p.pay_final = 1;
 			k2p.sel_mode = 1;
-			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2p);
+			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * GS)), dim3(K2D_NT), 0, ts, k2p);
 		}
 	} else {
 		K2Params k2p = k2;	/* one pass behind the commit: the repaired selection where there is one */
 		k2p.sel_mode = 2;
-		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * h->S)), dim3(K2D_NT), 0, ts, k2p);
+		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * GS)), dim3(K2D_NT), 0, ts, k2p);
 	}
 	HIPCHK(h, hipGetLastError());
 	if (staged && h->stage_dump)
@@ -1437,6 +1480,7 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(pt.e[6], ts));
 	{
 		K3Params k3{};
+		k3.sbase = h->back.sbase;
 		k3.src = nullptr;	/* (the counters kernel copies nothing) */
 		k3.dst = nullptr;
 		k3.cap = h->cap;
@@ -1463,7 +1507,7 @@ static int enqueue_back(vdl2gpu_t *h)
 			if (staged && h->stage_dump)
 				HIPCHK(h, hipEventRecord(pt.e[22], ts));
 		}
-		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)h->S), dim3(64), 0, ts, k3);
+		hipLaunchKernelGGL(k3_rebase, dim3((unsigned)GS), dim3(64), 0, ts, k3);
 		HIPCHK(h, hipGetLastError());
 	}
 	if (staged)
@@ -1500,6 +1544,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	}
 	/* include/vdl2gpu.h: a device buffer must stay unchanged "until the second push after this one has been issued": that push
 	 * is this call, for the buffer of the push before last (with two output rings the wait for that push's ring implied it) */
+	const int SB = h->grp_sbase, GS = h->grp_scount;	/* the streams of this pass (push_checked) */
 	auto hnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double hp_t = hnow();	/* (always on: six clock reads a push; vdl2gpu_get_host_profile() hands the sums out, VDL2GPU_HOST_PROF prints them at destroy) */
 	auto hp = [&](int k) { const double t = hnow(); h->hprof[k] += t - hp_t; hp_t = t; };
@@ -1534,7 +1579,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		/* the channeliser of the push before last has read this buffer */
 		if (h->k1_rec[stg])
 			HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->k1_done[stg], 0));
-		for (int s = 0; s < h->S; ++s)
+		for (int s = SB; s < SB + GS; ++s)	/* (the pass's streams, where all S would lie: the channeliser indexes by stream) */
 			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw[stg] + (size_t)s * per,
 						 (const char *)iq + (size_t)s * stream_stride_bytes, per,
 						 hipMemcpyHostToDevice, h->in_stream));
@@ -1552,6 +1597,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	vdl2gpu_plan(h->total_in, nsamples, (unsigned)h->sdrclk, (unsigned)h->L, &k1.c0, &k1.no0, &k1.nf0, &J);
 	const int par = (int)(h->pushes % VDL2_NSET);	/* table set, plane set and output ring of this push */
 	const int pset = par;
+	k1.sbase = SB;
 	k1.raw = src;
 	k1.stream_stride = stride;
 	k1.fmt = h->cfg.fmt;
@@ -1559,7 +1605,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	k1.sdrclk = h->sdrclk;
 	k1.L = h->L;
 	k1.maxwin = h->maxwin;
-	k1.parity = (int)(h->pushes & 1);	/* the carried partial window is double-buffered in StreamState.acc: read [parity], written [parity ^ 1] */
+	k1.parity = (int)(h->tstep & 1);	/* the carried partial window is double-buffered in StreamState.acc: read [parity], written [parity ^ 1] */
 	k1.quirk = h->quirk;
 	k1.N = (long long)nsamples;
 	k1.J = J;
@@ -1585,7 +1631,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	int rc = get_events(h, pt);
 	if (rc)
 		return rc;
-	pt.samples = nsamples;
+	pt.samples = h->grp_last ? nsamples : 0;	/* (samples per stream: counted once per push, not once per pass) */
 	pt.fast = false;
 	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
 	pt.index = h->pushes;
@@ -1622,7 +1668,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			q.jbeg = jbeg;
 			q.jend = jend;
 			const unsigned gx = (unsigned)((jend - jbeg + 1 + per_block - 1) / per_block);
-			const dim3 grid(gx, (unsigned)h->S);
+			const dim3 grid(gx, (unsigned)GS);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: launch_k1<VDL2GPU_FMT_CU8>(q, grid, smem, ks); break;
 			case VDL2GPU_FMT_CS16: launch_k1<VDL2GPU_FMT_CS16>(q, grid, smem, ks); break;
@@ -1690,7 +1736,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			long long ngrp;
 			{
 				const long long slots = (long long)h->n_cu * 2 * K1F_WAVES_OF(h->cfg.fmt);
-				const long long per_fam = (long long)K1F_ROLES * 8 * h->S;
+				const long long per_fam = (long long)K1F_ROLES * 8 * GS;
 				long long nfam = slots / per_fam;
 				if (nfam < 4 && (nfam + 1) * per_fam * 100 <= slots * 108)
 					++nfam;
@@ -1704,12 +1750,13 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			 * host knows where each one stands */
 			k1.tickets = h->d_k1_tickets;
 			for (int x = 0; x < 8; ++x) {
-				k1.tbase[x] = h->k1_tbase[x];
+				k1.tbase[x] = h->k1_tbase[(size_t)SB * 8 + x];	/* (every stream of the pass stands where the first does: all have seen the same pushes) */
 				const long long n_x = (k1.per_n - x + 7) >> 3;
 				if (n_x > 0)
-					h->k1_tbase[x] += (unsigned)((n_x + K1F_CHUNK - 1) / K1F_CHUNK);
+					for (int sg = SB; sg < SB + GS; ++sg)
+						h->k1_tbase[(size_t)sg * 8 + x] += (unsigned)((n_x + K1F_CHUNK - 1) / K1F_CHUNK);
 			}
-			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)h->S);
+			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)GS);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CU8>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
 			case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_fast<VDL2GPU_FMT_CS16>, grid, dim3(K1F_THREADS), 0, ks, k1); break;
@@ -1731,6 +1778,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			kp.edge_state = whole ? 1 : 0;
 			kp.parity = k1.parity;
 			kp.J = J;
+			kp.sbase = SB;
 			kp.raw = src;
 			kp.stream_stride = stride;
 			kp.nbch = h->C;
@@ -1765,7 +1813,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			int best = 1;
 			double best_eff = -1;
 			for (int nsub : divs) {
-				const long long tasks = blocks * nsub * h->S;
+				const long long tasks = blocks * nsub * GS;
 				const long long rounds = (tasks + resident - 1) / resident;
 				const double eff = (double)tasks / (double)(rounds * resident) - 0.004 * nsub;	/* shorter tasks pay their start-up more often */
 				if (eff > best_eff) {
@@ -1779,7 +1827,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			kp.wpt = K1P_PER_OUT / best;
 			if (staged)
 				(void)hipEventRecord(pt.e[8], ks);
-			const dim3 grid((unsigned)(blocks * kp.nsub), (unsigned)h->S);
+			const dim3 grid((unsigned)(blocks * kp.nsub), (unsigned)GS);
 			switch (h->cfg.fmt) {
 			case VDL2GPU_FMT_CU8: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CU8>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
 			case VDL2GPU_FMT_CS16: hipLaunchKernelGGL(k1_pp<VDL2GPU_FMT_CS16>, grid, dim3(K1P_THREADS), 0, ks, kp); break;
@@ -1832,6 +1880,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(pt.e[10], fs));
 	{
 		K2Params k2{};
+		k2.sbase = SB;
+		k2.scount = GS;
 		k2.dec = h->d_dec[pset];
 		k2.cap = h->cap;
 		k2.nbch = h->C;
@@ -1872,7 +1922,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.headtap = h->d_headtap;
 		k2.headtap_n = h->d_headtap_n;
 		k2.headtap_cap = h->headtap_cap;
-		if (h->d_headtap) {
+		if (h->d_headtap && SB == 0) {	/* (once per push: its first pass) */
 			/* VDL2GPU_F_DEBUG_HEADS: one tap buffer for the handle, so the pipeline is drained first -- the back stage and the
 			 * tail of the two pushes before would otherwise still be appending to it ("every trigger of the LAST push") */
 			HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1897,20 +1947,20 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.items = h->d_items[par];
 		k2.drain_slot = -1;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
-		const dim3 gch((unsigned)h->C, (unsigned)h->S);
+		const dim3 gch((unsigned)h->C, (unsigned)GS);
 		ScanDrain pdrain, rdrain;
 		if (!serial) {
 			{
 				/* as many workgroups as are resident at once, each walking its share of the channel's tiles */
 				const unsigned want = h->full_scan ? tiles : tiles / 2 + 1;
-				unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * h->S - 1) / (h->C * h->S));
+				unsigned per = (unsigned)((h->n_cu * h->probe_occ + h->C * GS - 1) / (h->C * GS));
 				per = per < 1 ? 1 : (per > want ? want : per);
 				per = std::min<unsigned>(per, VDL2_MAXWG);
 				/* the probe needs the carry the push before made (the first 49152 frames of this plane set); with the front
 				 * stage on two streams (below) that copy is not on this stream */
 				if (fs2 != fs && h->last_two_streams)
 					HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
-				pdrain = launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)h->S), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : (VDL2_PROBE_STRIDE == 2 ? 2 : 3), 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
+				pdrain = launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)GS), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : (VDL2_PROBE_STRIDE == 2 ? 2 : 3), 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
 			}
 			/* FRONT, second half (VDL2GPU_FRONT2=1; off by default: same step time either way): regions, region scan, sort and the carry copy -- one-workgroup-
 			 * per-channel kernels and two short wide ones, 80 us of mostly idle GPU -- go to the copy stream, so that the NEXT push's
@@ -1925,7 +1975,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				scan_drain(k2d, pdrain);
 				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs2, k2d);
 			}
-			rdrain = launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)h->S), fs2, VDL2_SURV_REGION, 0, 1, 2);
+			rdrain = launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)GS), fs2, VDL2_SURV_REGION, 0, 1, 2);
 			HIPCHK(h, hipGetLastError());
 		}
 		if (!serial) {
@@ -1934,7 +1984,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs2, k2d);
 		}
 		if (!serial && (h->knob.k2b_front || k2.reach_on))
-			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((h->S * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
+			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
 		if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[4], fs2));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
 		HIPCHK(h, hipGetLastError());
@@ -1950,15 +2000,19 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			/* the next plane set's head was last read by the tail of the push two back (a repaired channel's payloads are
 			 * decoded late: a burst at the very start of that push lies in its head); the next push's channeliser, right
 			 * behind this copy, waits for that same tail anyway */
-			if (two_streams && h->k2_rec[(par + 1) % VDL2_NSET])
+			/* (with stream groups the streams' next pass is ngroups passes on, in set (par + ngroups) % 3; the last reader of
+			 * THESE streams' planes there was their pass 2 * ngroups >= 4 passes back, whose tail this pass's channeliser has
+			 * waited for: tails follow each other) */
+			if (two_streams && h->ngroups == 1 && h->k2_rec[(par + 1) % VDL2_NSET])
 				HIPCHK(h, hipStreamWaitEvent(fs2, h->k2_done[(par + 1) % VDL2_NSET], 0));
 			K3Params k3{};
+			k3.sbase = SB;
 			k3.src = h->d_dec[pset];
-			k3.dst = h->d_dec[(pset + 1) % VDL2_NSET];
+			k3.dst = h->d_dec[(pset + h->ngroups) % VDL2_NSET];
 			k3.cap = h->cap;
 			k3.nbch = h->C;
 			k3.J = J;
-			hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)h->S), dim3(K3_THREADS), 0, fs2, k3);
+			hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)GS), dim3(K3_THREADS), 0, fs2, k3);
 			HIPCHK(h, hipGetLastError());
 			if (two_streams)	/* a following push that keeps to the main stream must see the carry (and with two front streams: the next probe) */
 				HIPCHK(h, hipEventRecord(h->f_tail, fs2));
@@ -1977,6 +2031,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		h->back.serial = serial;
 		h->back.two_streams = two_streams;
 		h->back.tiles = tiles;
+		h->back.sbase = SB;
+		h->back.scount = GS;
 		h->back.pt_index = h->pending.size();
 	}
 	h->pending.push_back(pt);
@@ -1995,7 +2051,12 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	h->ring_slab[ring] = slab;
 	h->ring_push[ring] = h->pushes;
 	h->ring_samples[ring] = nsamples;
-	h->total_in += nsamples;
+	for (int sg = SB; sg < SB + GS; ++sg)
+		h->last_set[(size_t)sg] = par;
+	if (h->grp_last) {	/* every stream has been through: stream time advances */
+		h->total_in += nsamples;
+		h->tstep++;
+	}
 	h->pushes++;
 	return VDL2GPU_OK;
 }
@@ -2599,7 +2660,7 @@ extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *ou
 		return rc;
 	StreamState ss;
 	HIPCHK(h, hipMemcpy(&ss, h->d_ss + stream, sizeof ss, hipMemcpyDeviceToHost));
-	const int par = (int)((h->pushes - 1) % VDL2_NSET);
+	const int par = h->last_set[(size_t)stream];
 	const int64_t n = std::min<int64_t>(ss.last_J, max_complex);
 	if (n <= 0)
 		return 0;
@@ -2674,11 +2735,11 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) % VDL2_NSET] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set[(size_t)stream]] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, VDL2_CAND_CAP);
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_cands[(h->pushes - 1) % VDL2_NSET] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_cands[h->last_set[(size_t)stream]] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -2695,11 +2756,11 @@ extern "C" int vdl2gpu_debug_clheads(vdl2gpu_t *h, int stream, int ch, int *out,
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) % VDL2_NSET] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set[(size_t)stream]] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, VDL2_CAND_CAP);
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_clhead[(h->pushes - 1) % VDL2_NSET] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_clhead[h->last_set[(size_t)stream]] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -2711,7 +2772,8 @@ extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
 	int rc = vdl2gpu_sync(h);
 	if (rc)
 		return rc;
-	HIPCHK(h, hipMemcpy(out, h->d_fail[(h->pushes - 1) % VDL2_NSET], (size_t)h->S * VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
+	for (int st = 0; st < h->S; ++st)	/* (every stream from the set of its last pass) */
+		HIPCHK(h, hipMemcpy(out + (size_t)st * VDL2_CS, h->d_fail[h->last_set[(size_t)st]] + (size_t)st * VDL2_CS, VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
 	return h->S * VDL2_CS;
 }
 
@@ -2725,10 +2787,10 @@ extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, in
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[(h->pushes - 1) % VDL2_NSET] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set[(size_t)stream]] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, (unsigned)std::min(max_segs, VDL2_SEG_CAP));
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_segs[(h->pushes - 1) % VDL2_NSET] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_segs[h->last_set[(size_t)stream]] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 

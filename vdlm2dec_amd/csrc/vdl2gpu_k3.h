@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(K3_THREADS)
 void k3_carry(K3Params p)
 {
-	const int c = blockIdx.y, s = blockIdx.z;
+	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	const size_t plane = ((size_t)s * VDL2_CS + c) * p.cap;
 	const float2 *src = p.src + plane + p.J;
@@ -51,11 +51,11 @@ __global__ void k_push_init(KInitParams p)
 /* runs after k3_compact (same stream): publish the new time base and hand the push's counters to the host */
 __global__ void k3_rebase(K3Params p)
 {
-	const int s = blockIdx.x;
+	const int s = (int)blockIdx.x + p.sbase;
 	/* channels that went through the serial machine because their candidates did not fit the tables (the host then
 	 * shortens the parts it cuts pushes into): one lane per channel slot, not one load after the other */
 	unsigned novf = 0, maxc = 0;
-	if (s == 0) {
+	if (blockIdx.x == 0) {	/* (the counters of the launch's streams: the other streams' words of this table set are zero) */
 		for (int sc = (int)threadIdx.x; sc < (p.nstreams * VDL2_CS + 63) / 64 * 64; sc += 64) {
 			const bool live = sc < p.nstreams * VDL2_CS && sc % VDL2_CS < p.nbch;
 			const unsigned nc = live ? p.ctl[CTL_CAND0 + sc] : 0u;
@@ -70,7 +70,7 @@ __global__ void k3_rebase(K3Params p)
 	}
 	if (threadIdx.x != 0)
 		return;
-	if (s == 0) {
+	if (blockIdx.x == 0) {
 		p.host_cnt[0] = p.outc[2 * p.ring];
 		p.host_cnt[1] = p.outc[2 * p.ring + 1];
 		p.host_cnt[2] = p.outc[8];	/* running totals: serial redos, repairs */

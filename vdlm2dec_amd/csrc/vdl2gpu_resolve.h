@@ -149,7 +149,7 @@ void k2s_sort(K2Params p)
 	__shared__ WgSortShared ws;
 	__shared__ int s_np;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
+	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial)
 		return;
@@ -239,7 +239,7 @@ void k2s_fix(K2Params p)
 	__shared__ unsigned long long sT[VDL2_CAND_CAP];
 	__shared__ int s_np;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
+	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	if (tid == 0) {
 		s_np = 0;
@@ -300,7 +300,7 @@ void k2s_merge(K2Params p)
 	__shared__ unsigned long long knew[K2S_MERGE];
 	__shared__ K2xWork xw;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
+	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial)
 		return;
@@ -410,8 +410,9 @@ void k2b_clusters(K2Params p)
 	mach_init_taps(sh);
 	/* blockIdx.y selects a group of up to 64 (stream, channel) slots; exclusive prefix of the
 	 * group's cluster counts maps a ticket to (slot, primary candidate) */
-	const int sc0 = (int)blockIdx.y * 64;
-	const int nsc64 = (nsc - sc0) < 64 ? (nsc - sc0) : 64;
+	const int sc0 = p.sbase * VDL2_CS + (int)blockIdx.y * 64;
+	const int nsc_end = (p.sbase + p.scount) * VDL2_CS < nsc ? (p.sbase + p.scount) * VDL2_CS : nsc;	/* (the launch's streams) */
+	const int nsc64 = (nsc_end - sc0) < 64 ? (nsc_end - sc0) : 64;
 	if (tid == 0) {
 		unsigned acc = 0;
 		for (int k = 0; k < nsc64; ++k) {
@@ -583,7 +584,7 @@ void k2c_resolve(K2Params p)
 #endif
 	__builtin_amdgcn_s_setprio(K2C_PRIO);	/* one workgroup per channel beside the channeliser's thousands of waves */
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
+	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	int seg_from = -0x7fffffff;	/* repair round: stretches that end at or before the earliest event the verify pass found lie on the unchanged
 					 * part of the chain and have been verified -- only what lies behind is listed again */
@@ -996,7 +997,7 @@ void k2f_commit(K2Params p)
 	__shared__ MachSharedT<K2_NT> sh;
 	__shared__ K2xWork xw;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
+	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	ChanState *cs = p.cs + sc;
 	k2x_drain<K2_NT>(xw, p, sc);	/* the common area of the last verify pass */
@@ -1060,7 +1061,7 @@ void k2d_payload(K2Params p)
 	__shared__ unsigned s_slot;
 	__shared__ float sph[VDL2_MAXSYM];
 	__shared__ float s_tabs[72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE + 3 * 257];	/* mflt[], atanf range table, Grey1/2/3 (see burst_payload) */
-	const int sc = blockIdx.y;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of a stream */
+	const int sc = (int)blockIdx.y + p.sbase * VDL2_CS;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of the launch's streams */
 	if ((sc % VDL2_CS) >= p.nbch)
 		return;
 	/* second pass (pay_final): only the channels a repair round re-resolved behind the first pass's back; their records

@@ -945,7 +945,7 @@ __global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A
 void k2a_probe(K2Params p)
 {
 	__shared__ K2aShared sh;
-	const int c = blockIdx.y, s = blockIdx.z;
+	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	const long long dec_base = p.dec_base;
 	const long long avail_end = dec_base + VDL2_CARRY_FRAMES + p.J;
@@ -1141,7 +1141,7 @@ void k2r_regions(K2Params p)
 	__shared__ WgSortShared ws;
 	__shared__ int key[VDL2_CAND_CAP];
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = blockIdx.y;
+	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	/* the common area of the scan in front: the probe's (round 0), the previous round's verify pass's (complete round) */
 	k2x_drain<K2R_NT>(*reinterpret_cast<K2xWork *>(ws.tmp), p, sc);
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A
 void k2a_region(K2Params p)
 {
 	__shared__ K2aShared sh;
-	const int c = blockIdx.y, s = blockIdx.z;
+	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan)
 		return;
@@ -1270,7 +1270,7 @@ void k2a_verify(K2Params p)
 	__shared__ int s_list[64], s_nl, s_ni;
 	__shared__ int4 s_item[K2A_VITEMS];	/* lo, hi (stream-relative samples), sub-phase */
 	const int tid = threadIdx.x;
-	const int c = blockIdx.y, s = blockIdx.z;
+	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan || p.full_round)
 		return;

@@ -92,6 +92,8 @@ struct HeadTap {		/* diagnostics (VDL2GPU_F_DEBUG_HEADS): what one sync trigger 
 static_assert(sizeof(HeadTap) == 132 || sizeof(HeadTap) == 136, "HeadTap layout");
 
 struct K1Params {
+	int sbase;		/* first stream of the launch (grid dimension y counts from it): a push of several streams is worked off stream group by
+				 * stream group (vdl2gpu.hip, push_checked) */
 	const void *raw;
 	size_t stream_stride;
 	int fmt, nbch;
@@ -114,6 +116,7 @@ struct K1Params {
 };
 
 struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs) [per_lo, per_lo + per_n) of a push */
+	int sbase;		/* first stream of the launch */
 	const void *raw;
 	size_t stream_stride;
 	int nbch;
@@ -143,6 +146,7 @@ struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs)
 
 struct K2aItem;
 struct K2Params {
+	int sbase, scount;	/* the streams this launch is about: [sbase, sbase + scount); every grid's stream dimension counts from sbase */
 	const float2 *dec;
 	long long cap;
 	int nbch, nstreams;
@@ -236,6 +240,7 @@ enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repa
 #define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (11 + 2 * VDL2_SURV_SLOTS) * (size_t)(nsc))
 
 struct K3Params {
+	int sbase;		/* first stream of the launch */
 	const float2 *src;
 	float2 *dst;
 	long long cap;
