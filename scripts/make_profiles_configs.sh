@@ -4,7 +4,7 @@
 #   R=r04 scripts/make_profiles_configs.sh [c3 c4 busy15 busy30]      (copy gpurun_out/profiles/* to profiles/ afterwards)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${R:-r04}
+R=${R:-r05}
 OUT=gpurun_out/profiles
 mkdir -p $OUT
 here=$(pwd)
