@@ -871,6 +871,10 @@ static int create_impl(vdl2gpu_t *h)
 	/* Parts (see push_checked): at most 36 s of air time; until the first pushes have been collected and their candidate
 	 * density is known, 8.4 s -- a saturated channel (250 candidates a second) fills half of the tables in that long. */
 	h->split_unit = ((cfg.flags & VDL2GPU_F_RTL_QUIRK) || h->sdrclk != 500 || h->L != 80) ? 32768 : K1F_PER_IN;
+	/* other rates: whole periods of the dump schedule (4 * SDRCLK samples), so that a part that starts on a schedule boundary is ONE
+	 * k1_pp launch like a whole push (push_impl: whole_pp) -- unless the quirk wants whole 32768-sample blocks */
+	if (!(cfg.flags & VDL2GPU_F_RTL_QUIRK) && h->split_unit == 32768 && (4 * h->sdrclk) % h->L == 0 && ((size_t)4 * h->sdrclk * h->sample_bytes) % 16 == 0)
+		h->split_unit = (size_t)4 * h->sdrclk * ((32768 + (size_t)4 * h->sdrclk - 1) / ((size_t)4 * h->sdrclk));	/* (about the block's size) */
 	h->split_default = (size_t)(36.0 * (double)h->cfg.sdrinrate) / h->split_unit * h->split_unit;
 	{
 		/* the verify pass maps one workgroup to K2A_VRUN tiles and the item list has room for VDL2_MAXWG private areas: a part

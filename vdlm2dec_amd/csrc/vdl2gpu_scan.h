@@ -381,7 +381,7 @@ struct alignas(8) K2xWork {
  * [Round 4 ran this as a kernel of its own behind every scan, four launches of 6144 workgroups a push most of which found
  * nothing and 30 us each as they ran; a scan workgroup's own area holds a chunk or two, and the workgroup is there anyway.] */
 template <int NT, int U, class PR>
-__device__ void k2x_chunk(K2xWork &sh, PR p, int sc, int mode, int skip, unsigned w0, unsigned stride, unsigned nhere)
+__device__ __forceinline__ void k2x_chunk(K2xWork &sh, PR p, int sc, int mode, int skip, unsigned w0, unsigned stride, unsigned nhere)
 {
 	static_assert(NT >= K2X_NT && (U == 1 || U == 2), "k2x_chunk");
 	const int tid = threadIdx.x;
@@ -622,7 +622,11 @@ __device__ __forceinline__ void k2a_tail(K2aShared &sh, int sc)
 	if (threadIdx.x == 0)
 		w.tabs = 0;
 	const unsigned base = blockIdx.x * (unsigned)p.surv_pch * K2A_ITEM_WORDS;
-	for (unsigned off = 0; off < n; off += K2X_NT)
+	/* the first chunk (all there is, as a rule) in straight-line code: inside a loop the compiler hoists the chunk's invariants in
+	 * front of it and parks them in scratch -- 80 bytes per lane written and read back by every workgroup: 31 MB a scan */
+	if (n > 0)
+		k2x_chunk<K2A_THREADS, 1, K2ParamsK &>(w, p, sc, p.surv_mode, p.surv_skip, base, (unsigned)p.surv_pch, n < K2X_NT ? n : K2X_NT);
+	for (unsigned off = K2X_NT; off < n; off += K2X_NT)
 		k2x_chunk<K2A_THREADS, 1, K2ParamsK &>(w, p, sc, p.surv_mode, p.surv_skip, base + off, (unsigned)p.surv_pch, n - off < K2X_NT ? n - off : K2X_NT);
 }
 
