@@ -64,10 +64,20 @@ __device__ __forceinline__ void burst_timing(int clk0, int *j0, int *rb)
  * have no LDS to spare) each byte lane computes the four or five phases it needs itself. */
 #define VDL2_MAXSYM 5456	/* symbols 7 .. (25 + 8 * 2040 - 1) / 3 */
 /* (inlined: as a call it costs the resolver and the gather kernel 8 % -- callee-saved registers through scratch) */
-template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
-						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph = nullptr,
-						  int tag = 1, int slot = 0, const float *lds_tabs = nullptr, const uint8_t *pn8 = nullptr)
+/* TAB (K2d): sph, lds_tabs and pn8 are all there -- a compile-time fact, so that the kernel does not carry the other paths' code and
+ * their scalar-register appetite (with run-time tests the compiler loaded all of mflt[] into 65 scalar registers for the path K2d never
+ * takes and spilled 367 of them: 11 900 lines of ISA, 5 500 without) */
+template <int NT, bool TAB = false> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t *rec, const float2 *x0, const uint8_t *pn, long long nstar,
+						  int clk0, float df, int nbrow, int nlbyte, int stream, ChanCfg cfg, float *sph_ = nullptr,
+						  int tag = 1, int slot = 0, const float *lds_tabs_ = nullptr, const uint8_t *pn8_ = nullptr,
+						  const float *lds_fir = nullptr)
 {
+	/* lds_tabs: mflt[72], the atanf range table AND the three soft-bit tables in LDS (K2d); lds_fir: only the first two (the serial
+	 * machine's MachSharedT.smf / .atab are adjacent): the phases then come from k2_fir_phase_tab -- the same result bits -- and no
+	 * kernel that decodes a payload holds mflt[] in scalar registers */
+	float *const sph = sph_;
+	const float *const lds_tabs = lds_tabs_;
+	const uint8_t *const pn8 = pn8_;
 	const int tid = threadIdx.x;
 	int j0, rb;
 	burst_timing(clk0, &j0, &rb);
@@ -78,16 +88,16 @@ template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t 
 		w[i] = 0u;
 	__syncthreads();
 	const float2 *xs0 = x0 + (nsym0 - 16);
-	if (sph) {
+	if (TAB || sph) {
 		const int kmax = (25 + 8 * (g.ND + g.NF) - 1) / 3;
 		/* lds_tabs (K2d): mflt[72], the atanf range table and the three soft-bit tables in LDS -- the lanes' table look-ups are
 		 * LDS reads instead of dependent loads from constant memory, the atan2f has no branches (same result bits) */
-		if (lds_tabs)
+		if (TAB || lds_tabs)
 			for (int k = 7 + tid; k <= kmax; k += NT)
 				sph[k - 7] = k2_fir_phase_tab(xs0 + 8LL * k, rb, lds_tabs, lds_tabs + 72);
-		else
+		else if (!TAB)
 			for (int k = 7 + tid; k <= kmax; k += NT)
-				sph[k - 7] = k2_fir_phase(xs0 + 8LL * k, rb);
+				sph[k - 7] = k2_fir_phase_tab(xs0 + 8LL * k, rb, lds_fir, lds_fir + 72);
 		__syncthreads();
 	}
 	for (int b = tid; b < g.ND + g.NF; b += NT) {
@@ -95,15 +105,22 @@ template <int NT> __device__ __forceinline__ void burst_payload(vdl2gpu_burst_t 
 		const int k0 = q0 / 3;	/* >= 8: never needs P1 */
 		int q = q0;
 		unsigned byte = 0;
-		const float *grey = lds_tabs ? lds_tabs + 72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE : nullptr;
-		const unsigned pnb = pn8 ? pn8[b] : 0u;	/* the byte's eight scrambler bits in one load (pn[25 + 8b + i] << i) */
-		float pprev = sph ? sph[k0 - 8] : k2_fir_phase(xs0 + 8LL * (k0 - 1), rb);
+		const float *grey = (TAB || lds_tabs) ? lds_tabs + 72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE : nullptr;
+		const unsigned pnb = (TAB || pn8) ? pn8[b] : 0u;	/* the byte's eight scrambler bits in one load (pn[25 + 8b + i] << i) */
+		float pprev, pk;
+		if (TAB || sph)
+			pprev = sph[k0 - 8];
+		else
+			pprev = k2_fir_phase_tab(xs0 + 8LL * (k0 - 1), rb, lds_fir, lds_fir + 72);
 		for (int k = k0; q < q0 + 8; ++k) {
-			const float pk = sph ? sph[k - 7] : k2_fir_phase(xs0 + 8LL * k, rb);
+			if (TAB || sph)
+				pk = sph[k - 7];
+			else
+				pk = k2_fir_phase_tab(xs0 + 8LL * k, rb, lds_fir, lds_fir + 72);
 			const int idx = k2_grey_index(pk, pprev, df);
 			pprev = pk;
 			for (int i = q - 3 * k; i < 3 && q < q0 + 8; ++i, ++q) {
-				const float v = k2_soft_bit(idx, i, pn8 ? (int)((pnb >> (q - q0)) & 1u) : (int)pn[q], grey);
+				const float v = k2_soft_bit(idx, i, (TAB || pn8) ? (int)((pnb >> (q - q0)) & 1u) : (int)pn[q], grey);
 				if ((double)v > 0.5)
 					byte |= 1u << (q - q0);
 			}
@@ -165,6 +182,7 @@ template <int NT> struct MachSharedT {
 	float fctl[8];
 };
 
+static_assert(offsetof(MachSharedT<64>, atab) == offsetof(MachSharedT<64>, smf) + 72 * sizeof(float), "burst_payload's lds_fir: smf[72] with atab[] right behind it");
 struct MachCtx {
 	const float2 *x;	/* channel plane, frame 0 = stream time dec_base */
 	long long dec_base, avail_end;
@@ -574,7 +592,7 @@ template <int NT, bool XL> __device__ __forceinline__ long long mach_commit_trig
 		__syncthreads();
 		const unsigned slot = (unsigned)sh.ctl[6];
 		if (!XL && !cx.desc && slot != 0xffffffffu)
-			burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg);
+			burst_payload<NT>(cx.recs + slot, x0, cx.pn, nstar, clk0, df, nbrow, nlbyte, cx.stream, cx.cfg, nullptr, 1, 0, nullptr, nullptr, sh.smf);
 		if (slot == 0xffffffffu)
 			out.badslot = 1;
 		out.nslots++;

@@ -1053,7 +1053,8 @@ void k2f_commit(K2Params p)
  */
 #define K2D_NT 256
 #ifndef K2D_WAVES
-#define K2D_WAVES 2
+#define K2D_WAVES 5	/* 91 registers, no spill (round 4: 119 / four wavefronts -- with the table paths a run-time choice the kernel carried the
+			 * code and the scalar registers of the paths it never takes: burst_payload<NT, TAB>) */
 #endif
 __global__ __launch_bounds__(K2D_NT) __attribute__((amdgpu_waves_per_eu(K2D_WAVES, 8)))
 void k2d_payload(K2Params p)
@@ -1110,7 +1111,7 @@ void k2d_payload(K2Params p)
 			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.dec_base;
-			burst_payload<K2D_NT>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc, s_tabs, p.pn8);
+			burst_payload<K2D_NT, true>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc, s_tabs, p.pn8);
 		}
 		__syncthreads();
 	}
