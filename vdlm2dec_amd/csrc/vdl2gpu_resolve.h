@@ -534,14 +534,14 @@ void k2b_clusters(K2Params p)
  * search in that class's own list (ranks in time order, ascending), -1 if there is none.  (Scanning
  * the time-sorted list for the next entry of the class costs a candidate of a rare class a walk to the
  * end of the list, one LDS round trip per step.) */
-__device__ __forceinline__ int k2c_next(const int *ctime, const unsigned short *clist, const int *coff, int want, int r)
+__device__ __forceinline__ int k2c_next(const int *skey, const unsigned short *clist, const int *coff, int want, int r)
 {
 	const int cls = r * 2 + (want & 1);
 	int lo = coff[cls], hi = coff[cls + 1];
 	const int end = hi;
 	while (lo < hi) {
 		const int mid = (lo + hi) >> 1;
-		if (ctime[mid] < want)
+		if ((skey[clist[mid]] >> 2) < want)	/* (the class list holds ranks; their times are the sorted keys': four bytes a candidate less in LDS) */
 			lo = mid + 1;
 		else
 			hi = mid;
@@ -549,16 +549,18 @@ __device__ __forceinline__ int k2c_next(const int *ctime, const unsigned short *
 	return lo < end ? (int)clist[lo] : -1;
 }
 
-/* one hop of the walk in 16 bits: rank of the successor | its cluster status << 12, 0xffff = none */
+/* one hop of the walk in 16 bits: rank of the successor (13 bits) | its cluster status << 13, 0xffff = none */
+#define K2C_RANK 0x1fffu
+#define K2C_RBITS 13
 #define K2C_HOP_NONE 0xffffu
 #define K2C_VIS 4096	/* entries of the visited list; more than that (it would take ten thousand bursts in a
 			 * channel's push) fails the channel over to the serial redo */
 /* sjump[j], for a steady cluster j: bits 0-11 = the last steady cluster within four hops of j (j itself if
  * the first hop is not steady); K2C_J_CONT: all four hops were steady, go on from there; otherwise the
- * chain ends behind it (no successor) or, K2C_J_SPECIAL, at the non-steady cluster in bits 16-27 */
+ * chain ends behind it (no successor) or, K2C_J_SPECIAL, at the non-steady cluster in bits 16-28 */
 #define K2C_J_CONT 0x80000000u
-#define K2C_J_SPECIAL 0x10000000u
-static_assert(VDL2_CAND_CAP <= 4096, "a hop holds a 12-bit rank");
+#define K2C_J_SPECIAL 0x40000000u
+static_assert(VDL2_CAND_CAP <= 8191, "a hop holds a 13-bit rank");
 
 __global__ __launch_bounds__(K2_NT)
 void k2c_resolve(K2Params p)
@@ -567,16 +569,17 @@ void k2c_resolve(K2Params p)
 	__shared__ int skey[VDL2_CAND_CAP];		/* sorted keys: nrel*4 + r */
 	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
 	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
-	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status */
+	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status | sub-phase the idle search resumes in << 2 (bits 0-3 of the cluster's head) */
 	__shared__ unsigned short svis[K2C_VIS];	/* what the real chain visited: rank | 0x8000 = that cluster; rank = the steady
 							 * hops of swalk[rank] */
 	__shared__ unsigned sjump[VDL2_CAND_CAP];	/* the walk's view of swalk[]: see K2C_J_* */
-	__shared__ int2 shead[VDL2_CAND_CAP];		/* cl_pack() of every candidate's cluster, by sorted rank */
+	__shared__ int sx[VDL2_CAND_CAP];		/* where the idle search resumes behind every candidate's cluster (cl_pack().x), by sorted rank; the
+							 * rest of the head is read from device memory where it is needed (publishing: every lane its own) --
+							 * 27 bytes of LDS per candidate instead of 35: the tables hold 5120 */
 	__shared__ int s_walk[4];
 	__shared__ int s_cnt[4];
 	__shared__ unsigned short clist[VDL2_CAND_CAP];	/* ranks of the candidates, class by class, time order within */
 	__shared__ unsigned long long swalk[VDL2_CAND_CAP];	/* the next four hops from a steady cluster: what the walk reads */
-	__shared__ int ctime[VDL2_CAND_CAP];		/* times of clist[] */
 	__shared__ int coff[9];				/* where each class (r * 2 + time parity) starts in clist */
 	__shared__ int s_wcnt[K2_NT / 64][8];
 #ifndef K2C_PRIO
@@ -648,7 +651,9 @@ void k2c_resolve(K2Params p)
 			const int idx = p.sidx[(size_t)sc * VDL2_CAND_CAP + i];
 			skey[i] = p.skey[(size_t)sc * VDL2_CAND_CAP + i];
 			sidx[i] = (unsigned short)idx;
-			shead[i] = head[idx];
+			const int2 hd = head[idx];
+			sx[i] = hd.x;
+			sstat[i] = (uint8_t)(hd.y & 15);
 		}
 	}
 	__syncthreads();
@@ -704,7 +709,6 @@ void k2c_resolve(K2Params p)
 				if (cls == q)
 					at = excl[q]++;
 			clist[at] = (unsigned short)j;
-			ctime[at] = k >> 2;
 		}
 		__syncthreads();
 	}
@@ -712,12 +716,10 @@ void k2c_resolve(K2Params p)
 	/* 2. successor table.  (Interleaving several searches per thread to overlap their LDS round trips
 	 *    was slower: this kernel, with two serial machines inlined, has no registers to spare.) */
 	for (int j = tid; j < ncand; j += K2_NT) {
-		const int2 hd = shead[j];
-		const int status = hd.y & 3;
+		const int status = sstat[j] & 3;
 		int nx = -1;
 		if (status == CL_STEADY)
-			nx = k2c_next(ctime, clist, coff, hd.x, (hd.y >> 2) & 3);	/* hd.x lies behind the candidate's own time */
-		sstat[j] = (uint8_t)status;
+			nx = k2c_next(skey, clist, coff, sx[j], (sstat[j] >> 2) & 3);	/* sx[j] lies behind the candidate's own time */
 		snext[j] = (nx < 0) ? (unsigned short)K2C_NOCAND : (unsigned short)nx;
 	}
 	__syncthreads();
@@ -727,15 +729,15 @@ void k2c_resolve(K2Params p)
 		unsigned long long e = 0;
 		unsigned jv = 0;
 		int at = j;
-		bool open = (sstat[j] == CL_STEADY);
+		bool open = ((sstat[j] & 3) == CL_STEADY);
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			unsigned hop = K2C_HOP_NONE;
 			if (open) {
 				const unsigned nx = snext[at];
 				if (nx != K2C_NOCAND) {
-					const unsigned stt = sstat[nx];
-					hop = nx | (stt << 12);
+					const unsigned stt = sstat[nx] & 3u;
+					hop = nx | (stt << K2C_RBITS);
 					open = (stt == CL_STEADY);
 					if (open)
 						at = (int)nx;
@@ -744,7 +746,7 @@ void k2c_resolve(K2Params p)
 			}
 			e |= (unsigned long long)hop << (16 * i);
 			if (!open && !(jv & K2C_J_SPECIAL) && hop != K2C_HOP_NONE)
-				jv |= K2C_J_SPECIAL | ((hop & 0xfffu) << 16);
+				jv |= K2C_J_SPECIAL | ((hop & K2C_RANK) << 16);
 		}
 		swalk[j] = e;
 		sjump[j] = jv | (unsigned)at | (open ? K2C_J_CONT : 0u);
@@ -772,7 +774,7 @@ void k2c_resolve(K2Params p)
 		}
 		/* 3. history-free: walk the successor table until something special happens */
 		if (tid == 0) {
-			int cur = k2c_next(ctime, clist, coff, (int)(st.pos - cx.dec_base), st.r);
+			int cur = k2c_next(skey, clist, coff, (int)(st.pos - cx.dec_base), st.r);
 			int last = -1, why = 0;	/* why: 0 = no more candidates, 1 = special cluster at cur */
 			if (lazy && (st.r != r_probe || (int)(st.pos & 1) != par_probe)) {
 				/* the chain idles from here to the next candidate in a class the probe did not
@@ -791,7 +793,7 @@ void k2c_resolve(K2Params p)
 						atomicMin(p.fail + sc, 0);
 				}
 			}
-			if (cur >= 0 && sstat[cur] != CL_STEADY)
+			if (cur >= 0 && (sstat[cur] & 3) != CL_STEADY)
 				why = 1;
 			else if (cur >= 0) {
 				/* A lone lane chasing pointers: a wavefront on its own issues an instruction every ~5
@@ -809,11 +811,11 @@ void k2c_resolve(K2Params p)
 					++nvis;
 					if (!(v & K2C_J_CONT))
 						break;
-					last = (int)(v & 0xfffu);
+					last = (int)(v & K2C_RANK);
 				}
-				last = (int)(v & 0xfffu);
+				last = (int)(v & K2C_RANK);
 				if (v & K2C_J_SPECIAL) {
-					cur = (int)((v >> 16) & 0xfffu);
+					cur = (int)((v >> 16) & K2C_RANK);
 					why = 1;
 				} else
 					cur = -1;
@@ -828,8 +830,8 @@ void k2c_resolve(K2Params p)
 		const int cur = s_walk[0], last = s_walk[1], why = s_walk[2];
 		__syncthreads();
 		if (last >= 0) {
-			st.pos = cx.dec_base + shead[last].x;
-			st.r = (shead[last].y >> 2) & 3;
+			st.pos = cx.dec_base + sx[last];
+			st.r = (sstat[last] >> 2) & 3;
 		}
 		if (!why) {
 			/* idle to the end of the data: next evaluation is the first one past it */
@@ -841,7 +843,7 @@ void k2c_resolve(K2Params p)
 		}
 		const long long ncand_t = cx.dec_base + (skey[cur] >> 2);
 		const Cluster *cl = clusters + sidx[cur];
-		const int status = sstat[cur];
+		const int status = sstat[cur] & 3;
 		if (status == CL_DEFER_FIRST) {
 			st.pos = ncand_t;
 			out.ndefer++;
@@ -891,14 +893,14 @@ void k2c_resolve(K2Params p)
 			const unsigned ve = svis[t >> 2];
 			int j = -1;
 			if (ve & 0x8000u)
-				j = (t & 3) == 0 ? (int)(ve & 0xfffu) : -1;
+				j = (t & 3) == 0 ? (int)(ve & K2C_RANK) : -1;
 			else {
 				const unsigned hop = (unsigned)(swalk[ve] >> (16 * (t & 3))) & 0xffffu;
-				if (hop != K2C_HOP_NONE && (hop >> 12) == CL_STEADY)
-					j = (int)(hop & 0xfffu);
+				if (hop != K2C_HOP_NONE && (hop >> K2C_RBITS) == CL_STEADY)
+					j = (int)(hop & K2C_RANK);
 			}
 			if (j >= 0) {
-				const int2 hd = shead[j];
+				const int2 hd = p.clhead[(size_t)sc * VDL2_CAND_CAP + sidx[j]];	/* (from device memory: a lane each, all in flight together) */
 				const int ns = (hd.y >> 4) & 15;
 				/* K2b's descriptors sit in static slots: (candidate index) * VDL2_CL_MAXB + burst */
 				const unsigned slot0 = (unsigned)(((size_t)sc * VDL2_CAND_CAP + sidx[j]) * VDL2_CL_MAXB);
@@ -916,7 +918,7 @@ void k2c_resolve(K2Params p)
 				d += (hd.y >> 24) & 255;
 				const int r_s = (hd.y >> 2) & 3;
 				const long long n_s = cx.dec_base + hd.x;
-				if (lazy && sstat[j] == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe) &&
+				if (lazy && (sstat[j] & 3) == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe) &&
 				    ((snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2)) > seg_from) {
 					/* after this cluster the chain idles in class (r_s, parity of n_s) until
 					 * the successor's trigger (or the end of the data) */
