@@ -458,22 +458,22 @@ def test_resolver_builds_the_clusters_it_is_not_given(built, oracle, monkeypatch
 
 
 def test_candidate_tables_overflow_falls_back_to_the_serial_machine(built, oracle, monkeypatch):
-    """More than 5120 trigger candidates of one channel in one part (700 short bursts in 12 s of air time, the part
+    """More than 6144 trigger candidates of one channel in one part (950 short bursts in 15 s of air time, the part
     length pinned to the whole push through the test build's VDL2GPU_SPLIT_SAMPLES): the parallel tables are unusable
     for that push and the channel is handled by the serial machine -- slower, and still the oracle's bursts; the next,
     ordinary push goes through the tables again."""
     from vdlm2dec_amd.demod import Receiver, plan_channels
-    n = 24_000_000
-    spec = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=170.0, info_max=4)
+    n = 30_000_000
+    spec = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=200.0, info_max=4)
     raw = synth.synth_stream(spec, "cs16")
     want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
-    assert len(want) >= 660         # x 8 classes: more than the tables' 5120 candidates
+    assert len(want) >= 900         # x 8 classes: more than the tables' 6144 candidates
     monkeypatch.setenv("VDL2GPU_SPLIT_SAMPLES", str(n))
     with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=n, testhooks=True) as rx:
         got = rx.run(raw, block=n)
         st = rx.stats()
         assert _gpu_keys(got) == want
-        assert st["serial_samples"] > 500_000 and st["overflowed"] == 0     # most of the push's 1 008 000 decimated samples
+        assert st["serial_samples"] > 600_000 and st["overflowed"] == 0     # most of the push's 1 260 000 decimated samples
         s0 = st["serial_samples"]
         rx.push(raw[:4_000_000])        # 2 M samples: far below the tables' capacity
         rx.poll()
@@ -505,8 +505,8 @@ def test_a_sudden_load_overflows_once_and_the_parts_adapt(built, oracle):
     tables (serial machine for that push: exact, counted), the following ones are cut by the density it showed and go
     through the tables."""
     from vdlm2dec_amd.demod import Receiver, plan_channels
-    n = 24_000_000
-    dense = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=170.0, info_max=4)      # 683 bursts x 8 classes > 5120 candidates
+    n = 30_000_000
+    dense = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=7, bursts_per_s=200.0, info_max=4)      # 949 bursts x 8 classes > 6144 candidates
     quiet = synth.random_scenario(2_000_000, S.FO8[:1], n, seed=8, bursts_per_s=1.0, info_max=40)
     rd, rq = synth.synth_stream(dense, "cs16"), synth.synth_stream(quiet, "cs16")
     seq = [rq] * 10 + [rd] * 4          # ten quiet pushes: the density window (four parts) has forgotten the start-up parts
@@ -519,7 +519,7 @@ def test_a_sudden_load_overflows_once_and_the_parts_adapt(built, oracle):
             serial.append(rx.stats()["serial_samples"])
     assert _gpu_keys(got) == want
     assert serial[9] < 100_000                              # quiet: tables
-    assert serial[10] - serial[9] > 500_000                 # the first dense push: one part, overflow, serial machine
+    assert serial[10] - serial[9] > 600_000                 # the first dense push: one part, overflow, serial machine
     assert serial[13] - serial[12] < 100_000                # two pushes later the parts fit
 
 

@@ -1171,7 +1171,7 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 		h->err = "an earlier HIP error left the handle unusable: " + h->err;
 		return VDL2GPU_EHIP;
 	}
-	/* A push carries at most ~36 s of air time through the tables, and less on busy channels: the tables hold 5120 trigger
+	/* A push carries at most ~36 s of air time through the tables, and less on busy channels: the tables hold 6144 trigger
 	 * candidates per channel, and a channel that overflows them is handled by the serial machine for the whole part
 	 * (exact, ~15 ms for 34 s of 8 channels).  Longer pushes are cut into equal parts whose length follows the candidate
 	 * density of the pushes collected lately (harvest_ring) -- multiples of a k1_fast superperiod (8000 samples at

@@ -567,19 +567,20 @@ void k2c_resolve(K2Params p)
 {
 	__shared__ MachSharedT<K2_NT> sh;
 	__shared__ int skey[VDL2_CAND_CAP];		/* sorted keys: nrel*4 + r */
-	__shared__ unsigned short sidx[VDL2_CAND_CAP];	/* sorted rank -> candidate index */
-	__shared__ unsigned short snext[VDL2_CAND_CAP];	/* rank of the candidate that follows the cluster */
+	/* (sorted rank -> candidate index is read from device memory where it is needed -- publishing: a lane each --, and the rank of the
+	 * candidate that follows a cluster is the first hop of swalk[]: 23 bytes of LDS per candidate, the tables hold 6144) */
 	__shared__ uint8_t sstat[VDL2_CAND_CAP];	/* cluster status | sub-phase the idle search resumes in << 2 (bits 0-3 of the cluster's head) */
 	__shared__ unsigned short svis[K2C_VIS];	/* what the real chain visited: rank | 0x8000 = that cluster; rank = the steady
 							 * hops of swalk[rank] */
 	__shared__ unsigned sjump[VDL2_CAND_CAP];	/* the walk's view of swalk[]: see K2C_J_* */
 	__shared__ int sx[VDL2_CAND_CAP];		/* where the idle search resumes behind every candidate's cluster (cl_pack().x), by sorted rank; the
 							 * rest of the head is read from device memory where it is needed (publishing: every lane its own) --
-							 * 27 bytes of LDS per candidate instead of 35: the tables hold 5120 */
+							 * together with the notes at the top: 23 bytes of LDS per candidate instead of 35 */
 	__shared__ int s_walk[4];
 	__shared__ int s_cnt[4];
 	__shared__ unsigned short clist[VDL2_CAND_CAP];	/* ranks of the candidates, class by class, time order within */
 	__shared__ unsigned long long swalk[VDL2_CAND_CAP];	/* the next four hops from a steady cluster: what the walk reads */
+	unsigned short *const sw16 = reinterpret_cast<unsigned short *>(swalk);	/* (hop i of rank j: sw16[4 j + i]) */
 	__shared__ int coff[9];				/* where each class (r * 2 + time parity) starts in clist */
 	__shared__ int s_wcnt[K2_NT / 64][8];
 #ifndef K2C_PRIO
@@ -650,7 +651,6 @@ void k2c_resolve(K2Params p)
 		for (int i = tid; i < ncand; i += K2_NT) {
 			const int idx = p.sidx[(size_t)sc * VDL2_CAND_CAP + i];
 			skey[i] = p.skey[(size_t)sc * VDL2_CAND_CAP + i];
-			sidx[i] = (unsigned short)idx;
 			const int2 hd = head[idx];
 			sx[i] = hd.x;
 			sstat[i] = (uint8_t)(hd.y & 15);
@@ -720,13 +720,13 @@ void k2c_resolve(K2Params p)
 		int nx = -1;
 		if (status == CL_STEADY)
 			nx = k2c_next(skey, clist, coff, sx[j], (sstat[j] >> 2) & 3);	/* sx[j] lies behind the candidate's own time */
-		snext[j] = (nx < 0) ? (unsigned short)K2C_NOCAND : (unsigned short)nx;
+		/* the first hop: rank of the candidate that follows the cluster | that one's status (the other three: 2b) */
+		sw16[4 * j] = (nx < 0) ? (unsigned short)K2C_HOP_NONE : (unsigned short)((unsigned)nx | ((sstat[nx] & 3u) << K2C_RBITS));
 	}
 	__syncthreads();
 	/* 2b. four hops per table entry: the walk below is one lane chasing pointers through LDS, a round
 	 *     trip per read, so it reads as rarely as possible */
 	for (int j = tid; j < ncand; j += K2_NT) {
-		unsigned long long e = 0;
 		unsigned jv = 0;
 		int at = j;
 		bool open = ((sstat[j] & 3) == CL_STEADY);
@@ -734,21 +734,19 @@ void k2c_resolve(K2Params p)
 		for (int i = 0; i < 4; ++i) {
 			unsigned hop = K2C_HOP_NONE;
 			if (open) {
-				const unsigned nx = snext[at];
-				if (nx != K2C_NOCAND) {
-					const unsigned stt = sstat[nx] & 3u;
-					hop = nx | (stt << K2C_RBITS);
-					open = (stt == CL_STEADY);
+				hop = sw16[4 * at];	/* (first hops only are read here, and nobody writes them in this step) */
+				if (hop != K2C_HOP_NONE) {
+					open = ((hop >> K2C_RBITS) == CL_STEADY);
 					if (open)
-						at = (int)nx;
+						at = (int)(hop & K2C_RANK);
 				} else
 					open = false;
 			}
-			e |= (unsigned long long)hop << (16 * i);
+			if (i > 0)
+				sw16[4 * j + i] = (unsigned short)hop;
 			if (!open && !(jv & K2C_J_SPECIAL) && hop != K2C_HOP_NONE)
 				jv |= K2C_J_SPECIAL | ((hop & K2C_RANK) << 16);
 		}
-		swalk[j] = e;
 		sjump[j] = jv | (unsigned)at | (open ? K2C_J_CONT : 0u);
 	}
 	__syncthreads();
@@ -842,7 +840,7 @@ void k2c_resolve(K2Params p)
 			break;
 		}
 		const long long ncand_t = cx.dec_base + (skey[cur] >> 2);
-		const Cluster *cl = clusters + sidx[cur];
+		const Cluster *cl = clusters + p.sidx[(size_t)sc * VDL2_CAND_CAP + cur];
 		const int status = sstat[cur] & 3;
 		if (status == CL_DEFER_FIRST) {
 			st.pos = ncand_t;
@@ -900,10 +898,13 @@ void k2c_resolve(K2Params p)
 					j = (int)(hop & K2C_RANK);
 			}
 			if (j >= 0) {
-				const int2 hd = p.clhead[(size_t)sc * VDL2_CAND_CAP + sidx[j]];	/* (from device memory: a lane each, all in flight together) */
+				const unsigned gidx = p.sidx[(size_t)sc * VDL2_CAND_CAP + j];	/* (from device memory: a lane each, all in flight together) */
+				const int2 hd = p.clhead[(size_t)sc * VDL2_CAND_CAP + gidx];
+				const unsigned hop0 = sw16[4 * j];
+				const int next_t = (hop0 == K2C_HOP_NONE) ? t_end : (skey[hop0 & K2C_RANK] >> 2);	/* the successor's trigger, or the end of the data */
 				const int ns = (hd.y >> 4) & 15;
 				/* K2b's descriptors sit in static slots: (candidate index) * VDL2_CL_MAXB + burst */
-				const unsigned slot0 = (unsigned)(((size_t)sc * VDL2_CAND_CAP + sidx[j]) * VDL2_CL_MAXB);
+				const unsigned slot0 = (unsigned)(((size_t)sc * VDL2_CAND_CAP + gidx) * VDL2_CL_MAXB);
 				if (ns) {
 					const unsigned q = (unsigned)atomicAdd(&s_walk[0], ns);
 					for (int i = 0; i < ns; ++i) {
@@ -919,14 +920,14 @@ void k2c_resolve(K2Params p)
 				const int r_s = (hd.y >> 2) & 3;
 				const long long n_s = cx.dec_base + hd.x;
 				if (lazy && (sstat[j] & 3) == CL_STEADY && (r_s != r_probe || (int)(n_s & 1) != par_probe) &&
-				    ((snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2)) > seg_from) {
+				    next_t > seg_from) {
 					/* after this cluster the chain idles in class (r_s, parity of n_s) until
 					 * the successor's trigger (or the end of the data) */
 					const unsigned q = (unsigned)atomicAdd(&s_walk[1], 1);
 					if (q < VDL2_SEG_CAP) {
 						Seg g;
 						g.lo = hd.x;
-						g.hi = (snext[j] == K2C_NOCAND) ? t_end : (skey[snext[j]] >> 2);
+						g.hi = next_t;
 						g.r = r_s;
 						g.pad = 0;
 						segs[q] = g;

@@ -22,7 +22,7 @@ static_assert(VDL2_NSET >= 3 && VDL2_NSET <= 4, "d_outc[] has the per-ring count
 #define VDL2_SERIAL_BELOW 4096	/* pushes of at most this many 84 kS/s frames go to the serial machine directly */
 #define VDL2_CARRY_FRAMES 49152	/* >= longest burst (43592 frames) + history + slack */
 #define VDL2_PN_BITS (16384 + 64)
-#define VDL2_CAND_CAP 5120	/* trigger candidates per channel per push (round 5: 4096 -> 5120, what the resolver's 27 bytes of LDS per candidate allow) */
+#define VDL2_CAND_CAP 6144	/* trigger candidates per channel per push (round 5: 4096 -> 6144, what the resolver's 23 bytes of LDS per candidate allow) */
 #define VDL2_CL_MAXB 4		/* bursts per cluster before the resolver takes over */
 #define VDL2_SEL_CAP 16384	/* bursts on the real chain per channel per push */
 
