@@ -166,13 +166,24 @@ void vdl2gpu_rcv_flush(void)
 
 static void flush_at_exit(void)
 {
+	int flushed = 0;
 	if (pthread_mutex_trylock(&g_mu) == 0) {	/* (a thread caught in the middle of a hand-off keeps the lock: then nothing can be flushed safely) */
 		if (g_h) {
 			commit_slot();
 			deliver(g_h, 1);
+			flushed = 1;
 		}
 		pthread_mutex_unlock(&g_mu);
 	}
+#ifndef VDL2GPU_FRAMES
+	/* decodeVdlm2() only QUEUES a burst for the reference's block thread (vdlm2.c:189-201); main.c's own stopVdlm2() has
+	 * returned long before an atexit handler runs, so what was queued just now would die with the process: wait for the
+	 * queue once more (stopVdlm2, vdlm2.c:182-187: it polls once a second, up to five times). */
+	if (flushed)
+		stopVdlm2();
+#else
+	(void)flushed;
+#endif
 }
 
 void *rcv_thread(void *arg)

@@ -39,6 +39,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libvdl2gpu.so is built -fvisibility=hidden with an export map (csrc/vdl2gpu.map): what this header declares is what it exports */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define VDL2GPU_ABI_VERSION 6	/* 3: vdl2gpu_debug_heads, VDL2GPU_F_DEBUG_HEADS, VDL2GPU_MSGBLK_*; 4: vdl2gpu_stats_t.repairs; 5: vdl2gpu_inflight, the handle lock ("Threads");
 				 * 6: vdl2gpu_get_host_profile, vdl2gpu_debug_clheads */
@@ -338,6 +342,9 @@ int vdl2gpu_debug_heads(vdl2gpu_t *h, uint32_t *out, int max_entries);
 /* Device build of the fixed-sequence atan2f, elementwise (host arrays). */
 int vdl2gpu_debug_atan2f(vdl2gpu_t *h, const float *y, const float *x, float *out, size_t n);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

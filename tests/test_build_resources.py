@@ -76,7 +76,7 @@ def test_scan_tile_loops_touch_no_scratch(tmp_path):
     import subprocess
     import __graft_entry__ as g
     asm = tmp_path / "vdl2gpu.s"
-    flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC") and not f.startswith("-Wl,")]
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-S", "--cuda-device-only", "-w",
                            os.path.join(g.CSRC, "vdl2gpu.hip"), "-o", str(asm)])
     text = asm.read_text().splitlines()

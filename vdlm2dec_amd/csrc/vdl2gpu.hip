@@ -85,16 +85,7 @@ struct vdl2gpu {
 	float2 *d_lo = nullptr;
 	unsigned *d_k1_tickets = nullptr;	/* k1_fast's work counters */
 	std::vector<unsigned> k1_tbase;	/* [S][8] what they hold, per stream and XCD (the same for every role; the same for every stream between two calls) */
-	/* Stream groups.  A push of S > 1 streams is worked off group by group, each group a pass of its own through the pipeline
-	 * (its own table / plane set and output ring, like a part of a long push): eight streams in one pass wrote 1.4 GB of planes
-	 * between the channeliser and the scans that read them -- out of the 256 MB Infinity Cache and back from HBM --, and were
-	 * 10 % slower than eight single-stream pushes; a group is what fits (one stream of a 67 MS push: 180 MB).  Fixed for the
-	 * handle's life: a stream's carry goes to the plane set its NEXT pass will use, ngroups sets on ((3 does not divide ngroups). */
-	int ngroups = 1;		/* passes per push */
-	int grp_sbase = 0, grp_scount = 0;	/* the streams of the pass being enqueued (push_checked -> push_impl) */
-	bool grp_last = true;		/* ... it is the push's last: stream time advances behind it */
-	uint64_t tstep = 0;		/* pushes counted in stream time (every stream has seen so many) */
-	std::vector<int> last_set;	/* [S] the table / plane set of the stream's last pass (the debug calls read it) */
+	int last_set = 0;		/* the table / plane set of the last push (the debug calls read it) */
 	float2 *d_lo_ext = nullptr;	/* [S][8][8 + L + 40]: every LO table with its last 8 entries in front and its first 40 behind (k1_pp reads 8 at a time) */
 	float2 *d_dec[VDL2_NSET] = {};	/* plane sets, used in turn (push % 3): a set is written by the channeliser two pushes after its last
 							 * reader, the back stage's tail, was ENQUEUED -- with two sets the channeliser had to wait for that tail */
@@ -134,7 +125,6 @@ struct vdl2gpu {
 	int *d_skey[VDL2_NSET] = {};
 	unsigned short *d_sidx[VDL2_NSET] = {}, *d_prim[VDL2_NSET] = {};
 	int *d_seeds[VDL2_NSET] = {};
-	uint8_t *d_cinfo[VDL2_NSET] = {};	/* per sorted candidate: class, primary, first of its burst (k2s_sort -> k2s_fix) */
 	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (worked off by the scan workgroups themselves; the common area by the next kernel) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
@@ -147,8 +137,7 @@ struct vdl2gpu {
 					 * waited for them (0.472 against 0.462 ms per step at 64, same box; 32 and 16: 0.468, 0.469) */
 	int force_serial = 0;
 	int quirk = 0;		/* VDL2GPU_F_RTL_QUIRK */
-	int n_cu = 256;		/* CUs the wide kernels' streams may use (all of them minus reserve_cus) */
-	int n_cu_all = 256, reserve_cus = 0;
+	int n_cu = 256;
 	int probe_occ = 4;	/* resident k2a_probe workgroups per CU */
 	bool stage_events = true;	/* per-stage HIP events (vdl2gpu_timing_t breakdown): an event record between two kernels of the chain
 					 * costs ~3 us, so only every stage_every-th push carries them (the sums are scaled up in harvest) */
@@ -226,12 +215,7 @@ struct vdl2gpu {
 		bool no_k1_fast = false;	/* VDL2GPU_NO_K1_FAST: general channeliser only */
 		bool no_tail = false;		/* VDL2GPU_NO_TAIL: everything behind the verify pass stays on the main stream */
 		bool no_whole_pp = false;	/* VDL2GPU_NO_WHOLE_PP: 5/6/10 MS/s pushes always run their first and last period through the general channeliser (round 4) */
-		bool reach = false;		/* VDL2GPU_REACH=1: clusters only for the classes the chain can meet a burst in (K2sReach: 4.8 per burst instead
-						 * of 7.9, a second short cluster launch; measured: nothing at the headline, 2-7 % on busy channels) */
 		double table_fill = 0.90;	/* VDL2GPU_TABLE_FILL (percent): how full the busiest channel's candidate table may get before parts are shortened */
-		bool front2 = false;		/* VDL2GPU_FRONT2=1: the second half of the front stage on the copy stream (measured: 0.477 against 0.475 ms, no gain) */
-		bool pay_tail = false;		/* VDL2GPU_PAY_TAIL: the payload decode beside the verify pass on the payload (tail) stream instead of the copy stream */
-		bool k2b_front = false;		/* VDL2GPU_K2B_FRONT: the cluster kernel at the end of the front stage instead of the start of the back stage */
 		bool k1_pp = false;		/* VDL2GPU_K1_PP: k1_pp at 2 MS/s as well */
 		bool debug_counters = false;	/* VDL2GPU_DEBUG_COUNTERS: cycle counters of the demodulator kernels */
 		bool split_fixed = false;	/* (test hook) the part length was given: do not adapt it */
@@ -258,12 +242,10 @@ struct vdl2gpu {
 		int par = 0, ring = 0, slab = 0;
 		bool staged = false, serial = false, two_streams = false;
 		unsigned tiles = 0;
-		int sbase = 0, scount = 1;	/* the streams of the pass */
 		size_t pt_index = 0;	/* its PushTiming in `pending` */
 	} back;
 	hipStream_t fstream = nullptr;
 	hipEvent_t f_done[VDL2_NSET] = {};	/* FRONT of the push on that plane / table set has been enqueued up to its last kernel */
-	hipEvent_t probe_done = nullptr;	/* front stream -> copy stream: the probe and its second stage have run (VDL2GPU_FRONT2) */
 	hipEvent_t k1_ev = nullptr;	/* channeliser + carry copy of the latest push that kept to the main stream */
 	hipEvent_t f_tail = nullptr;	/* the end of the latest front stage on fstream (carry copy included) */
 	bool k1_ev_rec = false, last_two_streams = false;
@@ -618,8 +600,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 			(void)hipEventDestroy(h->f_done[r]);
 	if (h->k1_ev)
 		(void)hipEventDestroy(h->k1_ev);
-	if (h->probe_done)
-		(void)hipEventDestroy(h->probe_done);
 	if (h->f_tail)
 		(void)hipEventDestroy(h->f_tail);
 	if (h->pay_stream) {
@@ -672,7 +652,6 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_seeds[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
-		(void)hipFree(h->d_cinfo[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_items[r]);
 	(void)hipFree(h->d_dbg);
@@ -707,44 +686,13 @@ static int create_impl(vdl2gpu_t *h)
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k2a_probe, K2A_THREADS, 0) == hipSuccess && occ > 0)
 			h->probe_occ = occ;
 	}
-	/* Reserved CUs.  Every wide kernel here sizes itself to the whole GPU and holds its slots until it is through (the channeliser's
-	 * ticketed workgroups, the probe's and the cluster kernel's persistent ones), so a one-workgroup-per-channel kernel of ANOTHER
-	 * push -- the resolver wants a CU's whole LDS, the repair round's kernels follow each other -- finds no CU until one of them
-	 * ends: the repair round (12 + 50 + 40 us of kernels alone) took 315 us of every period, and the chain resolver -> verify pass ->
-	 * round -> commit -> next push's resolver was as long as the period.  The streams that carry the wide kernels (front, main,
-	 * records) are created with a CU mask that leaves `reserve_cus` CUs out (mask bit i is CU i / 8 of XCD i % 8: the lowest bits are
-	 * one CU of every XCD); the state stream is unmasked: its narrow kernels find the reserved CUs empty. */
-	h->reserve_cus = 0;
-	if (const char *e = getenv("VDL2GPU_RESERVE_CUS"))
-		h->reserve_cus = std::max(0, std::min(atoi(e), h->n_cu / 2));
-	auto wide_stream = [&](hipStream_t *st, int prio) -> hipError_t {
-		if (h->reserve_cus <= 0)
-			return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
-		std::vector<uint32_t> mask((size_t)(h->n_cu + 31) / 32, 0u);
-		for (int i = h->reserve_cus; i < h->n_cu; ++i)
-			mask[(size_t)i / 32] |= 1u << (i % 32);
-		return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
-	};
 	{
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, wide_stream(&h->stream, prio_hi));
+		HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
 	}
-	h->n_cu_all = h->n_cu;
-	h->n_cu -= h->reserve_cus;	/* (what the wide kernels' grids are sized by) */
 	const int S = h->S, L = h->L;
 	h->k1_tbase.assign((size_t)S * 8, 0u);
-	h->last_set.assign((size_t)S, 0);
-	h->grp_scount = S;
-	{
-		/* one stream per pass -- unless 3 divided the number of passes (the stream's next pass must find its carry in ANOTHER set
-		 * of the three): then the first pass takes two streams.  Opt-in (VDL2GPU_STREAM_GROUPS=1): once the scans worked their items off
-		 * themselves (round 5) eight streams in one pass ran at eight times the single-stream rate anyway (148 against 146 GS/s). */
-		const char *e = getenv("VDL2GPU_STREAM_GROUPS");
-		h->ngroups = (S > 1 && e && atoi(e) != 0) ? (S % 3 == 0 ? S - 1 : S) : 1;
-		if (h->ngroups % 3 == 0)
-			h->ngroups = 1;
-	}
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
 	h->cap = (VDL2_CARRY_FRAMES + jmax + 64 + 15) / 16 * 16;	/* planes start on 128-byte lines */
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
@@ -765,7 +713,7 @@ static int create_impl(vdl2gpu_t *h)
 	}
 	HIPCHK(h, hipMalloc(&h->d_outc, 16 * sizeof(unsigned)));
 	HIPCHK(h, hipMemsetAsync(h->d_outc, 0, 16 * sizeof(unsigned), h->stream));
-	HIPCHK(h, wide_stream(&h->copy_stream, 0));
+	HIPCHK(h, hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, 0));
 	/* (HIP multiplexes its streams onto four hardware queues: a fifth stream shares one with another, and kernels that
 	 * were meant to run side by side then run one behind the other -- this handle makes exactly main, copy, resolver, payload;
 	 * host input adds one for its copies, which may share a queue with the record read-back) */
@@ -781,12 +729,11 @@ static int create_impl(vdl2gpu_t *h)
 	{
 		int prio_lo = 0, prio_hi = 0;
 		HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		HIPCHK(h, wide_stream(&h->fstream, prio_lo));	/* the back stage (main stream, high priority) is the shorter one: it goes first */
+		HIPCHK(h, hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, prio_lo));	/* the back stage (main stream, high priority) is the shorter one: it goes first */
 	}
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipEventCreateWithFlags(&h->f_done[r], hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k1_ev, hipEventDisableTiming));
-	HIPCHK(h, hipEventCreateWithFlags(&h->probe_done, hipEventDisableTiming));
 	HIPCHK(h, hipEventCreateWithFlags(&h->f_tail, hipEventDisableTiming));
 	HIPCHK(h, hipStreamCreateWithFlags(&h->pay_stream, hipStreamNonBlocking));
 	HIPCHK(h, hipEventCreateWithFlags(&h->k2c_done, hipEventDisableTiming));
@@ -835,8 +782,6 @@ static int create_impl(vdl2gpu_t *h)
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
 	for (int r = 0; r < VDL2_NSET; ++r)
-		HIPCHK(h, hipMalloc(&h->d_cinfo[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP));
-	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
@@ -848,12 +793,8 @@ static int create_impl(vdl2gpu_t *h)
 	h->k2d_grid = std::max(1, env_int("VDL2GPU_K2D_GRID", h->k2d_grid));
 	h->knob.no_k1_fast = getenv("VDL2GPU_NO_K1_FAST") != nullptr;
 	h->hprof_on = getenv("VDL2GPU_HOST_PROF") != nullptr;
-	h->knob.k2b_front = env_int("VDL2GPU_K2B_FRONT", 0) != 0;
 	h->knob.no_tail = getenv("VDL2GPU_NO_TAIL") != nullptr;
-	h->knob.reach = env_int("VDL2GPU_REACH", 0) != 0;
 	h->knob.no_whole_pp = getenv("VDL2GPU_NO_WHOLE_PP") != nullptr;
-	h->knob.pay_tail = env_int("VDL2GPU_PAY_TAIL", 0) != 0;
-	h->knob.front2 = env_int("VDL2GPU_FRONT2", 0) != 0;
 	h->knob.table_fill = std::min(100, std::max(10, env_int("VDL2GPU_TABLE_FILL", 90))) / 100.0;
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
 	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
@@ -1179,25 +1120,7 @@ static int push_checked(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t st
 	 * (other rates; VDL2GPU_F_RTL_QUIRK needs whole blocks anyway); any cut gives the same bursts. */
 	int rc = VDL2GPU_OK;
 	const size_t lim = h ? h->split_samples : 0;
-	/* a part of the push (all of it as a rule), stream group by stream group (vdl2gpu::ngroups) */
-	auto passes = [&](const void *q, size_t n) -> int {
-		if (!h)
-			return push_impl(h, q, n, stream_stride_bytes, memkind, wait_copy);
-		const int ng = h->ngroups, S = h->S;
-		int sb = 0, r = VDL2GPU_OK;
-		for (int g = 0; g < ng && r == VDL2GPU_OK; ++g) {
-			const int cnt = (g == 0) ? S - (ng - 1) : 1;	/* one stream per pass; the first takes what is left over */
-			h->grp_sbase = sb;
-			h->grp_scount = cnt;
-			h->grp_last = g == ng - 1;
-			r = push_impl(h, q, n, stream_stride_bytes, memkind, wait_copy);
-			sb += cnt;
-		}
-		h->grp_sbase = 0;
-		h->grp_scount = S;
-		h->grp_last = true;
-		return r;
-	};
+	auto passes = [&](const void *q, size_t n) -> int { return push_impl(h, q, n, stream_stride_bytes, memkind, wait_copy); };
 	if (!h || !iq || lim == 0 || nsamples <= lim)
 		rc = passes(iq, nsamples);
 	else {
@@ -1306,7 +1229,7 @@ static int enqueue_back(vdl2gpu_t *h)
 	const int par = h->back.par, ring = h->back.ring;
 	const bool staged = h->back.staged, serial = h->back.serial;
 	const unsigned tiles = h->back.tiles;
-	const int GS = h->back.scount;	/* the streams of this pass */
+	const int GS = h->S;
 	PushTiming &pt = h->pending[h->back.pt_index];
 	const dim3 gch((unsigned)h->C, (unsigned)GS);
 	hipStream_t rs = h->stream;
@@ -1316,13 +1239,7 @@ static int enqueue_back(vdl2gpu_t *h)
 	 * balanced with it here: FRONT = channeliser + scan, BACK = clusters + resolver + verify */
 	if (staged)
 		HIPCHK(h, hipEventRecord(pt.e[2], rs));
-	if (!serial && k2.reach_on) {
-		/* the front stage made the clusters of the classes the chain was PREDICTED to meet each burst in (k2s_sort, K2sReach);
-		 * with their real exits known, the few that have become reachable without a cluster: one narrow kernel and a short
-		 * second launch of the cluster kernel (0.3 clusters per burst) */
-		hipLaunchKernelGGL(k2s_fix, gch, dim3(K2S_NT), 0, rs, k2);
-		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
-	} else if (!serial && !h->knob.k2b_front)
+	if (!serial)
 		hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, rs, k2);
 	HIPCHK(h, hipGetLastError());
 	if (staged)
@@ -1353,7 +1270,7 @@ static int enqueue_back(vdl2gpu_t *h)
 	 * workgroups and finished.  The repair rounds write a selection of their own (K2Params.sel_list2), so nothing the decode
 	 * reads changes under it; the tail waits for it only where it needs its records: in front of the second payload pass and the
 	 * export.  (VDL2GPU_PAY_TAIL=1: on the payload stream in front of the tail, round 3's arrangement.) */
-	hipStream_t ps = (h->knob.pay_tail || h->knob.front2) ? h->pay_stream : h->copy_stream;	/* (four hardware queues: the copy stream has one job) */
+	hipStream_t ps = h->copy_stream;	/* (four hardware queues: the copy stream has one job) */
 	if (spec) {
 		HIPCHK(h, hipStreamWaitEvent(ps, h->k2c_done, 0));
 		hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * GS)), dim3(K2D_NT), 0, ps, k2);
@@ -1484,7 +1401,6 @@ static int enqueue_back(vdl2gpu_t *h)
 		HIPCHK(h, hipEventRecord(pt.e[6], ts));
 	{
 		K3Params k3{};
-		k3.sbase = h->back.sbase;
 		k3.src = nullptr;	/* (the counters kernel copies nothing) */
 		k3.dst = nullptr;
 		k3.cap = h->cap;
@@ -1548,7 +1464,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	}
 	/* include/vdl2gpu.h: a device buffer must stay unchanged "until the second push after this one has been issued": that push
 	 * is this call, for the buffer of the push before last (with two output rings the wait for that push's ring implied it) */
-	const int SB = h->grp_sbase, GS = h->grp_scount;	/* the streams of this pass (push_checked) */
+	const int GS = h->S;
 	auto hnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double hp_t = hnow();	/* (always on: six clock reads a push; vdl2gpu_get_host_profile() hands the sums out, VDL2GPU_HOST_PROF prints them at destroy) */
 	auto hp = [&](int k) { const double t = hnow(); h->hprof[k] += t - hp_t; hp_t = t; };
@@ -1583,7 +1499,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		/* the channeliser of the push before last has read this buffer */
 		if (h->k1_rec[stg])
 			HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->k1_done[stg], 0));
-		for (int s = SB; s < SB + GS; ++s)	/* (the pass's streams, where all S would lie: the channeliser indexes by stream) */
+		for (int s = 0; s < GS; ++s)
 			HIPCHK(h, hipMemcpyAsync((char *)h->d_raw[stg] + (size_t)s * per,
 						 (const char *)iq + (size_t)s * stream_stride_bytes, per,
 						 hipMemcpyHostToDevice, h->in_stream));
@@ -1601,7 +1517,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	vdl2gpu_plan(h->total_in, nsamples, (unsigned)h->sdrclk, (unsigned)h->L, &k1.c0, &k1.no0, &k1.nf0, &J);
 	const int par = (int)(h->pushes % VDL2_NSET);	/* table set, plane set and output ring of this push */
 	const int pset = par;
-	k1.sbase = SB;
 	k1.raw = src;
 	k1.stream_stride = stride;
 	k1.fmt = h->cfg.fmt;
@@ -1609,7 +1524,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	k1.sdrclk = h->sdrclk;
 	k1.L = h->L;
 	k1.maxwin = h->maxwin;
-	k1.parity = (int)(h->tstep & 1);	/* the carried partial window is double-buffered in StreamState.acc: read [parity], written [parity ^ 1] */
+	k1.parity = (int)(h->pushes & 1);	/* the carried partial window is double-buffered in StreamState.acc: read [parity], written [parity ^ 1] */
 	k1.quirk = h->quirk;
 	k1.N = (long long)nsamples;
 	k1.J = J;
@@ -1627,7 +1542,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	const bool serial = h->force_serial || (J <= VDL2_SERIAL_BELOW && !h->full_scan && !noregion);
 	const bool two_streams = !serial;	/* see vdl2gpu::Back */
 	hipStream_t fs = two_streams ? h->fstream : h->stream;
-	hipStream_t fs2 = (two_streams && h->knob.front2) ? h->copy_stream : fs;	/* second half of the front stage (see below) */
 	/* stream time of frame 0 of this push's planes: the outputs completed before it, minus the carried frames in front */
 	const long long dec_base = (long long)(((unsigned __int128)h->total_in * 21u) / (unsigned)h->sdrclk) - VDL2_CARRY_FRAMES;
 
@@ -1635,7 +1549,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	int rc = get_events(h, pt);
 	if (rc)
 		return rc;
-	pt.samples = h->grp_last ? nsamples : 0;	/* (samples per stream: counted once per push, not once per pass) */
+	pt.samples = nsamples;	/* (per stream) */
 	pt.fast = false;
 	pt.staged = h->stage_events && (h->pushes % (uint64_t)h->stage_every) == 0;
 	pt.index = h->pushes;
@@ -1754,10 +1668,10 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			 * host knows where each one stands */
 			k1.tickets = h->d_k1_tickets;
 			for (int x = 0; x < 8; ++x) {
-				k1.tbase[x] = h->k1_tbase[(size_t)SB * 8 + x];	/* (every stream of the pass stands where the first does: all have seen the same pushes) */
+				k1.tbase[x] = h->k1_tbase[x];	/* (every stream stands where the first does: all have seen the same pushes) */
 				const long long n_x = (k1.per_n - x + 7) >> 3;
 				if (n_x > 0)
-					for (int sg = SB; sg < SB + GS; ++sg)
+					for (int sg = 0; sg < GS; ++sg)
 						h->k1_tbase[(size_t)sg * 8 + x] += (unsigned)((n_x + K1F_CHUNK - 1) / K1F_CHUNK);
 			}
 			const dim3 grid((unsigned)ngrp * K1F_ROLES, (unsigned)GS);
@@ -1782,7 +1696,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			kp.edge_state = whole ? 1 : 0;
 			kp.parity = k1.parity;
 			kp.J = J;
-			kp.sbase = SB;
 			kp.raw = src;
 			kp.stream_stride = stride;
 			kp.nbch = h->C;
@@ -1884,8 +1797,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		HIPCHK(h, hipEventRecord(pt.e[10], fs));
 	{
 		K2Params k2{};
-		k2.sbase = SB;
-		k2.scount = GS;
 		k2.dec = h->d_dec[pset];
 		k2.cap = h->cap;
 		k2.nbch = h->C;
@@ -1926,7 +1837,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.headtap = h->d_headtap;
 		k2.headtap_n = h->d_headtap_n;
 		k2.headtap_cap = h->headtap_cap;
-		if (h->d_headtap && SB == 0) {	/* (once per push: its first pass) */
+		if (h->d_headtap) {
 			/* VDL2GPU_F_DEBUG_HEADS: one tap buffer for the handle, so the pipeline is drained first -- the back stage and the
 			 * tail of the two pushes before would otherwise still be appending to it ("every trigger of the LAST push") */
 			HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1945,8 +1856,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.skey = h->d_skey[par];
 		k2.sidx = h->d_sidx[par];
 		k2.prim = h->d_prim[par];
-		k2.cinfo = h->d_cinfo[par];
-		k2.reach_on = (!serial && !h->full_scan && h->knob.reach) ? 1 : 0;
 		k2.seeds = h->d_seeds[par];
 		k2.items = h->d_items[par];
 		k2.drain_slot = -1;
@@ -1962,39 +1871,27 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 				per = std::min<unsigned>(per, VDL2_MAXWG);
 				/* the probe needs the carry the push before made (the first 49152 frames of this plane set); with the front
 				 * stage on two streams (below) that copy is not on this stream */
-				if (fs2 != fs && h->last_two_streams)
-					HIPCHK(h, hipStreamWaitEvent(fs, h->f_tail, 0));
 				pdrain = launch_scan(SCAN_PROBE, k2, dim3(per, (unsigned)h->C, (unsigned)GS), fs, VDL2_SURV_PROBE, h->full_scan ? 0 : (VDL2_PROBE_STRIDE == 2 ? 2 : 3), 0, (h->full_scan ? 4 : 1) * ((want + per - 1) / per));
-			}
-			/* FRONT, second half (VDL2GPU_FRONT2=1; off by default: same step time either way): regions, region scan, sort and the carry copy -- one-workgroup-
-			 * per-channel kernels and two short wide ones, 80 us of mostly idle GPU -- go to the copy stream, so that the NEXT push's
-			 * channeliser, which needs none of them (it writes its plane set from frame 49152 on, the carry copy fills what lies
-			 * below), runs beside them instead of behind them: the front stream carries channeliser + probe only. */
-			if (fs2 != fs) {
-				HIPCHK(h, hipEventRecord(h->probe_done, fs));
-				HIPCHK(h, hipStreamWaitEvent(fs2, h->probe_done, 0));
 			}
 			{
 				K2Params k2d = k2;	/* (k2r_regions works the probe's common area off first, k2s_sort the region scan's) */
 				scan_drain(k2d, pdrain);
-				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs2, k2d);
+				hipLaunchKernelGGL(k2r_regions, gch, dim3(K2R_NT), 0, fs, k2d);
 			}
-			rdrain = launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)GS), fs2, VDL2_SURV_REGION, 0, 1, 2);
+			rdrain = launch_scan(SCAN_REGION, k2, dim3(128, (unsigned)h->C, (unsigned)GS), fs, VDL2_SURV_REGION, 0, 1, 2);
 			HIPCHK(h, hipGetLastError());
 		}
 		if (!serial) {
 			K2Params k2d = k2;
 			scan_drain(k2d, rdrain);
-			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs2, k2d);
+			hipLaunchKernelGGL(k2s_sort, gch, dim3(K2S_NT), 0, fs, k2d);
 		}
-		if (!serial && (h->knob.k2b_front || k2.reach_on))
-			hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, fs2, k2);
 		if (staged)
-		HIPCHK(h, hipEventRecord(pt.e[4], fs2));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
+		HIPCHK(h, hipEventRecord(pt.e[4], fs));	/* end of the front stage's scan + sort (e[4] is free: the verify pass is timed from e[12]) */
 		HIPCHK(h, hipGetLastError());
 		/* ---- end of the FRONT stage */
 		if (two_streams)
-			HIPCHK(h, hipEventRecord(h->f_done[par], fs2));
+			HIPCHK(h, hipEventRecord(h->f_done[par], fs));
 		{
 			/* the carry for the NEXT push: the last 49152 frames of this push's planes (its own carry included if it is
 			 * shorter) go in front of where the next push's output will start, in the other plane set -- a fixed amount,
@@ -2004,24 +1901,20 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 			/* the next plane set's head was last read by the tail of the push two back (a repaired channel's payloads are
 			 * decoded late: a burst at the very start of that push lies in its head); the next push's channeliser, right
 			 * behind this copy, waits for that same tail anyway */
-			/* (with stream groups the streams' next pass is ngroups passes on, in set (par + ngroups) % 3; the last reader of
-			 * THESE streams' planes there was their pass 2 * ngroups >= 4 passes back, whose tail this pass's channeliser has
-			 * waited for: tails follow each other) */
-			if (two_streams && h->ngroups == 1 && h->k2_rec[(par + 1) % VDL2_NSET])
-				HIPCHK(h, hipStreamWaitEvent(fs2, h->k2_done[(par + 1) % VDL2_NSET], 0));
+			if (two_streams && h->k2_rec[(par + 1) % VDL2_NSET])
+				HIPCHK(h, hipStreamWaitEvent(fs, h->k2_done[(par + 1) % VDL2_NSET], 0));
 			K3Params k3{};
-			k3.sbase = SB;
 			k3.src = h->d_dec[pset];
-			k3.dst = h->d_dec[(pset + h->ngroups) % VDL2_NSET];
+			k3.dst = h->d_dec[(pset + 1) % VDL2_NSET];
 			k3.cap = h->cap;
 			k3.nbch = h->C;
 			k3.J = J;
-			hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)GS), dim3(K3_THREADS), 0, fs2, k3);
+			hipLaunchKernelGGL(k3_carry, dim3(24, (unsigned)h->C, (unsigned)GS), dim3(K3_THREADS), 0, fs, k3);
 			HIPCHK(h, hipGetLastError());
 			if (two_streams)	/* a following push that keeps to the main stream must see the carry (and with two front streams: the next probe) */
-				HIPCHK(h, hipEventRecord(h->f_tail, fs2));
+				HIPCHK(h, hipEventRecord(h->f_tail, fs));
 			else {	/* ... and a following push's front stage this push's channeliser state and carry, made on the main stream */
-				HIPCHK(h, hipEventRecord(h->k1_ev, fs2));
+				HIPCHK(h, hipEventRecord(h->k1_ev, fs));
 				h->k1_ev_rec = true;
 			}
 		}
@@ -2035,8 +1928,6 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		h->back.serial = serial;
 		h->back.two_streams = two_streams;
 		h->back.tiles = tiles;
-		h->back.sbase = SB;
-		h->back.scount = GS;
 		h->back.pt_index = h->pending.size();
 	}
 	h->pending.push_back(pt);
@@ -2055,12 +1946,8 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 	h->ring_slab[ring] = slab;
 	h->ring_push[ring] = h->pushes;
 	h->ring_samples[ring] = nsamples;
-	for (int sg = SB; sg < SB + GS; ++sg)
-		h->last_set[(size_t)sg] = par;
-	if (h->grp_last) {	/* every stream has been through: stream time advances */
-		h->total_in += nsamples;
-		h->tstep++;
-	}
+	h->last_set = par;
+	h->total_in += nsamples;
 	h->pushes++;
 	return VDL2GPU_OK;
 }
@@ -2664,7 +2551,7 @@ extern "C" int64_t vdl2gpu_debug_dec(vdl2gpu_t *h, int stream, int ch, float *ou
 		return rc;
 	StreamState ss;
 	HIPCHK(h, hipMemcpy(&ss, h->d_ss + stream, sizeof ss, hipMemcpyDeviceToHost));
-	const int par = h->last_set[(size_t)stream];
+	const int par = h->last_set;
 	const int64_t n = std::min<int64_t>(ss.last_J, max_complex);
 	if (n <= 0)
 		return 0;
@@ -2739,11 +2626,11 @@ extern "C" int vdl2gpu_debug_cands(vdl2gpu_t *h, int stream, int ch, int *out, i
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set[(size_t)stream]] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, VDL2_CAND_CAP);
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_cands[h->last_set[(size_t)stream]] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_cands[h->last_set] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -2760,11 +2647,11 @@ extern "C" int vdl2gpu_debug_clheads(vdl2gpu_t *h, int stream, int ch, int *out,
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set[(size_t)stream]] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set] + CTL_CAND0 + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, VDL2_CAND_CAP);
 	n = std::min<unsigned>(n, (unsigned)max_cands);
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_clhead[h->last_set[(size_t)stream]] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_clhead[h->last_set] + (size_t)sc * VDL2_CAND_CAP, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -2777,7 +2664,7 @@ extern "C" int vdl2gpu_debug_fail(vdl2gpu_t *h, int *out, int n)
 	if (rc)
 		return rc;
 	for (int st = 0; st < h->S; ++st)	/* (every stream from the set of its last pass) */
-		HIPCHK(h, hipMemcpy(out + (size_t)st * VDL2_CS, h->d_fail[h->last_set[(size_t)st]] + (size_t)st * VDL2_CS, VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out + (size_t)st * VDL2_CS, h->d_fail[h->last_set] + (size_t)st * VDL2_CS, VDL2_CS * sizeof(int), hipMemcpyDeviceToHost));
 	return h->S * VDL2_CS;
 }
 
@@ -2791,10 +2678,10 @@ extern "C" int vdl2gpu_debug_segs(vdl2gpu_t *h, int stream, int ch, int *out, in
 		return rc;
 	const int sc = stream * VDL2_CS + ch;
 	unsigned n = 0;
-	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set[(size_t)stream]] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&n, h->d_ctl[h->last_set] + CTL_CAND0 + 3 * (size_t)h->S * VDL2_CS + sc, sizeof n, hipMemcpyDeviceToHost));
 	n = std::min<unsigned>(n, (unsigned)std::min(max_segs, VDL2_SEG_CAP));
 	if (n)
-		HIPCHK(h, hipMemcpy(out, h->d_segs[h->last_set[(size_t)stream]] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(out, h->d_segs[h->last_set] + (size_t)sc * VDL2_SEG_CAP, (size_t)n * sizeof(Seg), hipMemcpyDeviceToHost));
 	return (int)n;
 }
 

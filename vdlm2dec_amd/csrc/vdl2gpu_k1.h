@@ -47,7 +47,7 @@ void k1_channelise(K1Params p)
 	float2 *lo_s = k1_smem;					/* [(L+maxwin)][8] */
 	float2 *xs = k1_smem + (size_t)(p.L + p.maxwin) * VDL2_CS;	/* [32*maxwin] */
 	const int tid = threadIdx.x;
-	const int s = (int)blockIdx.y + p.sbase;
+	const int s = (int)blockIdx.y;
 	const float2 *lo = p.lo + (size_t)s * VDL2_CS * p.L;
 	for (int idx = tid; idx < (p.L + p.maxwin) * VDL2_CS; idx += K1_THREADS) {
 		const int n = idx >> 3, c = idx & 7;
@@ -320,7 +320,7 @@ void k1_pp(K1PParams p)
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int s = (int)blockIdx.y + p.sbase;
+	const int s = (int)blockIdx.y;
 	const int blk = (int)(blockIdx.x / (unsigned)p.nsub), sub = (int)(blockIdx.x % (unsigned)p.nsub);
 	const int k0 = sub * p.wpt, k1 = k0 + p.wpt;		/* this task's windows of the period */
 	const int pb = blk * 64;				/* its first period, counted from per_lo */
@@ -758,7 +758,7 @@ void k1_fast(K1Params p)
 	__shared__ int s_next;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
-	const int s = (int)blockIdx.y + p.sbase;
+	const int s = (int)blockIdx.y;
 	/* A workgroup owns 16 consecutive outputs -- ONE 128-byte line of every channel plane -- of a superperiod (4
 	 * periods of the schedule: 8000 inputs, 336 outputs, 21 lines) for many superperiods: lane = (window, channel),
 	 * 16 windows x 4 channels to a wavefront, the two wavefronts share the windows' ~381 samples through LDS.  A

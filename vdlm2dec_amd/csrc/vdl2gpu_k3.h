@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(K3_THREADS)
 void k3_carry(K3Params p)
 {
-	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
+	const int c = blockIdx.y, s = (int)blockIdx.z;
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	const size_t plane = ((size_t)s * VDL2_CS + c) * p.cap;
 	const float2 *src = p.src + plane + p.J;
@@ -51,7 +51,7 @@ __global__ void k_push_init(KInitParams p)
 /* runs after k3_compact (same stream): publish the new time base and hand the push's counters to the host */
 __global__ void k3_rebase(K3Params p)
 {
-	const int s = (int)blockIdx.x + p.sbase;
+	const int s = (int)blockIdx.x;
 	/* channels that went through the serial machine because their candidates did not fit the tables (the host then
 	 * shortens the parts it cuts pushes into): one lane per channel slot, not one load after the other */
 	unsigned novf = 0, maxc = 0;

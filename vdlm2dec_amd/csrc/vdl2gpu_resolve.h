@@ -10,136 +10,6 @@
  * when it ever needs one (status CL_INVALID), so this is a cost decision, never a correctness one.
  */
 #define K2S_NT 1024
-/* ---- Which clusters are worth making: the classes a burst can be MET in.
- * A burst fires the detector in all eight classes, so its candidates are eight, and round 4 made a cluster for each: which
- * class the chain is in when it gets there is only known when the chain is resolved.  But the class a burst LEAVES the
- * detector in follows from its candidate record alone in 92 % of the cases (the timing estimate of d8psk.c:303-305 -> clk0 ->
- * sub-phase; the parity of the burst's first symbol -- length and header do not enter; the rest are re-triggers on the stale
- * phase ring behind the burst), and the eight candidates of a burst estimate the same physical timing: their exits fall into one
- * or two classes.  So the set of classes the chain can be in shrinks to one or two within a burst or two of the push's start,
- * wherever it started (scripts/dev/exit_classes.py: 2.0 clusters per burst cover every chain when the exits are known).
- *   k2s_sort  (front stage)  propagates the reachable set through the bursts with PREDICTED exits and marks as primaries only
- *             the candidates whose class is reachable: K2b makes 2.0 clusters per burst instead of 7.9;
- *   k2s_fix   (back stage, behind that K2b) propagates again, with the ACTUAL exits of the clusters that exist, and marks what
- *             has become reachable and has no cluster: K2b's second launch makes 0.3 per burst more.
- * What the real chain still meets without a cluster (1.2 % of its bursts: a cluster of the second launch that left in an
- * unpredicted class) the resolver replays itself, as it always did for candidates that were no primaries: a cost decision, never
- * a correctness one.
- * A burst = a run of candidates less than K2S_GROUP_GAP samples apart.  Its effect on the reachable set is a map T: class ->
- * set of classes (a byte per class: T[c] = exits of the burst's primary of class c, or {c} if it has none: the chain passes),
- * the set behind the burst the union of T[c] over the set in front of it. */
-#define K2S_GROUP_GAP 16
-/* HEDGE: the predictions are wrong for one cluster in thirteen, and tables made for the predicted sets alone let one wrong exit
- * cascade (the chain arrives in a class nobody expected, is replayed, leaves in a class nobody expected ...: 21 % of the bursts
- * met without a cluster).  So a burst's clusters are also made for the classes that ANY candidate of the burst before leaves
- * the detector in -- the chain may have met that burst in a class it was not expected in, but it left it the way one of its
- * candidates does.  2.2 clusters per burst in the first launch, 0.1 in the second, and in the recordings looked at no burst
- * of any chain without its cluster (scripts/dev/exit_classes.py <load> hedge). */
-struct K2sReach {			/* k2s_sort: overlays WgSortShared once the sort is through; T[] overlays the sort's keys */
-	unsigned short gid[VDL2_CAND_CAP];	/* sorted candidate -> its burst */
-	uint8_t info[VDL2_CAND_CAP];		/* sorted candidate: class | primary << 3 | first of its burst << 4 */
-	uint8_t em[VDL2_CAND_CAP];		/* in: sorted candidate -> set of classes its cluster leaves (or is predicted to leave) the detector in;
-						 * out: burst -> set of classes clusters are wanted for */
-	unsigned g2[VDL2_CAND_CAP / 2];		/* per burst, 16 bits: exits of all its primaries | classes that have a primary << 8 */
-	unsigned wsum[K2S_NT / 64];
-	unsigned ngroups;
-};
-static_assert(sizeof(K2sReach) <= sizeof(WgSortShared), "K2sReach overlays the sort's scratch");
-
-/* the class a steady cluster of this candidate leaves the detector in, from the record alone: burst_timing() of the timing
- * estimate (mach_trigger), the parity of the burst's first symbol (the idle search resumes an even number of samples behind it) */
-__device__ __forceinline__ int k2s_pred_exit(const Cand &cd)
-{
-	const float of = 4.0f * (cd.p2err - 4.0f * cd.perr + 3.0f * cd.err) / (cd.p2err - 2.0f * cd.perr + cd.err);
-	int clk0 = (int)roundf(of);
-	clk0 = clk0 < 0 ? 0 : (clk0 > 68 ? 68 : clk0);
-	int j0, rb;
-	burst_timing(clk0, &j0, &rb);
-	return (rb & 3) * 2 + ((cd.nrel + j0) & 1);
-}
-
-/* in: rs.info[], rs.em[] of the ncand sorted candidates.  out: rs.gid[], rs.em[g] = the classes burst g's clusters are wanted for.
- * T[]: VDL2_CAND_CAP eight-byte words of LDS, scratch: per burst, class c -> set of classes behind it (a byte each). */
-template <int NT> __device__ void k2s_reach_run(K2sReach &rs, unsigned long long *T, int ncand)
-{
-	const int tid = threadIdx.x;
-	constexpr int PER = VDL2_CAND_CAP / NT;
-	static_assert(VDL2_CAND_CAP % NT == 0, "k2s_reach_run");
-	/* burst index = inclusive count of first-of-burst flags - 1 */
-	{
-		unsigned loc[PER], sum = 0;
-#pragma unroll
-		for (int k = 0; k < PER; ++k) {
-			const int j = tid * PER + k;
-			sum += (j < ncand && (rs.info[j] & 16)) ? 1u : 0u;
-			loc[k] = sum;
-		}
-		unsigned incl = sum;
-		for (int d = 1; d < 64; d <<= 1) {
-			const unsigned o = __shfl_up(incl, d, 64);
-			if ((tid & 63) >= d)
-				incl += o;
-		}
-		if ((tid & 63) == 63)
-			rs.wsum[tid >> 6] = incl;
-		__syncthreads();
-		unsigned base = 0;
-		for (int w = 0; w < (tid >> 6); ++w)
-			base += rs.wsum[w];
-		base += incl - sum;
-#pragma unroll
-		for (int k = 0; k < PER; ++k) {
-			const int j = tid * PER + k;
-			if (j < ncand)
-				rs.gid[j] = (unsigned short)(base + loc[k] - 1u);
-		}
-		if (tid == NT - 1)
-			rs.ngroups = base + sum;
-	}
-	__syncthreads();
-	const int ng = (int)rs.ngroups;
-	for (int g = tid; g < ng; g += NT)
-		T[g] = 0x8040201008040201ull;	/* T[c] = {c}: the chain passes */
-	for (int g = tid; g < (ng + 1) / 2; g += NT)
-		rs.g2[g] = 0u;
-	__syncthreads();
-	for (int j = tid; j < ncand; j += NT) {
-		const unsigned inf = rs.info[j];
-		if (inf & 8) {	/* a primary: at most one per class and burst (K2S_LOOKBACK > a burst's run of candidates) */
-			const int sh8 = 8 * (int)(inf & 7);
-			const int g = rs.gid[j];
-			atomicAnd(&T[g], ~(0xffull << sh8));
-			atomicOr(&T[g], (unsigned long long)rs.em[j] << sh8);
-			atomicOr(&rs.g2[g >> 1], ((unsigned)rs.em[j] | (0x100u << (inf & 7))) << (16 * (g & 1)));
-		}
-	}
-	__syncthreads();
-	if (tid == 0) {
-		/* one lane, a dependent chain per burst: the set is a single class as a rule (one shift), else eight selects */
-		unsigned reach = 0xffu, hedge = 0u;
-		unsigned long long tn = ng > 0 ? T[0] : 0ull;
-		for (int g = 0; g < ng; ++g) {
-			const unsigned long long t = tn;
-			if (g + 1 < ng)
-				tn = T[g + 1];
-			const unsigned g2 = (rs.g2[g >> 1] >> (16 * (g & 1))) & 0xffffu;
-			rs.em[g] = (uint8_t)(reach | hedge);
-			unsigned nr;
-			if ((reach & (reach - 1u)) == 0u)
-				nr = (unsigned)(t >> (8 * (__ffs((int)reach) - 1))) & 0xffu;
-			else {
-				nr = 0u;
-#pragma unroll
-				for (int c = 0; c < 8; ++c)
-					nr |= ((reach >> c) & 1u) ? ((unsigned)(t >> (8 * c)) & 0xffu) : 0u;
-			}
-			reach = nr ? nr : 0xffu;	/* (never empty: T's bytes are not) */
-			hedge = (g2 & 0xffu) | (hedge & ~(g2 >> 8));
-		}
-	}
-	__syncthreads();
-}
-
 #define K2S_MERGE 256		/* candidates a repair round merges into the sorted table instead of sorting again */
 #define K2S_LOOKBACK 72		/* a triggered detector is busy for at least 9 symbols = 72 samples */
 __global__ __launch_bounds__(K2S_NT)
@@ -149,7 +19,7 @@ void k2s_sort(K2Params p)
 	__shared__ WgSortShared ws;
 	__shared__ int s_np;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
+	const int c = blockIdx.x, s = (int)blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial)
 		return;
@@ -173,8 +43,6 @@ void k2s_sort(K2Params p)
 	 * candidate and the samples, so the clusters of the earlier rounds stand -- only primaries that are new
 	 * (or were not primary before) go to K2b */
 	const int nold = (p.round > 0) ? (int)p.ctl[CTL_NCLUST0 + sc] : 0;
-	K2sReach &rs = *reinterpret_cast<K2sReach *>(&ws);	/* (the sort is through with its scratch; sbuf[] becomes K2sReach's T[] behind the loop below) */
-	const bool reach_on = p.reach_on && p.round == 0;
 	for (int j = tid; j < ncand; j += K2S_NT) {
 		const unsigned long long v = sbuf[j];
 		const int key = (int)(v >> 16), idx = (int)(v & 0xffffu);
@@ -195,14 +63,6 @@ void k2s_sort(K2Params p)
 		if (p.prim_drop > 0 && j % p.prim_drop == p.prim_drop - 1)
 			primary = false;
 #endif
-		if (reach_on) {
-			const bool first = j == 0 || n - (int)((sbuf[j - 1] >> 16) >> 2) >= K2S_GROUP_GAP;
-			rs.info[j] = (uint8_t)(cls | (primary ? 8 : 0) | (first ? 16 : 0));
-			rs.em[j] = primary ? (uint8_t)(1u << k2s_pred_exit(cands[idx])) : (uint8_t)0;
-			if (p.cinfo)	/* k2s_fix starts from these */
-				p.cinfo[(size_t)sc * VDL2_CAND_CAP + j] = rs.info[j];
-			continue;
-		}
 		int2 *head = p.clhead + (size_t)sc * VDL2_CAND_CAP + idx;
 		if (!primary)
 			*head = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
@@ -210,81 +70,10 @@ void k2s_sort(K2Params p)
 			prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
 	}
 	__syncthreads();
-	if (reach_on) {
-		/* clusters only for the primaries whose class the chain can be in when it meets their burst (predicted exits) */
-		k2s_reach_run<K2S_NT>(rs, sbuf, ncand);
-		for (int j = tid; j < ncand; j += K2S_NT) {
-			const unsigned inf = rs.info[j];
-			const int idx = (int)sidx[j];	/* (written by this thread above) */
-			const bool want = (inf & 8) && ((rs.em[rs.gid[j]] >> (inf & 7)) & 1u);
-			if (want)
-				prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
-			else
-				p.clhead[(size_t)sc * VDL2_CAND_CAP + idx] = cl_pack(0, CL_INVALID, 0, 0, 0, 0, 0);
-		}
-		__syncthreads();
-	}
 	if (tid == 0) {
 		p.ctl[CTL_NPRIM0 + sc] = (unsigned)s_np;
 		p.ctl[CTL_NCLUST0 + sc] = (unsigned)ncand;
 	}
-}
-
-/* Behind K2b's first launch (see K2sReach): the reachable sets again, with the exits the clusters that exist really have, and
- * the primaries that have become reachable without a cluster to K2b's second launch. */
-__global__ __launch_bounds__(K2S_NT)
-void k2s_fix(K2Params p)
-{
-	__shared__ K2sReach rs;
-	__shared__ unsigned long long sT[VDL2_CAND_CAP];
-	__shared__ int s_np;
-	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
-	const int sc = s * VDL2_CS + c;
-	if (tid == 0) {
-		s_np = 0;
-		p.ctl[CTL_NPRIM0 + sc] = 0u;	/* (whatever happens below: nothing stale for K2b) */
-	}
-	if (p.force_serial || !p.reach_on)
-		return;
-	const int ncand = (int)p.ctl[CTL_CAND0 + sc];
-	if (ncand > VDL2_CAND_CAP || p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc] != 0)
-		return;		/* tables unusable: the resolver runs serially */
-	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
-	const unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
-	const int2 *heads = p.clhead + (size_t)sc * VDL2_CAND_CAP;
-	const uint8_t *cinfo = p.cinfo + (size_t)sc * VDL2_CAND_CAP;
-	for (int j = tid; j < ncand; j += K2S_NT) {
-		const unsigned inf = cinfo[j];
-		rs.info[j] = (uint8_t)inf;
-		unsigned em = 0;
-		if (inf & 8) {
-			const int idx = sidx[j];
-			const int2 hd = heads[idx];
-			const int st = hd.y & 3;
-			if (st == CL_INVALID)
-				em = 1u << k2s_pred_exit(cands[idx]);	/* no cluster (yet): predicted */
-			else if (st == CL_STEADY)
-				em = 1u << (((hd.y >> 2) & 3) * 2 + (hd.x & 1));	/* where the idle search really resumes */
-			else
-				em = 0xffu;	/* the resolver goes on serially behind it, or the push ends inside it: anything */
-		}
-		rs.em[j] = (uint8_t)em;
-	}
-	__syncthreads();
-	k2s_reach_run<K2S_NT>(rs, sT, ncand);
-	unsigned short *prim = p.prim + (size_t)sc * VDL2_CAND_CAP;
-	for (int j = tid; j < ncand; j += K2S_NT) {
-		const unsigned inf = rs.info[j];
-		if ((inf & 8) && ((rs.em[rs.gid[j]] >> (inf & 7)) & 1u)) {
-			const int idx = sidx[j];
-			if ((heads[idx].y & 3) == CL_INVALID)
-				prim[atomicAdd(&s_np, 1)] = (unsigned short)idx;
-		}
-	}
-	__syncthreads();
-	if (tid == 0)
-		p.ctl[CTL_NPRIM0 + sc] = (unsigned)s_np;
 }
 
 /* K2s for a repair round that only re-resolves (K2Params.mini_round): the table is sorted but for the handful of candidates
@@ -300,7 +89,7 @@ void k2s_merge(K2Params p)
 	__shared__ unsigned long long knew[K2S_MERGE];
 	__shared__ K2xWork xw;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
+	const int c = blockIdx.x, s = (int)blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial)
 		return;
@@ -410,9 +199,8 @@ void k2b_clusters(K2Params p)
 	mach_init_taps(sh);
 	/* blockIdx.y selects a group of up to 64 (stream, channel) slots; exclusive prefix of the
 	 * group's cluster counts maps a ticket to (slot, primary candidate) */
-	const int sc0 = p.sbase * VDL2_CS + (int)blockIdx.y * 64;
-	const int nsc_end = (p.sbase + p.scount) * VDL2_CS < nsc ? (p.sbase + p.scount) * VDL2_CS : nsc;	/* (the launch's streams) */
-	const int nsc64 = (nsc_end - sc0) < 64 ? (nsc_end - sc0) : 64;
+	const int sc0 = (int)blockIdx.y * 64;
+	const int nsc64 = (nsc - sc0) < 64 ? (nsc - sc0) : 64;
 	if (tid == 0) {
 		unsigned acc = 0;
 		for (int k = 0; k < nsc64; ++k) {
@@ -555,7 +343,7 @@ __device__ __forceinline__ int k2c_next(const int *skey, const unsigned short *c
 #define K2C_HOP_NONE 0xffffu
 #define K2C_VIS 4096	/* entries of the visited list; more than that (it would take ten thousand bursts in a
 			 * channel's push) fails the channel over to the serial redo */
-/* sjump[j], for a steady cluster j: bits 0-11 = the last steady cluster within four hops of j (j itself if
+/* sjump[j], for a steady cluster j: bits 0-12 = the last steady cluster within four hops of j (j itself if
  * the first hop is not steady); K2C_J_CONT: all four hops were steady, go on from there; otherwise the
  * chain ends behind it (no successor) or, K2C_J_SPECIAL, at the non-steady cluster in bits 16-28 */
 #define K2C_J_CONT 0x80000000u
@@ -588,7 +376,7 @@ void k2c_resolve(K2Params p)
 #endif
 	__builtin_amdgcn_s_setprio(K2C_PRIO);	/* one workgroup per channel beside the channeliser's thousands of waves */
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
+	const int c = blockIdx.x, s = (int)blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	int seg_from = -0x7fffffff;	/* repair round: stretches that end at or before the earliest event the verify pass found lie on the unchanged
 					 * part of the chain and have been verified -- only what lies behind is listed again */
@@ -1000,7 +788,7 @@ void k2f_commit(K2Params p)
 	__shared__ MachSharedT<K2_NT> sh;
 	__shared__ K2xWork xw;
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
+	const int c = blockIdx.x, s = (int)blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	ChanState *cs = p.cs + sc;
 	k2x_drain<K2_NT>(xw, p, sc);	/* the common area of the last verify pass */
@@ -1065,7 +853,7 @@ void k2d_payload(K2Params p)
 	__shared__ unsigned s_slot;
 	__shared__ float sph[VDL2_MAXSYM];
 	__shared__ float s_tabs[72 + VDL2_ATAN_ROWS * VDL2_ATAN_STRIDE + 3 * 257];	/* mflt[], atanf range table, Grey1/2/3 (see burst_payload) */
-	const int sc = (int)blockIdx.y + p.sbase * VDL2_CS;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of the launch's streams */
+	const int sc = (int)blockIdx.y;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of every stream */
 	if ((sc % VDL2_CS) >= p.nbch)
 		return;
 	/* second pass (pay_final): only the channels a repair round re-resolved behind the first pass's back; their records

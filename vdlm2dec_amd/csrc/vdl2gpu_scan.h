@@ -603,7 +603,9 @@ static_assert(sizeof(K2xWork) <= sizeof(K2aShared), "the sparse stages' LDS over
 /* The tail reads the kernel's parameters AGAIN, from the kernarg segment, behind a point the compiler cannot move loads across:
  * as fields of the by-value `p` they are loaded at the kernel's entry and the dozen pointers and switches only the tail uses
  * would be held in scalar registers through the tile loop, which has none to spare (46-69 scalar and 23-47 vector registers
- * spilled when the tail took `p`; none this way).  K2Params is the kernels' only parameter: it lies at offset 0. */
+ * spilled when the tail took `p`; none this way).  K2Params MUST STAY the scan kernels' only explicit parameter (k2a_probe,
+ * k2a_region, k2a_verify): it is read at offset 0 of the kernarg segment, and nothing but this comment and the marker test in
+ * tests/test_build_resources.py would notice a second one in front of it. */
 typedef const __attribute__((address_space(4))) K2Params K2ParamsK;
 __device__ __forceinline__ K2ParamsK &k2_kernarg_again()
 {
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A
 void k2a_probe(K2Params p)
 {
 	__shared__ K2aShared sh;
-	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
+	const int c = blockIdx.y, s = (int)blockIdx.z;
 	const int sc = s * VDL2_CS + c;
 	const long long dec_base = p.dec_base;
 	const long long avail_end = dec_base + VDL2_CARRY_FRAMES + p.J;
@@ -1145,7 +1147,7 @@ void k2r_regions(K2Params p)
 	__shared__ WgSortShared ws;
 	__shared__ int key[VDL2_CAND_CAP];
 	const int tid = threadIdx.x;
-	const int c = blockIdx.x, s = (int)blockIdx.y + p.sbase;
+	const int c = blockIdx.x, s = (int)blockIdx.y;
 	const int sc = s * VDL2_CS + c;
 	/* the common area of the scan in front: the probe's (round 0), the previous round's verify pass's (complete round) */
 	k2x_drain<K2R_NT>(*reinterpret_cast<K2xWork *>(ws.tmp), p, sc);
@@ -1224,7 +1226,7 @@ __global__ __launch_bounds__(K2A_THREADS) __attribute__((amdgpu_waves_per_eu(K2A
 void k2a_region(K2Params p)
 {
 	__shared__ K2aShared sh;
-	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
+	const int c = blockIdx.y, s = (int)blockIdx.z;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan)
 		return;
@@ -1274,7 +1276,7 @@ void k2a_verify(K2Params p)
 	__shared__ int s_list[64], s_nl, s_ni;
 	__shared__ int4 s_item[K2A_VITEMS];	/* lo, hi (stream-relative samples), sub-phase */
 	const int tid = threadIdx.x;
-	const int c = blockIdx.y, s = (int)blockIdx.z + p.sbase;
+	const int c = blockIdx.y, s = (int)blockIdx.z;
 	const int sc = s * VDL2_CS + c;
 	if (p.force_serial || p.full_scan || p.full_round)
 		return;

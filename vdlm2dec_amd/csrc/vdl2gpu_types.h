@@ -92,8 +92,6 @@ struct HeadTap {		/* diagnostics (VDL2GPU_F_DEBUG_HEADS): what one sync trigger 
 static_assert(sizeof(HeadTap) == 132 || sizeof(HeadTap) == 136, "HeadTap layout");
 
 struct K1Params {
-	int sbase;		/* first stream of the launch (grid dimension y counts from it): a push of several streams is worked off stream group by
-				 * stream group (vdl2gpu.hip, push_checked) */
 	const void *raw;
 	size_t stream_stride;
 	int fmt, nbch;
@@ -116,7 +114,6 @@ struct K1Params {
 };
 
 struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs) [per_lo, per_lo + per_n) of a push */
-	int sbase;		/* first stream of the launch */
 	const void *raw;
 	size_t stream_stride;
 	int nbch;
@@ -146,7 +143,6 @@ struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs)
 
 struct K2aItem;
 struct K2Params {
-	int sbase, scount;	/* the streams this launch is about: [sbase, sbase + scount); every grid's stream dimension counts from sbase */
 	const float2 *dec;
 	long long cap;
 	int nbch, nstreams;
@@ -196,8 +192,6 @@ struct K2Params {
 	int *skey;		/* [S*8][CAND_CAP] candidates sorted by time: nrel*4 + r */
 	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
-	uint8_t *cinfo;		/* [S*8][CAND_CAP] by sorted rank: class | primary << 3 | first of its burst << 4 (k2s_sort -> k2s_fix, see K2sReach) */
-	int reach_on;		/* clusters only for the candidates whose class the chain can be in (K2sReach); 0: for every primary (round 4) */
 	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
 	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen: a private area per scan workgroup (worked off by that workgroup behind
 				 * its last tile), a common area behind them (worked off by the next kernel on the stream) */
@@ -240,7 +234,6 @@ enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repa
 #define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (11 + 2 * VDL2_SURV_SLOTS) * (size_t)(nsc))
 
 struct K3Params {
-	int sbase;		/* first stream of the launch */
 	const float2 *src;
 	float2 *dst;
 	long long cap;

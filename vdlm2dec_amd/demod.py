@@ -243,7 +243,7 @@ class Receiver:
                                                 out.ctypes.data_as(C.c_void_p), y.size))
         return out
 
-    def debug_cands(self, stream: int, ch: int, max_cands: int = 4096) -> np.ndarray:
+    def debug_cands(self, stream: int, ch: int, max_cands: int = 6144) -> np.ndarray:
         buf = np.zeros((max_cands, 6), np.int32)
         n = self._check(self.L.vdl2gpu_debug_cands(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
         return buf[:n].copy()
@@ -256,7 +256,7 @@ class Receiver:
         v = list(buf)
         return {"wait_input": v[0], "enqueue": v[1] + v[3] + v[5], "wait_for_ring": v[2], "spill": v[4], "event_wait": v[6], "pushes": int(v[7])}
 
-    def debug_clheads(self, stream: int, ch: int, max_cands: int = 4096) -> np.ndarray:
+    def debug_clheads(self, stream: int, ch: int, max_cands: int = 6144) -> np.ndarray:
         """(n_s_rel, packed) per candidate of the last push, in debug_cands()'s order: where and how the idle search resumes."""
         buf = np.zeros((max_cands, 2), np.int32)
         n = self._check(self.L.vdl2gpu_debug_clheads(self.h, stream, ch, buf.ctypes.data_as(C.c_void_p), max_cands))
