@@ -18,7 +18,7 @@ for i in range(1, len(ks) + 1):
 sel = ks[best[0] + 3:best[1] - 3]
 print("pushes", sel[0], "..", sel[-1], "period (K1 start to K1 start) us:", [round(rows[b][0] - rows[a][0]) for a, b in zip(sel, sel[1:])][:24])
 names = [(0, "K1 begins"), (1, "K1 ends"), (10, "scan begins"), (4, "front ends"), (2, "clusters begin"), (13, "clusters end"), (23, "resolver begins"), (14, "resolver ends"),
-         (12, "verify begins"), (15, "verify ends"), (16, "tail begins"), (17, "merge ends"), (18, "resolver2 ends"), (5, "rounds end"), (20, "commit ends"),
+         (12, "verify begins"), (15, "verify ends"), (16, "tail begins"), (17, "merge ends"), (18, "patch ends"), (5, "rounds end"), (20, "commit ends"),
          (21, "payload2 ends"), (22, "export ends"), (6, "commit..export end"), (7, "tail ends")]
 for p in sel[4:10]:
     r = rows[p]

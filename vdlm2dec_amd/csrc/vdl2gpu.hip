@@ -125,6 +125,9 @@ struct vdl2gpu {
 	int *d_skey[VDL2_NSET] = {};
 	unsigned short *d_sidx[VDL2_NSET] = {}, *d_prim[VDL2_NSET] = {};
 	int *d_seeds[VDL2_NSET] = {};
+	uint8_t *d_onchain[VDL2_NSET] = {};	/* K2Params.onchain, .slog, .win: what a local repair stands on and what it leaves (k2p_patch) */
+	K2Slog *d_slog[VDL2_NSET] = {};
+	int2 *d_win[VDL2_NSET] = {};
 	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (worked off by the scan workgroups themselves; the common area by the next kernel) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
@@ -649,9 +652,12 @@ extern "C" void vdl2gpu_destroy(vdl2gpu_t *h)
 		(void)hipFree(h->d_sidx[r]);
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_prim[r]);
-	for (int r = 0; r < VDL2_NSET; ++r)
+	for (int r = 0; r < VDL2_NSET; ++r) {
 		(void)hipFree(h->d_seeds[r]);
-	for (int r = 0; r < VDL2_NSET; ++r)
+		(void)hipFree(h->d_onchain[r]);
+		(void)hipFree(h->d_slog[r]);
+		(void)hipFree(h->d_win[r]);
+	}
 	for (int r = 0; r < VDL2_NSET; ++r)
 		(void)hipFree(h->d_items[r]);
 	(void)hipFree(h->d_dbg);
@@ -781,6 +787,11 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_prim[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(unsigned short)));
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_seeds[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP * sizeof(int)));
+	for (int r = 0; r < VDL2_NSET; ++r) {
+		HIPCHK(h, hipMalloc(&h->d_onchain[r], (size_t)S * VDL2_CS * VDL2_CAND_CAP));
+		HIPCHK(h, hipMalloc(&h->d_slog[r], (size_t)S * VDL2_CS * VDL2_SLOG_CAP * sizeof(K2Slog)));
+		HIPCHK(h, hipMalloc(&h->d_win[r], (size_t)S * VDL2_CS * VDL2_WIN_CAP * sizeof(int2)));
+	}
 	for (int r = 0; r < VDL2_NSET; ++r)
 		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
 	/* every environment knob is read here, once */
@@ -1336,15 +1347,21 @@ static int enqueue_back(vdl2gpu_t *h)
 				hipLaunchKernelGGL(k2b_clusters, dim3((unsigned)(h->n_cu * 4 * K2B_GRIDW), (unsigned)((GS * VDL2_CS + 63) / 64)), dim3(K2B_NT), 0, ts, k2r);
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
 				vdrain = ScanDrain();	/* (nothing is verified behind a complete round) */
+			} else if (rr == 1) {
+				/* the first round repairs locally: from each event the verify pass listed to where the new chain rejoins the old one
+				 * (k2p_patch: one narrow kernel, tables read where they lie), and the verify pass looks at what changed */
+				scan_drain(k2r, vdrain);
+				hipLaunchKernelGGL(k2p_patch, gch, dim3(K2P_NT), 0, ts, k2r);
+				if (staged && h->stage_dump)
+					HIPCHK(h, hipEventRecord(pt.e[18], ts));
+				scan_drain(k2r, ScanDrain());
+				vdrain = launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
 			} else {
+				/* a further round resolves the channels that still fail again from their input state, with everything listed so far */
 				scan_drain(k2r, vdrain);
 				hipLaunchKernelGGL(k2s_merge, gch, dim3(K2M_NT), 0, ts, k2r);
-				if (staged && h->stage_dump && rr == 1)
-					HIPCHK(h, hipEventRecord(pt.e[17], ts));
 				scan_drain(k2r, ScanDrain());
 				hipLaunchKernelGGL(k2c_resolve, gch, dim3(K2_NT), 0, ts, k2r);
-				if (staged && h->stage_dump && rr == 1)
-					HIPCHK(h, hipEventRecord(pt.e[18], ts));
 				vdrain = launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
 			}
 		}
@@ -1365,9 +1382,8 @@ static int enqueue_back(vdl2gpu_t *h)
 	if (h->ring_spec[ring]) {
 		if (ts != ps)
 			HIPCHK(h, hipStreamWaitEvent(ts, h->pay_done, 0));	/* the export needs the first pass's records, K3 publishes the record count */
-		if (h->repair_rounds > 0 && !h->full_scan && !serial) {
-			K2Params k2p = k2;	/* what the repair rounds re-resolved is decoded now; nothing to do as a rule */
-			k2p.pay_final = 1;
+		if (!h->full_scan && !serial) {
+			K2Params k2p = k2;	/* what the repair rounds (or K2f's serial redo) made void of the first selection is tagged now, what they selected is decoded */
 			k2p.sel_mode = 1;
 			hipLaunchKernelGGL(k2d_payload, dim3((unsigned)h->k2d_grid, (unsigned)(VDL2_CS * GS)), dim3(K2D_NT), 0, ts, k2p);
 		}
@@ -1857,6 +1873,9 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.sidx = h->d_sidx[par];
 		k2.prim = h->d_prim[par];
 		k2.seeds = h->d_seeds[par];
+		k2.onchain = h->d_onchain[par];
+		k2.slog = h->d_slog[par];
+		k2.win = h->d_win[par];
 		k2.items = h->d_items[par];
 		k2.drain_slot = -1;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
@@ -2105,17 +2124,12 @@ static int harvest_ring(vdl2gpu_t *h, int ring, bool blocking)
 			const vdl2gpu_burst_t *pin = reinterpret_cast<const vdl2gpu_burst_t *>(h->h_pin);
 			h->ready.insert(h->ready.end(), pin, pin + m);
 		}
-		/* K2d ran ahead of the verify pass: for a channel that K2f then redid serially, its records
-		 * (trig_sample == 0 on the device) are void; K2f's own (== 1) are the channel's bursts */
-		const unsigned *mask = h->h_pin_cnt + 32 * ring + 8;
-		bool any = false;
-		if (h->ring_spec[ring])
-			for (int i = 0; i < 16; ++i)
-				any = any || mask[i] != 0;
+		/* K2d ran ahead of the verify pass: what a repair round (or K2f's serial redo) made void of the first selection
+		 * K2d's second pass has tagged (trig_sample == 2 on the device); everything else is a burst of the chain */
+		const bool any = h->ring_spec[ring];
 		const size_t iold = h->ready_idx.size();
 		auto take = [&](vdl2gpu_burst_t &b, uint64_t handle) {
-			const unsigned sc = (unsigned)b.end_sample;
-			if (any && b.trig_sample == 0 && sc < 512 && (mask[sc >> 5] >> (sc & 31) & 1u))
+			if (any && b.trig_sample == 2)
 				return;
 			b.trig_sample = dec_to_sample(b.trig_dec, (unsigned)h->sdrclk);
 			b.end_sample = dec_to_sample(b.end_dec, (unsigned)h->sdrclk);

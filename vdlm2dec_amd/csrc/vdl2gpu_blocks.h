@@ -46,7 +46,7 @@ struct K4Params {
 					 * device-scope counter for space at the same moment cost more than the whole block
 					 * path; longer and further frames go to the arena behind rec_cap slots, entries
 					 * rounded up to 8 bytes, space taken from nframes[2] */
-	const unsigned *fmask;		/* channels redone serially (bit s*C+c): records tagged 0 of those are void, or nullptr */
+	const unsigned *fmask;		/* not nullptr: the records come from the pipeline, where K2d's second pass tags the void ones 2 (trig_sample) */
 	unsigned long long *dbg;	/* diagnostics: stage cycle counters, or nullptr */
 	const unsigned *tabs;		/* K4_TABW words from k4_tables: gexp[512], glog[256], crc_tab[256] */
 };
@@ -337,11 +337,8 @@ void k4_frames(K4Params p)
 		vdl2gpu_frame_t *const myslot = p.compact ? reinterpret_cast<vdl2gpu_frame_t *>(reinterpret_cast<char *>(p.frames) + (size_t)ib * K4_SLOT) : nullptr;
 		if (myslot && lane == 0)
 			myslot->len = 0;
-		{
-			const unsigned sc = (unsigned)rec->end_sample;	/* device-side: the channel's index */
-			if (rec->trig_sample == 0 && sc < 512u && ((sh.fm[sc >> 5] >> (sc & 31u)) & 1u))
-				continue;
-		}
+		if (p.fmask && rec->trig_sample == 2)	/* (device-side tag) a burst of the first selection that a repair round made void: K2d's second pass says so */
+			continue;
 		if (nbrow < 1 || nbrow > VDL2GPU_MAXROWS || nlbyte < 0 || nlbyte > 249)
 			continue;
 		/* ---- rows to LDS */

@@ -394,8 +394,9 @@ void k2c_resolve(K2Params p)
 			p.fail[sc] = 0x7f7f7f7f;	/* the repair pass is verified afresh */
 			p.ctl[CTL_NSEL1 + sc] = 0;	/* (the repair rounds' own selection: see CTL_NSEL1) */
 			p.ctl[CTL_NSEG0 + sc] = 0;
-			/* if K2d ran ahead on the first pass's selection, what it made of this channel is void (the host and K4
-			 * drop the records tagged 0 of masked channels); K2d decodes the repaired selection in its second pass */
+			p.ctl[CTL_NWIN0 + sc] = VDL2_WIN_ALL;	/* resolved again from the input state: nothing of the first selection stands */
+			/* if K2d ran ahead on the first pass's selection, what it made of this channel is void (K2d's second pass tags
+			 * those records 2: the host and K4 drop them) and K2d decodes the repaired selection in that second pass */
 			if (p.fmask && sc < 512)
 				atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
 		}
@@ -431,6 +432,15 @@ void k2c_resolve(K2Params p)
 	if (!tables_ok)
 		ncand = 0;
 	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
+	/* What a local repair (k2p_patch) needs of this pass: which candidates the chain met in the history-free state (a repaired
+	 * stretch that arrives at one of them has rejoined this chain), and what the serial stretches counted (no cluster head has it). */
+	uint8_t *const onchain = p.onchain + (size_t)sc * VDL2_CAND_CAP;
+	K2Slog *const slog = p.slog + (size_t)sc * VDL2_SLOG_CAP;
+	int nslog = 0;
+	const bool first_pass = p.round == 0;
+	if (first_pass)
+		for (int i = tid; i < (ncand + 3) / 4; i += K2_NT)
+			reinterpret_cast<uint32_t *>(onchain)[i] = 0u;
 	/* 1. candidates sorted by time (K2s) */
 	const long long pos_in = st.pos;
 	const long long tk0 = wall_clock64();
@@ -550,9 +560,21 @@ void k2c_resolve(K2Params p)
 			 * history-free again behind at least one more trigger than the push has counted so far (a plain 1
 			 * returned at once, without progress, when an earlier trigger had been counted). */
 			const long long p0 = st.pos;
+			const int c_trig = out.ntrig, c_rej = out.nrej, c_burst = out.nburst;
 			const int rc = machine_run<K2_NT, false>(sh, cx, st, tables_ok, replay ? out.ntrig + 1 : 0, 1 << 30, replay ? 1 : 0, out);
 			if (!replay)
 				n_slow += (unsigned long long)(st.pos - p0);
+			if (first_pass && tables_ok && (out.ntrig != c_trig || out.nrej != c_rej || out.nburst != c_burst)) {
+				if (tid == 0 && nslog < VDL2_SLOG_CAP) {
+					K2Slog g;
+					g.t = (int)(p0 - cx.dec_base);
+					g.ntrig = out.ntrig - c_trig;
+					g.nrej = out.nrej - c_rej;
+					g.nburst = out.nburst - c_burst;
+					slog[nslog] = g;
+				}
+				++nslog;
+			}
 			replay = false;
 			if (rc != MR_STEADY)
 				break;
@@ -630,6 +652,8 @@ void k2c_resolve(K2Params p)
 		const long long ncand_t = cx.dec_base + (skey[cur] >> 2);
 		const Cluster *cl = clusters + p.sidx[(size_t)sc * VDL2_CAND_CAP + cur];
 		const int status = sstat[cur] & 3;
+		if (first_pass && tid == 0)	/* (the chain met this candidate history-free too: whatever its cluster is, what follows is determined) */
+			onchain[p.sidx[(size_t)sc * VDL2_CAND_CAP + cur]] = 1;
 		if (status == CL_DEFER_FIRST) {
 			st.pos = ncand_t;
 			out.ndefer++;
@@ -688,6 +712,8 @@ void k2c_resolve(K2Params p)
 			if (j >= 0) {
 				const unsigned gidx = p.sidx[(size_t)sc * VDL2_CAND_CAP + j];	/* (from device memory: a lane each, all in flight together) */
 				const int2 hd = p.clhead[(size_t)sc * VDL2_CAND_CAP + gidx];
+				if (first_pass)
+					onchain[gidx] = 1;
 				const unsigned hop0 = sw16[4 * j];
 				const int next_t = (hop0 == K2C_HOP_NONE) ? t_end : (skey[hop0 & K2C_RANK] >> 2);	/* the successor's trigger, or the end of the data */
 				const int ns = (hd.y >> 4) & 15;
@@ -745,6 +771,8 @@ void k2c_resolve(K2Params p)
 		 * selection's records are reserved by K2f, when it is final. */
 		if (s_walk[0] > 0 && p.sel_reserved && p.round == 0)
 			p.ctl[CTL_SELBASE0 + sc] = atomicAdd(p.outc, (unsigned)s_walk[0]);
+		if (first_pass)
+			p.ctl[CTL_NSLOG0 + sc] = (unsigned)(tables_ok ? nslog : VDL2_SLOG_CAP + 1);	/* (no tables: nothing a local repair could stand on) */
 	}
 	__syncthreads();
 	if (steady_end) {
@@ -772,6 +800,388 @@ void k2c_resolve(K2Params p)
 			atomicAdd(p.dbg + 27, (unsigned long long)ncand);
 			atomicAdd(p.dbg + 28, (unsigned long long)s_walk[3]);	/* visited-list entries */
 			atomicAdd(p.dbg + 29, n_slow);
+		}
+	}
+}
+
+/* ====================================================================== K2p
+ * Local repair (the first repair round).  The verify pass found detector events the tables lacked -- a noise trigger that exists
+ * in one timing class only, once per hundred channel-seconds of ordinary traffic: most pushes have one somewhere -- and listed them
+ * as candidates without clusters.  Until round 5 the round re-resolved the failing channel from the START of the push (k2s_merge,
+ * k2c_resolve with a CU's whole LDS, a verify pass over everything behind the event, every payload decoded again: 0.3 ms on the
+ * tail of every push, and the chain resolver -> verify -> round -> commit -> next push's resolver was the period).  But the chain
+ * is a deterministic function of where the detector stands: the event lies in a stretch the old chain IDLED through history-free
+ * (that is what the verify pass scans), so up to the event the old chain stands; from the event on the new chain is followed --
+ * the event replayed by the serial machine, then cluster by cluster through the tables -- until it arrives, history-free, at a
+ * candidate the OLD chain also met history-free (K2Params.onchain): from there on the two are the same chain again.  A burst or
+ * two as a rule (the class a burst leaves the detector in depends on the burst, hardly on the class it was met in).
+ *   What changes is confined to the WINDOW [event, rejoin): the old chain's bursts triggered inside it are void (CTL_NWIN0 /
+ *   K2Params.win: K2d's second pass tags their records), the new chain's bursts there are the repair's selection (sel_list2), the
+ *   stretches the new chain idles through inside it are what the round's verify pass scans, the counters move by the difference.
+ *   A new chain that does not rejoin before the data end leaves the channel state itself (the window runs to the end).
+ * One workgroup per channel, tables read from device memory where they lie (a hop is three or four dependent reads; the windows
+ * are a few hops): 8 KB of LDS where the resolver wants 157 -- a workgroup that wants a CU's whole LDS waits for a wide kernel
+ * of another push to END.  What this kernel cannot do locally -- tables unusable, more new candidates than K2S_MERGE, more windows
+ * than VDL2_WIN_CAP, a first pass with more serial stretches than its log holds -- it leaves failed: a further round resolves the
+ * channel from its input state as before (k2s_merge + k2c_resolve), or K2f redoes it serially.
+ * Match: d8psk.c:292-313 (what a trigger changes), 97-107 (a rejected header), 317-319 (the sub-phase sticks). */
+#define K2P_NT K2_NT
+struct K2pShared {
+	MachSharedT<K2P_NT> m;
+	unsigned long long knew[K2S_MERGE];	/* the new candidates by time: (nrel * 4 + r) << 16 | index */
+	int2 win[VDL2_WIN_CAP];
+	union {
+		K2xWork xw;			/* (while the verify pass's common area is drained) */
+		int red[3][K2P_NT / 64];
+	} u;
+};
+
+/* first rank of the sorted table whose key is >= key (wave-parallel 64-ary search: three rounds for 6144 entries) */
+__device__ __forceinline__ int k2p_lower_bound(const int *skey, int n, int key)
+{
+	const int lane = threadIdx.x & 63;
+	int lo = 0, hi = n;
+	while (hi > lo) {
+		const int step = (hi - lo + 63) / 64;
+		const int j = lo + lane * step;
+		const bool ge = j >= hi || skey[j] >= key;
+		const unsigned long long m = __ballot(ge);
+		const int f = m ? __builtin_ctzll(m) : 64;
+		if (f == 0) {
+			hi = lo;
+			break;
+		}
+		const int nhi = lo + f * step < hi ? lo + f * step : hi;
+		lo = lo + (f - 1) * step + 1;
+		hi = nhi;
+	}
+	return lo;
+}
+
+/* first rank >= from of the sorted table with time >= want in class cls (sub-phase * 2 + parity of the time); n if none */
+__device__ __forceinline__ int k2p_next_old(const int *skey, int from, int n, int want, int cls)
+{
+	const int lane = threadIdx.x & 63;
+	for (int b = from; b < n; b += 64) {
+		const int j = b + lane;
+		const int k = j < n ? skey[j] : 0;
+		const int t = k >> 2;
+		const bool hit = j < n && t >= want && ((k & 3) * 2 + (t & 1)) == cls;
+		const unsigned long long m = __ballot(hit);
+		if (m)
+			return b + __builtin_ctzll(m);
+	}
+	return n;
+}
+
+/* the same among the new candidates (LDS, sorted by time) */
+__device__ __forceinline__ int k2p_next_new(const unsigned long long *knew, int n, int want, int cls)
+{
+	const int lane = threadIdx.x & 63;
+	for (int b = 0; b < n; b += 64) {
+		const int j = b + lane;
+		const int k = j < n ? (int)(knew[j] >> 16) : 0;
+		const int t = k >> 2;
+		const bool hit = j < n && t >= want && ((k & 3) * 2 + (t & 1)) == cls;
+		const unsigned long long m = __ballot(hit);
+		if (m)
+			return b + __builtin_ctzll(m);
+	}
+	return n;
+}
+
+__global__ __launch_bounds__(K2P_NT)
+void k2p_patch(K2Params p)
+{
+	__shared__ K2pShared ps;
+	MachSharedT<K2P_NT> &sh = ps.m;
+	const int tid = threadIdx.x;
+	const int c = blockIdx.x, s = (int)blockIdx.y;
+	const int sc = s * VDL2_CS + c;
+	if (p.force_serial)
+		return;
+	k2x_drain<K2P_NT>(ps.u.xw, p, sc);	/* the common area of the verify pass in front: what it finds there fails the channel like any other hit */
+	const int fail_in = p.fail[sc];
+	if (fail_in >= VDL2_VERIFIED)
+		return;		/* verified in the first pass: nothing to repair */
+	__syncthreads();
+	const int ncand = (int)p.ctl[CTL_CAND0 + sc];
+	const unsigned ovf_in = p.ctl[CTL_CAND0 + p.nstreams * VDL2_CS + sc];
+	const int nold = (int)p.ctl[CTL_NCLUST0 + sc], nnew = ncand - nold;
+	const unsigned nslog_in = p.ctl[CTL_NSLOG0 + sc];
+	if (tid == 0) {
+		p.redo[sc] = 1;
+		atomicAdd(p.outc_total_redo + 1, 1u);	/* channel-pushes that went through a repair round */
+		if (p.dbg)
+			atomicAdd(p.dbg + 24, 1ull);
+		p.ctl[CTL_NSEL1 + sc] = 0;
+		p.ctl[CTL_NSEG0 + sc] = 0;
+		p.ctl[CTL_NWIN0 + sc] = 0;
+		if (p.fmask && sc < 512)
+			atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
+	}
+	/* what cannot be repaired locally stays failed (fail[] keeps its value): the next round, or K2f, takes the channel from its input state */
+	if (ncand > VDL2_CAND_CAP || ovf_in != 0 || nnew <= 0 || nnew > K2S_MERGE || nslog_in > VDL2_SLOG_CAP)
+		return;
+	__syncthreads();
+	if (tid == 0)
+		p.fail[sc] = 0x7f7f7f7f;	/* the repair is verified afresh */
+	const ChanState *cs = p.cs + sc;	/* input state: left untouched until K2f commits */
+	ChanState *cs_out = p.cs_out + sc;	/* the first pass's result: what this kernel amends */
+	const Cand *cands = p.cands + (size_t)sc * VDL2_CAND_CAP;
+	const int *skey = p.skey + (size_t)sc * VDL2_CAND_CAP;
+	const unsigned short *sidx = p.sidx + (size_t)sc * VDL2_CAND_CAP;
+	const int2 *heads = p.clhead + (size_t)sc * VDL2_CAND_CAP;
+	const uint8_t *onchain = p.onchain + (size_t)sc * VDL2_CAND_CAP;
+	const Cluster *clusters = p.clusters + (size_t)sc * VDL2_CAND_CAP;
+	unsigned *sel = p.sel_list2 + (size_t)sc * VDL2_SEL_CAP;
+	unsigned *nsel = p.ctl + CTL_NSEL1 + sc;
+	Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
+	/* the new candidates by time: every one finds its rank by counting (there are a handful) */
+	for (int i = tid; i < nnew; i += K2P_NT) {
+		const unsigned long long v = (((unsigned long long)(unsigned)(cands[nold + i].nrel * 4 + cands[nold + i].r)) << 16) | (unsigned)(nold + i);
+		int at = 0;
+		for (int j = 0; j < nnew; ++j) {
+			const unsigned long long w = (((unsigned long long)(unsigned)(cands[nold + j].nrel * 4 + cands[nold + j].r)) << 16) | (unsigned)(nold + j);
+			at += (w < v) ? 1 : 0;
+		}
+		ps.knew[at] = v;
+	}
+	MachCtx cx;
+	mach_ctx(cx, p, s, c, true);	/* bursts of serial stretches become descriptors */
+	cx.sel = sel;
+	cx.nsel = nsel;
+	cx.dbg = nullptr;
+	const int r_probe = p.probe_r, par_probe = p.probe_par;
+	const int t_end = (int)(cx.avail_end - cx.dec_base);
+	mach_init_taps(sh);	/* (barriers inside: knew[] is in place behind it) */
+	MachOut out;
+	out.nslots = out.ntrig = out.nrej = out.nburst = out.ndefer = 0;
+	out.badslot = 0;
+	out.neval = 0;
+	MachState st;
+	st.pos = 0;
+	st.r = 0;
+	st.fresh = VDL2_STEADY;
+	int add_trig = 0, add_rej = 0, add_burst = 0;	/* what the table clusters on the new chain count */
+	int add_defer = 0;
+	int nwin = 0, nsegs = 0;
+	int rk = 0;		/* a rank of the sorted table at or below the first entry at the current time */
+	int ev = 0;		/* next new candidate to look at */
+	int t_cur = -0x7fffffff;	/* events before this lie inside a window already handled */
+	bool to_end = false, steady_end = false, failed = false;
+	/* mode of the one serial-machine call site below (two sites and the compiler makes it a function: see k2c_resolve) */
+	enum { GO_WALK, GO_REPLAY, GO_SERIAL } go = GO_WALK;
+	bool in_window = false;
+	int win_lo = 0;
+	for (;;) {
+		if (!in_window) {
+			/* the next event on the chain as it stands: the earliest new candidate behind the windows handled so far (it lies in
+			 * a stretch the old chain idles through in its class: the verify pass found it there) */
+			while (ev < nnew && (int)(ps.knew[ev] >> 18) < t_cur)
+				++ev;
+			if (ev >= nnew)
+				break;
+			const int key = (int)(ps.knew[ev] >> 16);
+			++ev;
+			win_lo = key >> 2;
+			in_window = true;
+			st.pos = cx.dec_base + win_lo;
+			st.r = key & 3;
+			st.fresh = VDL2_STEADY;
+			rk = k2p_lower_bound(skey, nold, key & ~3);
+			go = GO_REPLAY;
+		}
+		if (go != GO_WALK) {
+			if (go == GO_REPLAY)
+				mach_materialize<K2P_NT, false>(sh, cx, st.pos, st.r);
+			const bool replay = go == GO_REPLAY;
+			const int rc = machine_run<K2P_NT, false>(sh, cx, st, true, replay ? out.ntrig + 1 : 0, 1 << 30, replay ? 1 : 0, out);
+			go = GO_WALK;
+			if (rc != MR_STEADY) {	/* the data end (or a deferred burst) inside a history-dependent stretch: the channel state is the machine's */
+				to_end = true;
+				break;
+			}
+		}
+		/* history-free at (st.pos, st.r): the next event is the first candidate of that class at or behind st.pos, old or new */
+		const int want = (int)(st.pos - cx.dec_base), cls = st.r * 2 + (want & 1);
+		rk = k2p_next_old(skey, rk, nold, want, cls);
+		const int jn = k2p_next_new(ps.knew, nnew, want, cls);
+		const int t_old = rk < nold ? (skey[rk] >> 2) : 0x7fffffff;
+		const int t_new = jn < nnew ? (int)(ps.knew[jn] >> 18) : 0x7fffffff;
+		const int t_next = t_old < t_new ? t_old : t_new;
+		if (st.r != r_probe || (want & 1) != par_probe) {
+			/* the new chain idles from here to that candidate in a class the probe did not scan: the round's verify pass looks */
+			const int g_hi = t_next < t_end ? t_next : t_end;
+			if (g_hi > want) {
+				if (nsegs < VDL2_SEG_CAP) {
+					if (tid == 0) {
+						Seg g;
+						g.lo = want;
+						g.hi = g_hi;
+						g.r = st.r;
+						g.pad = 0;
+						segs[nsegs] = g;
+					}
+				} else
+					failed = true;
+				++nsegs;
+			}
+		}
+		if (t_next == 0x7fffffff) {	/* idle to the end of the data */
+			const long long rem = (cx.avail_end - st.pos + 1) / 2;
+			if (rem > 0)
+				st.pos += 2 * rem;
+			steady_end = true;
+			to_end = true;
+			break;
+		}
+		if (t_new < t_old) {	/* another new candidate: no cluster, replayed like the event */
+			st.pos = cx.dec_base + t_new;
+			go = GO_REPLAY;
+			continue;
+		}
+		const int idx = sidx[rk];
+		if (onchain[idx]) {
+			/* the old chain met this candidate history-free as well: the same chain from here on */
+			if (nwin < VDL2_WIN_CAP) {
+				if (tid == 0)
+					ps.win[nwin] = make_int2(win_lo, t_old);
+			} else
+				failed = true;
+			++nwin;
+			t_cur = t_old;
+			in_window = false;
+			continue;
+		}
+		const int2 hd = heads[idx];
+		const int status = hd.y & 3;
+		++rk;	/* (the search goes on behind this candidate) */
+		if (status == CL_INVALID) {
+			st.pos = cx.dec_base + t_old;
+			go = GO_REPLAY;
+			continue;
+		}
+		if (status == CL_DEFER_FIRST) {	/* the burst is not completely inside the data held: the chain ends in front of its trigger */
+			st.pos = cx.dec_base + t_old;
+			add_defer++;
+			steady_end = true;
+			to_end = true;
+			break;
+		}
+		{	/* a cluster K2b made: its bursts are on the new chain */
+			const int ns = (hd.y >> 4) & 15;
+			const unsigned slot0 = (unsigned)(((size_t)sc * VDL2_CAND_CAP + idx) * VDL2_CL_MAXB);
+			if (tid == 0 && ns) {
+				const unsigned q = atomicAdd(nsel, (unsigned)ns);	/* (the serial machine appends through the same counter) */
+				for (int i = 0; i < ns; ++i) {
+					if (q + i < VDL2_SEL_CAP)
+						sel[q + i] = slot0 + i;
+					else
+						atomicAdd(p.outc + 1, 1u);
+				}
+			}
+			add_trig += (hd.y >> 8) & 255;
+			add_rej += (hd.y >> 16) & 255;
+			add_burst += (hd.y >> 24) & 255;
+		}
+		if (status == CL_STEADY) {
+			st.pos = cx.dec_base + hd.x;
+			st.r = (hd.y >> 2) & 3;
+			continue;
+		}
+		/* CL_NONSTEADY: go on from the explicit state the cluster stopped in */
+		__syncthreads();
+		mach_load(sh, &clusters[idx].saved);
+		st.pos = clusters[idx].saved.pos;
+		st.r = clusters[idx].saved.r;
+		st.fresh = clusters[idx].saved.fresh < VDL2_STEADY ? clusters[idx].saved.fresh : VDL2_STEADY - 1;
+		go = GO_SERIAL;
+	}
+	__syncthreads();
+	if (to_end) {	/* the last window runs to the end of the data */
+		if (nwin < VDL2_WIN_CAP) {
+			if (tid == 0)
+				ps.win[nwin] = make_int2(win_lo, 0x7fffffff);
+		} else
+			failed = true;
+		++nwin;
+	}
+	if (out.badslot)
+		failed = true;
+	if (failed) {	/* more windows or stretches than the lists hold: not repaired */
+		if (tid == 0) {
+			atomicMin(p.fail + sc, 0);
+			p.ctl[CTL_NSEL1 + sc] = 0;
+			p.ctl[CTL_NSEG0 + sc] = 0;
+		}
+		return;
+	}
+	__syncthreads();
+	/* what the OLD chain counted inside the windows: the clusters it met there (their heads), the serial stretches it began there */
+	int sub_trig = 0, sub_rej = 0, sub_burst = 0;
+	for (int w = 0; w < nwin; ++w) {
+		const int2 wn = ps.win[w];
+		const int r_lo = k2p_lower_bound(skey, nold, wn.x * 4);
+		const int r_hi = wn.y == 0x7fffffff ? nold : k2p_lower_bound(skey, nold, wn.y * 4);
+		for (int j = r_lo + tid; j < r_hi; j += K2P_NT) {
+			const int idx = sidx[j];
+			if (onchain[idx]) {
+				const int2 hd = heads[idx];
+				sub_trig += (hd.y >> 8) & 255;
+				sub_rej += (hd.y >> 16) & 255;
+				sub_burst += (hd.y >> 24) & 255;
+			}
+		}
+		if (tid < (int)nslog_in) {
+			const K2Slog g = p.slog[(size_t)sc * VDL2_SLOG_CAP + tid];
+			if (g.t >= wn.x && g.t < wn.y) {
+				sub_trig += g.ntrig;
+				sub_rej += g.nrej;
+				sub_burst += g.nburst;
+			}
+		}
+	}
+	for (int d = 32; d > 0; d >>= 1) {
+		sub_trig += __shfl_xor(sub_trig, d, 64);
+		sub_rej += __shfl_xor(sub_rej, d, 64);
+		sub_burst += __shfl_xor(sub_burst, d, 64);
+	}
+	if ((tid & 63) == 0) {
+		ps.u.red[0][tid >> 6] = sub_trig;
+		ps.u.red[1][tid >> 6] = sub_rej;
+		ps.u.red[2][tid >> 6] = sub_burst;
+	}
+	__syncthreads();
+	sub_trig = sub_rej = sub_burst = 0;
+	for (int w = 0; w < K2P_NT / 64; ++w) {
+		sub_trig += ps.u.red[0][w];
+		sub_rej += ps.u.red[1][w];
+		sub_burst += ps.u.red[2][w];
+	}
+	for (int w = tid; w < nwin; w += K2P_NT)
+		p.win[(size_t)sc * VDL2_WIN_CAP + w] = ps.win[w];
+	/* old counters of the push as the first pass left them in cs_out (read before anything is stored) */
+	const unsigned long long o_trig = cs_out->n_trig, o_rej = cs_out->n_reject, o_burst = cs_out->n_burst, o_cand = cs_out->n_cand;
+	__syncthreads();
+	if (to_end) {
+		if (steady_end) {
+			mach_materialize<K2P_NT, false>(sh, cx, st.pos, st.r);
+			st.fresh = VDL2_STEADY;
+		}
+		__syncthreads();
+		mach_store(sh, st, cs_out);
+	}
+	if (tid == 0) {
+		p.ctl[CTL_NSEG0 + sc] = (unsigned)nsegs;
+		p.ctl[CTL_NWIN0 + sc] = (unsigned)nwin;
+		cs_out->n_trig = o_trig - (unsigned long long)sub_trig + (unsigned long long)(add_trig + out.ntrig);
+		cs_out->n_reject = o_rej - (unsigned long long)sub_rej + (unsigned long long)(add_rej + out.nrej);
+		cs_out->n_burst = o_burst - (unsigned long long)sub_burst + (unsigned long long)(add_burst + out.nburst);
+		cs_out->n_cand = o_cand + (unsigned long long)nnew;
+		if (to_end) {
+			cs_out->n_eval = cs->n_eval + (unsigned long long)((st.pos - cs->pos) / 2);
+			cs_out->n_defer = cs->n_defer + (unsigned long long)(out.ndefer + add_defer);
 		}
 	}
 }
@@ -832,6 +1242,7 @@ void k2f_commit(K2Params p)
 		cs->n_redo += 1;
 		atomicAdd(p.outc_total_redo, 1u);
 		p.ctl[CTL_NSEL1 + sc] = 0;	/* K2d: nothing of the resolver's for this channel (it is masked: K2d reads the repair rounds' selection) ... */
+		p.ctl[CTL_NWIN0 + sc] = VDL2_WIN_ALL;
 		p.redo[sc] = 1;			/* (... also where the mask does not reach: K2d's one pass behind the commit asks this word) */
 		if (p.fmask && sc < 512)	/* ... and if K2d ran ahead of the verify pass, the host drops what it made of it */
 			atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
@@ -856,18 +1267,42 @@ void k2d_payload(K2Params p)
 	const int sc = (int)blockIdx.y;	/* stream * VDL2_CS + channel slot, like everywhere else: the grid spans all VDL2_CS slots of every stream */
 	if ((sc % VDL2_CS) >= p.nbch)
 		return;
-	/* second pass (pay_final): only the channels a repair round re-resolved behind the first pass's back; their records
-	 * are final (tag 1).  A channel K2f redid serially has nothing selected. */
-	const bool masked = sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u);
-	if (p.sel_mode == 1 && !masked)
+	/* Which selection.  The first resolver pass's (sel_list) stands but for what the repair rounds made void of it (CTL_NWIN0: the
+	 * bursts triggered inside the windows of a local repair, or all of it), the rounds' own (sel_list2) comes on top.
+	 *   sel_mode 0: the first selection of every channel, beside the verify pass (nothing is known of any repair yet; records tagged 0);
+	 *   sel_mode 1: second pass, behind the commit: only the channels a round touched (masked) -- the first pass's records that have
+	 *               become void are tagged 2 (the host and K4 drop those), the rounds' selection is decoded (records tagged 1);
+	 *   sel_mode 2: the one pass behind the commit of handles that cannot run the decode ahead (more than 512 channel slots: the 16-word
+	 *               mask does not cover them; complete scans): what stands of the first selection, then the rounds' selection. */
+	const bool touched = p.sel_mode == 2 ? p.redo[sc] != 0 : (sc < 512 && (p.fmask[sc >> 5] >> (sc & 31) & 1u));
+	if (p.sel_mode == 1 && !touched)
 		return;
-	/* which of the two selections (see CTL_NSEL1).  The one pass behind the commit (sel_mode 2: the only mode of handles with
-	 * more than 512 channel slots, whose channels the 16-word mask does not cover) asks the channel's own word: a repair round
-	 * that re-resolved it (K2c) or K2f's serial redo set redo[sc] */
-	const bool alt = p.sel_mode == 1 || (p.sel_mode == 2 && p.redo[sc] != 0);
-	unsigned n = p.ctl[(alt ? CTL_NSEL1 : CTL_NSEL0) + sc];
-	n = n > VDL2_SEL_CAP ? VDL2_SEL_CAP : n;
-	const unsigned *sel = (alt ? p.sel_list2 : p.sel_list) + (size_t)sc * VDL2_SEL_CAP;
+	const unsigned nwin = (p.sel_mode != 0 && touched) ? p.ctl[CTL_NWIN0 + sc] : 0u;
+	const int2 *win = p.win + (size_t)sc * VDL2_WIN_CAP;
+	unsigned n0 = p.ctl[CTL_NSEL0 + sc], n1 = (p.sel_mode != 0 && touched) ? p.ctl[CTL_NSEL1 + sc] : 0u;
+	n0 = n0 > VDL2_SEL_CAP ? VDL2_SEL_CAP : n0;
+	n1 = n1 > VDL2_SEL_CAP ? VDL2_SEL_CAP : n1;
+	const unsigned *sel0 = p.sel_list + (size_t)sc * VDL2_SEL_CAP, *sel1 = p.sel_list2 + (size_t)sc * VDL2_SEL_CAP;
+	if (p.sel_mode == 1 && nwin != 0 && p.sel_reserved) {
+		/* the first pass's records of this channel lie in one piece from CTL_SELBASE0 on: tag what has become void */
+		const unsigned base0 = p.ctl[CTL_SELBASE0 + sc];
+		for (unsigned i = blockIdx.x * K2D_NT + threadIdx.x; i < n0; i += gridDim.x * K2D_NT) {
+			if (base0 + i >= p.rec_cap)
+				break;
+			vdl2gpu_burst_t *rec = p.recs + base0 + i;
+			bool dead = nwin == VDL2_WIN_ALL;
+			if (!dead) {
+				const long long t = rec->trig_dec - p.dec_base;
+				for (unsigned w = 0; w < nwin && w < VDL2_WIN_CAP; ++w)
+					dead = dead || (t >= win[w].x && t < win[w].y);
+			}
+			if (dead)
+				rec->trig_sample = 2;
+		}
+	}
+	/* the bursts this launch decodes for the channel: entries [0, na) of the first selection, then [0, n1) of the rounds' */
+	const unsigned na = p.sel_mode == 1 ? 0u : ((p.sel_mode == 2 && nwin == VDL2_WIN_ALL) ? 0u : n0);
+	const unsigned n = na + n1;
 	if (blockIdx.x >= n)
 		return;
 	for (int i = threadIdx.x; i < 72; i += K2D_NT)
@@ -881,13 +1316,24 @@ void k2d_payload(K2Params p)
 		g[514 + i] = d_tab(c_grey3, i);
 	}
 	__syncthreads();
-	const unsigned base = p.ctl[(alt ? CTL_SELBASE1 : CTL_SELBASE0) + sc];	/* reserved by K2c (sel_reserved: the payload decode runs beside the verify pass and
-							 * again for what a repair round re-resolved; every reserved record is written, the void ones tagged) */
+	/* reserved by K2c (first selection) and K2f (the rounds' selection, when it is final): K2d fills them without atomics */
+	const unsigned base0 = p.ctl[CTL_SELBASE0 + sc], base1 = p.ctl[CTL_SELBASE1 + sc];
 	for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+		const bool second = i >= na;
+		const BurstDesc d = p.stage[second ? sel1[i - na] : sel0[i]];
+		if (!second && p.sel_mode == 2 && nwin != 0) {	/* (block-uniform) a burst of the first selection inside a repaired window: not on the chain any more */
+			const long long t = d.nstar - p.dec_base;
+			bool dead = false;
+			for (unsigned w = 0; w < nwin && w < VDL2_WIN_CAP; ++w)
+				dead = dead || (t >= win[w].x && t < win[w].y);
+			if (dead)
+				continue;
+		}
 		unsigned slot;
 		if (p.sel_reserved)
-			slot = base + i;
+			slot = (second ? base1 : base0) + (second ? i - na : i);
 		else {
+			__syncthreads();
 			if (threadIdx.x == 0)
 				s_slot = atomicAdd(p.outc, 1u);
 			__syncthreads();
@@ -899,10 +1345,9 @@ void k2d_payload(K2Params p)
 			slot = 0xffffffffu;
 		}
 		if (slot != 0xffffffffu) {
-			const BurstDesc d = p.stage[sel[i]];
 			const int s = d.sc / VDL2_CS;
 			const float2 *x0 = p.dec + (size_t)d.sc * p.cap - p.dec_base;
-			burst_payload<K2D_NT, true>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.pay_final ? 1 : 0, d.sc, s_tabs, p.pn8);
+			burst_payload<K2D_NT, true>(p.recs + slot, x0, p.pn, d.nstar, d.clk0, d.df, d.nbrow, d.nlbyte, s, p.cfg[d.sc], sph, p.sel_mode == 0 ? 0 : 1, d.sc, s_tabs, p.pn8);
 		}
 		__syncthreads();
 	}

@@ -141,6 +141,9 @@ struct K1PParams {		/* k1_pp: whole periods (PER = 4*SDRCLK inputs = 84 outputs)
 	int wend[84];		/* last sample of each window, relative to the period's first sample */
 };
 
+struct K2Slog {			/* a stretch the first resolver pass handled with the serial machine: where it began (stream-relative) and what it counted */
+	int t, ntrig, nrej, nburst;
+};
 struct K2aItem;
 struct K2Params {
 	const float2 *dec;
@@ -176,7 +179,6 @@ struct K2Params {
 	int mini_round;		/* this repair round re-resolves with what the verify pass found and appended to the tables, nothing else: no scan, no
 				 * clusters (the resolver replays the few new candidates itself) */
 	int sel_reserved;	/* K2c reserves the output records of a channel's selected bursts in one piece (CTL_SELBASE0), K2d fills them without atomics */
-	int pay_final;		/* K2d: second pass, behind the repair rounds (only masked channels, records tagged final) */
 	unsigned rec_cap;
 	int force_serial;	/* diagnostics: skip the tables, run the serial machine */
 	int prim_drop;		/* test handicap: every prim_drop-th candidate gets no precomputed cluster (the resolver builds it) */
@@ -192,6 +194,10 @@ struct K2Params {
 	int *skey;		/* [S*8][CAND_CAP] candidates sorted by time: nrel*4 + r */
 	unsigned short *sidx;	/* [S*8][CAND_CAP] sorted rank -> candidate index */
 	unsigned short *prim;	/* [S*8][CAND_CAP] candidates whose cluster K2b computes */
+	uint8_t *onchain;	/* [S*8][CAND_CAP] by candidate: 1 = the first resolver pass's chain met this candidate in the history-free state (k2p_patch: a
+				 * repaired stretch of the chain that arrives at such a candidate has rejoined the old chain) */
+	K2Slog *slog;		/* [S*8][VDL2_SLOG_CAP] the first pass's serial stretches (their counts are not in any cluster head) */
+	int2 *win;		/* [S*8][VDL2_WIN_CAP] windows of stream-relative time [x, y): bursts of the first selection triggered inside are void (CTL_NWIN0) */
 	int *seeds;		/* [S*8][CAND_CAP] probe instants around which all classes are scanned */
 	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen: a private area per scan workgroup (worked off by that workgroup behind
 				 * its last tile), a common area behind them (worked off by the next kernel on the stream) */
@@ -231,7 +237,15 @@ enum { VDL2_SURV_PROBE = 0, VDL2_SURV_REGION = 1, VDL2_SURV_VERIFY = 2 /* + repa
 #define CTL_SELBASE1 (CTL_CAND0 + (10 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)
 #define CTL_NSURVLIM0 (CTL_CAND0 + (11 + VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)	/* [VDL2_SURV_SLOTS][S*8] ~(where the first group that the common area
 											 * refused would have begun): 0 = none refused; items below it are complete */
-#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (11 + 2 * VDL2_SURV_SLOTS) * (size_t)(nsc))
+#define CTL_NWIN0 (CTL_CAND0 + (11 + 2 * VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)	/* [S*8] what the repair rounds made void of the channel's FIRST selection: 0 nothing,
+											 * 1..VDL2_WIN_CAP: the bursts triggered inside so many windows of stream time (K2Params.win:
+											 * a local repair, k2p_patch), VDL2_WIN_ALL: all of it (the channel was resolved again from its
+											 * input state, or redone serially) */
+#define CTL_NSLOG0 (CTL_CAND0 + (12 + 2 * VDL2_SURV_SLOTS) * p.nstreams * VDL2_CS)	/* [S*8] entries of K2Params.slog the first resolver pass made (VDL2_SLOG_CAP + 1: more than it holds) */
+#define VDL2_CTL_WORDS(nsc) (CTL_CAND0 + (13 + 2 * VDL2_SURV_SLOTS) * (size_t)(nsc))
+#define VDL2_WIN_CAP 32
+#define VDL2_WIN_ALL 0xffffffffu
+#define VDL2_SLOG_CAP 16
 
 struct K3Params {
 	const float2 *src;
