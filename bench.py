@@ -329,7 +329,7 @@ def oracle_streams(tiles, fmt, rate, fos, ntiles, order=None):
 
 
 def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, steps, warmup, seed0, check_streams=4, stream_base=0, fence=None,
-            want_records=False):
+            want_records=False, repeats=3):
     """One more workload inside the same `bench.py --gpus 1` run (the `configs` object of the JSON line): resident input,
     pushes of ntiles x 4.2 MS per stream, bursts delivered to the host -- measured like the headline (pipelined, everything
     drained before the clock stops) and checked like it: every burst of the WHOLE run (first push included) against the
@@ -391,17 +391,22 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
         torch.cuda.synchronize(dev)
         if fence:
             fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            push()
-            if not os.environ.get("BENCH_LEG_NO_DRAIN"):      # development: how fast without the record read-back in the loop
-                drain(True)
-        drain(False)
-        rx.sync()
-        torch.cuda.synchronize(dev)
-        if fence:
-            fence()
-        dt = time.perf_counter() - t0
+        # `repeats` timed runs of `steps` pushes back to back (each drained and fenced): the line carries their median with min / max --
+        # boxes differ by 5-20 % from lease to lease and one run in ten is 10-20 % slow on the same box; a single shot says little
+        dts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                push()
+                if not os.environ.get("BENCH_LEG_NO_DRAIN"):      # development: how fast without the record read-back in the loop
+                    drain(True)
+            drain(False)
+            rx.sync()
+            torch.cuda.synchronize(dev)
+            if fence:
+                fence()
+            dts.append(time.perf_counter() - t0)
+        dt = float(np.median(dts))
         slow = [sync_push() for _ in range(3)]
         st = rx.stats()
     total_tiles = npush * ntiles
@@ -438,6 +443,9 @@ def run_leg(name, workload, local, rate, fos, fmt, nstr, ntiles, bursts_per_s, s
         pk["stream"] += stream_base
         extra = {"_records": pk, "_dt": dt}
     return {**extra, "workload": workload, "value": value if equal else None, "unit": "MS/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "repeats": {"n": repeats, "what": "timed runs of `steps` pushes, back to back on this box; value / ms_per_step are their median",
+                        "values": [nstr * batch * steps / x / 1e6 for x in dts] if equal else None,
+                        "min": (nstr * batch * steps / max(dts) / 1e6) if equal else None, "max": (nstr * batch * steps / min(dts) / 1e6) if equal else None},
             "warmup": warmup, "fmt": fmt, "sdrinrate": rate, "streams": nstr, "channels": 8 * nstr, "samples_per_step": batch * nstr,
             "bursts_per_s_per_channel_offered": bursts_per_s, "recordings_per_stream": nvar, "bursts_per_step": int(round(nrec / max(1, npush))),
             "first_push_ms": first_ms, "max_push_ms": max(slow),
@@ -1006,7 +1014,7 @@ def main():
         lt = args.tiles or 16
         leg = run_leg("config4_512ch", workload=CONFIGS[4]["workload"], local=local, rate=2_000_000, fos=_sy.DEFAULT_FO_8CH, fmt="cs16", nstr=8,
                       ntiles=lt, bursts_per_s=4.0, steps=min(6, args.steps), warmup=min(3, max(1, args.warmup)), seed0=1234, check_streams=2,
-                      stream_base=8 * rank, fence=fence, want_records=True)
+                      stream_base=8 * rank, fence=fence, want_records=True, repeats=1)
         recs4, dt4 = leg.pop("_records"), leg.pop("_dt")
         t = torch.tensor([dt4], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

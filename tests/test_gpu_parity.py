@@ -667,7 +667,7 @@ def test_busy_channels_stay_on_the_parallel_path(built, oracle, bps):
     with _rx(2_000_000, S.FO8, "cs16", max_push=1 << 20) as rx:     # (a cold process loads the kernels' code objects on their
         rx.push(np.zeros(2 << 20, np.int16))                        #  first launch: not what the first push of a HANDLE costs)
         rx.poll()
-    r = bench.run_leg("busy", "test", 0, 2_000_000, sy.DEFAULT_FO_8CH, "cs16", 1, 16, bps, steps=4, warmup=2, seed0=77)
+    r = bench.run_leg("busy", "test", 0, 2_000_000, sy.DEFAULT_FO_8CH, "cs16", 1, 16, bps, steps=4, warmup=2, seed0=77, repeats=1)
     assert r["parity"]["equal"] and r["parity"]["bursts_checked"] > 10_000
     assert r["serial_samples_frac"] < 0.01 and r["overflowed"] == 0
     assert r["first_push_ms"] < 5.0 and r["max_push_ms"] < 5.0, r
@@ -683,7 +683,7 @@ def test_three_pushes_in_the_pipeline_equal_the_oracle(built, oracle, nstr, ntil
     oracle's, whatever the load and the push length, and nothing is left to the serial redo."""
     import bench
     from vdlm2dec_amd import synth as sy
-    r = bench.run_leg("pipeline", "test", 0, 2_000_000, sy.DEFAULT_FO_8CH, "cs16", nstr, ntiles, bps, steps=steps, warmup=2, seed0=4321)
+    r = bench.run_leg("pipeline", "test", 0, 2_000_000, sy.DEFAULT_FO_8CH, "cs16", nstr, ntiles, bps, steps=steps, warmup=2, seed0=4321, repeats=1)
     assert r["parity"]["equal"] and r["parity"]["bursts_checked"] > 1000, r["parity"]
     assert r["serial_redos"] == 0 and r["overflowed"] == 0, r
 

@@ -133,7 +133,9 @@ struct vdl2gpu {
 	unsigned stage_cap = 0;
 	int prim_drop = 0;	/* VDL2GPU_PRIM_DROP (tests) */
 #ifndef VDL2_K2D_GRID
+#ifndef VDL2_K2D_GRID
 #define VDL2_K2D_GRID 64
+#endif
 #endif
 	int k2d_grid = VDL2_K2D_GRID;	/* payload workgroups per channel (VDL2GPU_K2D_GRID): 64 -- half the chip's wavefront slots at the kernel's 119 registers.
 					 * One workgroup per burst is a chain of latencies; 128 per channel held EVERY slot while the verify pass beside it

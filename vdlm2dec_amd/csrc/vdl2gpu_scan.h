@@ -628,8 +628,11 @@ __device__ __forceinline__ void k2a_tail(K2aShared &sh, int sc)
 	 * front of it and parks them in scratch -- 80 bytes per lane written and read back by every workgroup: 31 MB a scan */
 	if (n > 0)
 		k2x_chunk<K2A_THREADS, 1, K2ParamsK &>(w, p, sc, p.surv_mode, p.surv_skip, base, (unsigned)p.surv_pch, n < K2X_NT ? n : K2X_NT);
-	for (unsigned off = K2X_NT; off < n; off += K2X_NT)
-		k2x_chunk<K2A_THREADS, 1, K2ParamsK &>(w, p, sc, p.surv_mode, p.surv_skip, base + off, (unsigned)p.surv_pch, n - off < K2X_NT ? n - off : K2X_NT);
+	for (unsigned off = K2X_NT; off < n; off += K2X_NT) {
+		/* (every further chunk reads the parameters afresh as well: what the compiler cannot hoist out of the loop it does not park in scratch) */
+		K2ParamsK &q = k2_kernarg_again();
+		k2x_chunk<K2A_THREADS, 1, K2ParamsK &>(w, q, sc, q.surv_mode, q.surv_skip, base + off, (unsigned)q.surv_pch, n - off < K2X_NT ? n - off : K2X_NT);
+	}
 }
 
 /* What the scan workgroups' private areas did not hold lies in the list's common area (k2a_append: a stretch where far more
