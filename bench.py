@@ -884,7 +884,7 @@ def main():
                                     "and the final drain that `value` (exactly --steps steps between two fences, the contract's figure) contains"}
         traffic, traffic_src, whole_step = None, None, None
         try:
-            pmf = [f for f in ("r05_bench_pmc_hbm.json", "r04_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            pmf = [f for f in ("r06_bench_pmc_hbm.json", "r05_bench_pmc_hbm.json", "r04_bench_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
             key_now = source_key()
             if pm.get("source_key") != key_now:
@@ -909,7 +909,26 @@ def main():
                               for k in pm["FETCH_SIZE_KB_per_launch"])
                     vinst = sum(v.get("SQ_INSTS_VALU", 0.0) * per_step.get(k, 1.0) for k, v in sq.items())
                 floor_ms = vinst * 4 / 1024 / 2.4e9 * 1e3
-                whole_step = {"valu_wave_insts": vinst, "valu_floor_ms": floor_ms, "hbm_traffic_bytes": hbm, "step_over_valu_floor": ms_step / floor_ms if floor_ms > 0 else None,
+                # per kernel: the SIMDs' time its vector instructions take (4 cycles a wave instruction, 1024 SIMDs, the 2.1 GHz the part sustains
+                # under this load) against the time its launches last in the traced run of the same command: what share of the issue slots it
+                # holds it uses (the rest it waits: LDS and memory round trips, barriers, other kernels' wavefronts)
+                issue = None
+                try:
+                    import csv as _csv
+                    ksf = pmf.replace("_pmc_hbm.json", "_kernel_stats.csv")
+                    ks = {r["Name"].split("(")[0]: (int(r["Calls"]), float(r["AverageNs"])) for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", ksf)))}
+                    npush = max(1, ks.get("k2a_probe", (1, 0.0))[0])
+                    issue = {}
+                    for k, v in sqj.get("per_step", {}).items():
+                        if k in ks and v.get("SQ_INSTS_VALU", 0.0) > 0:
+                            busy_us = v["SQ_INSTS_VALU"] * 4 / 1024 / 2.1e9 * 1e6
+                            held_us = ks[k][0] / npush * ks[k][1] / 1e3
+                            issue[k.replace("void ", "")] = {"valu_us": round(busy_us, 1), "kernel_us": round(held_us, 1), "frac": round(busy_us / held_us, 3) if held_us > 0 else None}
+                except (OSError, KeyError, ValueError):
+                    issue = None
+                whole_step = {"issue_utilisation": issue, "issue_utilisation_source": f"SQ_INSTS_VALU per step (profiles/{sqf}) x 4 cycles / 1024 SIMDs / 2.1 GHz over launches per step x "
+                                                                                      f"AverageNs (profiles/{pmf.replace('_pmc_hbm.json', '_kernel_stats.csv')})",
+                              "valu_wave_insts": vinst, "valu_floor_ms": floor_ms, "hbm_traffic_bytes": hbm, "step_over_valu_floor": ms_step / floor_ms if floor_ms > 0 else None,
                               "hbm_traffic_over_algorithmic": hbm / (batch * nstr * sample_bytes) if batch else None,
                               "source": f"profiles/{sqf} (SQ_INSTS_VALU) and profiles/{pmf}, kernels x launches per step; 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz"}
         except (OSError, KeyError, ValueError, IndexError):

@@ -128,6 +128,7 @@ struct vdl2gpu {
 	uint8_t *d_onchain[VDL2_NSET] = {};	/* K2Params.onchain, .slog, .win: what a local repair stands on and what it leaves (k2p_patch) */
 	K2Slog *d_slog[VDL2_NSET] = {};
 	int2 *d_win[VDL2_NSET] = {};
+	unsigned item_cap = VDL2_ITEM_CAP, item_priv = VDL2_ITEM_PRIV;	/* K2Params.item_cap; of which private areas at most (create_impl) */
 	K2aItem *d_items[VDL2_NSET] = {};	/* what passed the scans' first screen (worked off by the scan workgroups themselves; the common area by the next kernel) */
 	int full_scan = 0;
 	unsigned stage_cap = 0;
@@ -703,6 +704,18 @@ static int create_impl(vdl2gpu_t *h)
 	h->k1_tbase.assign((size_t)S * 8, 0u);
 	const long long jmax = (long long)((21ull * cfg.max_push) / (unsigned)h->sdrclk) + 2;
 	h->cap = (VDL2_CARRY_FRAMES + jmax + 64 + 15) / 16 * 16;	/* planes start on 128-byte lines */
+	{
+		/* The item lists (what passes a scan's first screen: 80 bytes an item, three sets) by the longest PART the handle can be given
+		 * -- max_push, or what push_checked cuts longer pushes into (36 s of air time, a third more in a test build): 64 items of private
+		 * areas per 1024-instant tile (the verify pass's workgroups take four tiles and an area of 256 each; the probe's 42 a tile), the
+		 * common area half of that again.  A 67 MS push at 2 MS/s keeps round 5's 131 072 + 65 536 items per channel (126 MB a set and
+		 * stream); the live path's 32768-sample blocks 16 384 + 8 192 (16 MB). */
+		const long long jcap = 48LL * 84000;
+		const long long tiles_max = (VDL2_CARRY_FRAMES + std::min(jmax, jcap)) / K2A_TS + 2;
+		const unsigned priv = (unsigned)std::min<long long>(VDL2_ITEM_PRIV, std::max<long long>(16384, (64 * tiles_max + 4095) / 4096 * 4096));
+		h->item_priv = priv;
+		h->item_cap = priv / 2 * 3;
+	}
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
 	for (int r = 0; r < VDL2_NSET; ++r) {
 		HIPCHK(h, hipMalloc(&h->d_dec[r], dec_bytes));
@@ -795,7 +808,7 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_win[r], (size_t)S * VDL2_CS * VDL2_WIN_CAP * sizeof(int2)));
 	}
 	for (int r = 0; r < VDL2_NSET; ++r)
-		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
+		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * h->item_cap * sizeof(K2aItem)));
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
@@ -1081,7 +1094,10 @@ static ScanDrain launch_scan(int which, const K2Params &k2, dim3 grid, hipStream
 	/* a scan workgroup's private part of the item list: one and a half times what its tiles yield at the first screen's 2.7 %
 	 * (28 per tile and class; the region scan's tiles are sync words: far more pass) plus a sync word's worth; what it does
 	 * not hold goes to the common area */
+	const unsigned item_priv = k2.item_cap / 3 * 2;	/* (create_impl: the list is private areas + half as much common area) */
 	grid.x = std::min<unsigned>(grid.x, VDL2_MAXWG);
+	if (which != SCAN_VERIFY)	/* (the verify pass's grid IS its map of the part: 256 items x its workgroups fit by construction; the others walk their work with any grid) */
+		grid.x = std::max(1u, std::min<unsigned>(grid.x, item_priv / 256u));
 	unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u * (K2A_TS / 1024u)) + 128u + 255u) / 256u * 256u;	/* (42 of a 1024-instant tile pass: 2.7 % x 1.5) */
 	q.surv_common_cap = 0;	/* (0: whatever the list has left behind the private areas) */
 #ifdef VDL2GPU_TESTHOOKS
@@ -1093,7 +1109,7 @@ static ScanDrain launch_scan(int which, const K2Params &k2, dim3 grid, hipStream
 		q.surv_common_cap = g_test_item_common;
 #endif
 	q.surv_nwg = (int)grid.x;
-	q.surv_pch = (int)std::max(256u, std::min(want, VDL2_ITEM_PRIV / grid.x / 256u * 256u));
+	q.surv_pch = (int)std::max(256u, std::min(want, item_priv / grid.x / 256u * 256u));
 	q.surv_slot = slot;
 	q.surv_mode = mode;
 	q.surv_skip = skip;
@@ -1879,6 +1895,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.slog = h->d_slog[par];
 		k2.win = h->d_win[par];
 		k2.items = h->d_items[par];
+		k2.item_cap = h->item_cap;
 		k2.drain_slot = -1;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)GS);

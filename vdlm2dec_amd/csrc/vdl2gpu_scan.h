@@ -44,7 +44,7 @@
 #define K2X_WL 40		/* sparse stages (k2x_chunk): survivors whose exact phases are in LDS at once (2040 phases) */
 #define K2X_NT 256		/* ... and the items of a chunk: a lane each */
 #define K2X_CV 64		/* of which the fit screen of so many runs in ONE wavefront (11 % get that far) */
-#define VDL2_ITEM_CAP 196608	/* evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
+#define VDL2_ITEM_CAP 196608	/* (at most: K2Params.item_cap is sized by the longest part a handle can be given, vdl2gpu_create) evaluations per channel and scan that pass the first screen (2.7 % of the instants on noise and on
 				 * payload symbols alike: 39 000 of a 33 s class-scan).  The list is in two parts: a private area per scan
 				 * workgroup (p.surv_pch items each, filled through an LDS counter and worked off by the workgroup itself behind its last tile: k2a_tail) and behind
 				 * them a common area for what a workgroup's own area does not hold (one device-scope atomic per wavefront
@@ -305,7 +305,7 @@ __device__ __forceinline__ void k2a_append(K2aShared &sh, const K2Params &p, int
 			atomicMin(&sh.it_limit, off);
 			const unsigned priv = (unsigned)p.surv_nwg * pch;
 			const unsigned off2 = atomicAdd(p.ctl + CTL_NSURV0 + p.surv_slot * p.nstreams * VDL2_CS + sc, cnt);
-			stride = VDL2_ITEM_CAP - priv;
+			stride = p.item_cap - priv;
 			const unsigned room = (p.surv_common_cap > 0 && (unsigned)p.surv_common_cap < stride) ? (unsigned)p.surv_common_cap : stride;
 			base = (off2 + cnt <= room) ? priv * K2A_ITEM_WORDS + off2 : 0xffffffffu;
 			if (base == 0xffffffffu)	/* refused: the drain must not read the common area from here on (nothing was written there) */
@@ -318,7 +318,7 @@ __device__ __forceinline__ void k2a_append(K2aShared &sh, const K2Params &p, int
 	if (!pass)
 		return;
 	if (base != 0xffffffffu) {
-		float4 *dst = reinterpret_cast<float4 *>(p.items) + (size_t)sc * VDL2_ITEM_CAP * K2A_ITEM_WORDS + base + lane_rank;
+		float4 *dst = reinterpret_cast<float4 *>(p.items) + (size_t)sc * p.item_cap * K2A_ITEM_WORDS + base + lane_rank;
 		dst[0] = make_float4(__int_as_float(n_rel), __int_as_float(r | (odd ? 0x100 : 0)), __int_as_float(lo), __int_as_float(hi));
 #pragma unroll
 		for (int w = 0; w < 4; ++w) {
@@ -405,7 +405,7 @@ __device__ __forceinline__ void k2x_chunk(K2xWork &sh, PR p, int sc, int mode, i
 	K2aDef d{};
 	const bool have = act && (unsigned)tid < nhere;
 	if (have) {
-		const float4 *src = reinterpret_cast<const float4 *>(p.items) + (size_t)sc * VDL2_ITEM_CAP * K2A_ITEM_WORDS + w0 + tid;
+		const float4 *src = reinterpret_cast<const float4 *>(p.items) + (size_t)sc * p.item_cap * K2A_ITEM_WORDS + w0 + tid;
 		float4 raw[K2A_ITEM_WORDS];
 #pragma unroll
 		for (int l = 0; l < K2A_ITEM_WORDS; ++l)
@@ -645,7 +645,7 @@ template <int NT> __device__ void k2x_drain(K2xWork &w, const K2Params &p, int s
 	if (p.drain_slot < 0)
 		return;
 	const unsigned pch = (unsigned)p.drain_pch, priv = (unsigned)p.drain_nwg * pch;
-	const unsigned stride = VDL2_ITEM_CAP - priv;
+	const unsigned stride = p.item_cap - priv;
 	unsigned nc = p.ctl[CTL_NSURV0 + p.drain_slot * p.nstreams * VDL2_CS + sc];
 	{
 		const unsigned lim = ~p.ctl[CTL_NSURVLIM0 + p.drain_slot * p.nstreams * VDL2_CS + sc];
