@@ -811,6 +811,30 @@ def test_item_list_common_area_and_overflow(built, oracle, monkeypatch, hooks):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("rounds", [1, 2])
+def test_local_repair_does_not_stand_on_a_verify_pass_whose_list_overflowed(built, oracle, monkeypatch, rounds):
+    """Region scan dropped (every burst is an event the verify pass has to find) AND the verify passes' item lists cut down to three
+    small private areas and a common area of 200 items (test build): the list refuses items, the pass cannot vouch for the channel
+    (fail = 0) although it has listed the events it got to.  The local repair (k2p_patch) verifies only the stretches IT changes: it
+    must leave such a channel to a round that resolves it from its input state, or to the serial redo -- round 6's first version
+    repaired it locally and called it verified (scripts/soak.py seeds 6064, 6068, 6077 on handles with small item lists)."""
+    from vdlm2dec_amd import lib as _lib
+    from vdlm2dec_amd.demod import Receiver, plan_channels
+    monkeypatch.setenv("VDL2GPU_REPAIR_ROUNDS", str(rounds))
+    monkeypatch.setenv("VDL2GPU_TEST_ITEM_VERIFY", "1")
+    monkeypatch.setenv("VDL2GPU_TEST_ITEM_GRID", "3")
+    monkeypatch.setenv("VDL2GPU_TEST_ITEM_COMMON", "200")
+    spec = synth.random_scenario(2_000_000, S.FO8[:3], 7_000_000, seed=3131 + rounds, bursts_per_s=14.0, info_max=400)
+    raw = synth.synth_stream(spec, "cs16")
+    want = sorted(b.key() for b in oracle.run_oracle(raw, "cs16", spec.rate, spec.fo, S.FC))
+    with Receiver(spec.rate, plan_channels(S.FC, spec.fo), fmt="cs16", max_push=1_000_000, flags=_lib.F_TEST_NOREGION, testhooks=True) as rx:
+        got = rx.run(raw, block=1_000_000)
+        st = rx.stats()
+    assert _gpu_keys(got) == want and len(want) >= 60
+    assert st["repairs"] >= 5, st
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("rounds", [1, 2, 3])
 def test_superseded_repair_selections_leave_no_records_behind(built, oracle, monkeypatch, rounds):
     """Region scan dropped (test build), so the verify pass finds an unlisted event behind nearly every burst and channels go

@@ -40,7 +40,7 @@ extern "C" void sincosf(float, float *, float *);
 	} while (0)
 
 #ifdef VDL2GPU_TESTHOOKS
-static int g_test_item_grid = 0, g_test_item_common = 0;	/* read once per vdl2gpu_create (test build only) */
+static int g_test_item_grid = 0, g_test_item_common = 0, g_test_item_verify = 0;	/* read once per vdl2gpu_create (test build only) */
 #endif
 
 #define NEV 8	/* before K1 | K1 | probe+regions | K2b | K2c | verify | K2f+K2d | K3 */
@@ -226,6 +226,7 @@ struct vdl2gpu {
 		bool debug_counters = false;	/* VDL2GPU_DEBUG_COUNTERS: cycle counters of the demodulator kernels */
 		bool split_fixed = false;	/* (test hook) the part length was given: do not adapt it */
 		int k1f_nfam = 0;		/* VDL2GPU_K1F_NFAM */
+		int verify2_wg = 8;		/* VDL2GPU_VERIFY2_WG: workgroups per channel of the local repair round's verify pass */
 		int k1_dbg = 0;			/* VDL2GPU_K1_DBG */
 		int k1_nsub = 0;		/* VDL2GPU_K1_NSUB */
 	} knob;
@@ -709,12 +710,16 @@ static int create_impl(vdl2gpu_t *h)
 		 * -- max_push, or what push_checked cuts longer pushes into (36 s of air time, a third more in a test build): 64 items of private
 		 * areas per 1024-instant tile (the verify pass's workgroups take four tiles and an area of 256 each; the probe's 42 a tile), the
 		 * common area half of that again.  A 67 MS push at 2 MS/s keeps round 5's 131 072 + 65 536 items per channel (126 MB a set and
-		 * stream); the live path's 32768-sample blocks 16 384 + 8 192 (16 MB). */
+		 * stream); a handle for pushes of a few MS 32 768 + 32 768 (42 MB). */
 		const long long jcap = 48LL * 84000;
 		const long long tiles_max = (VDL2_CARRY_FRAMES + std::min(jmax, jcap)) / K2A_TS + 2;
-		const unsigned priv = (unsigned)std::min<long long>(VDL2_ITEM_PRIV, std::max<long long>(16384, (64 * tiles_max + 4095) / 4096 * 4096));
+		const unsigned priv = (unsigned)std::min<long long>(VDL2_ITEM_PRIV, std::max<long long>(32768, (64 * tiles_max + 4095) / 4096 * 4096));
 		h->item_priv = priv;
-		h->item_cap = priv / 2 * 3;
+		h->item_cap = priv + std::max(priv / 2, 32768u);	/* (the common area: what a stretch of sync words or a carrier sends past the private areas) */
+#ifdef VDL2_ITEMS_FULL_VALUES
+		h->item_priv = VDL2_ITEM_PRIV;
+		h->item_cap = VDL2_ITEM_CAP;
+#endif
 	}
 	const size_t dec_bytes = (size_t)S * (size_t)h->cap * VDL2_CS * sizeof(float2);
 	for (int r = 0; r < VDL2_NSET; ++r) {
@@ -808,7 +813,11 @@ static int create_impl(vdl2gpu_t *h)
 		HIPCHK(h, hipMalloc(&h->d_win[r], (size_t)S * VDL2_CS * VDL2_WIN_CAP * sizeof(int2)));
 	}
 	for (int r = 0; r < VDL2_NSET; ++r)
+#ifdef VDL2_ITEMS_ALLOC_FULL
+		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * VDL2_ITEM_CAP * sizeof(K2aItem)));
+#else
 		HIPCHK(h, hipMalloc(&h->d_items[r], (size_t)S * VDL2_CS * h->item_cap * sizeof(K2aItem)));
+#endif
 	/* every environment knob is read here, once */
 	auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 	h->full_scan = ((cfg.flags & VDL2GPU_F_FULLSCAN) || getenv("VDL2GPU_FULL_SCAN")) ? 1 : 0;
@@ -825,12 +834,14 @@ static int create_impl(vdl2gpu_t *h)
 	h->knob.k1_pp = getenv("VDL2GPU_K1_PP") != nullptr;
 	h->knob.debug_counters = getenv("VDL2GPU_DEBUG_COUNTERS") != nullptr;
 	h->knob.k1f_nfam = env_int("VDL2GPU_K1F_NFAM", 0);
+	h->knob.verify2_wg = std::max(1, env_int("VDL2GPU_VERIFY2_WG", 8));
 	h->knob.k1_dbg = env_int("VDL2GPU_K1_DBG", 0);
 	h->knob.k1_nsub = env_int("VDL2GPU_K1_NSUB", 0);
 #ifdef VDL2GPU_TESTHOOKS
 	h->prim_drop = env_int("VDL2GPU_PRIM_DROP", 0);
 	g_test_item_grid = env_int("VDL2GPU_TEST_ITEM_GRID", 0);
 	g_test_item_common = env_int("VDL2GPU_TEST_ITEM_COMMON", 0);
+	g_test_item_verify = env_int("VDL2GPU_TEST_ITEM_VERIFY", 0);	/* the two above for the verify passes only */
 #endif
 	/* A push in which a channel's verify pass fails with no round scheduled costs a serial redo of that channel's whole
 	 * push (milliseconds), an idle round 30 us: with 16 channels or more an event somewhere is frequent enough that one
@@ -1094,18 +1105,19 @@ static ScanDrain launch_scan(int which, const K2Params &k2, dim3 grid, hipStream
 	/* a scan workgroup's private part of the item list: one and a half times what its tiles yield at the first screen's 2.7 %
 	 * (28 per tile and class; the region scan's tiles are sync words: far more pass) plus a sync word's worth; what it does
 	 * not hold goes to the common area */
-	const unsigned item_priv = k2.item_cap / 3 * 2;	/* (create_impl: the list is private areas + half as much common area) */
+	const unsigned item_priv = k2.item_priv;
 	grid.x = std::min<unsigned>(grid.x, VDL2_MAXWG);
 	if (which != SCAN_VERIFY)	/* (the verify pass's grid IS its map of the part: 256 items x its workgroups fit by construction; the others walk their work with any grid) */
 		grid.x = std::max(1u, std::min<unsigned>(grid.x, item_priv / 256u));
 	unsigned want = (tiles_per_wg * (which == SCAN_REGION ? 400u : 42u * (K2A_TS / 1024u)) + 128u + 255u) / 256u * 256u;	/* (42 of a 1024-instant tile pass: 2.7 % x 1.5) */
 	q.surv_common_cap = 0;	/* (0: whatever the list has left behind the private areas) */
 #ifdef VDL2GPU_TESTHOOKS
-	if (g_test_item_grid > 0) {	/* VDL2GPU_TEST_ITEM_GRID: few scan workgroups with the smallest private areas -- most items take the common area's path */
+	const bool test_items = !g_test_item_verify || which == SCAN_VERIFY;
+	if (test_items && g_test_item_grid > 0) {	/* VDL2GPU_TEST_ITEM_GRID: few scan workgroups with the smallest private areas -- most items take the common area's path */
 		grid.x = std::min<unsigned>(grid.x, (unsigned)g_test_item_grid);
 		want = 256u;
 	}
-	if (g_test_item_common > 0)	/* VDL2GPU_TEST_ITEM_COMMON: a common area of so many items -- the list overflows */
+	if (test_items && g_test_item_common > 0)	/* VDL2GPU_TEST_ITEM_COMMON: a common area of so many items -- the list overflows */
 		q.surv_common_cap = g_test_item_common;
 #endif
 	q.surv_nwg = (int)grid.x;
@@ -1373,7 +1385,14 @@ static int enqueue_back(vdl2gpu_t *h)
 				if (staged && h->stage_dump)
 					HIPCHK(h, hipEventRecord(pt.e[18], ts));
 				scan_drain(k2r, ScanDrain());
-				vdrain = launch_scan(SCAN_VERIFY, k2r, vgrid, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN);
+				{
+					/* a handful of workgroups per channel, each walking its share of the part's runs of tiles (k2a_verify): the stretches a
+					 * local repair changed are a few tiles, and every workgroup of the launch, the 2 800 that find nothing included, has to
+					 * wait for a slot beside the other pushes' wide kernels before it can leave */
+					const unsigned nv = std::min<unsigned>(vgrid.x, (unsigned)h->knob.verify2_wg);
+					const dim3 vnarrow(nv, vgrid.y, vgrid.z);
+					vdrain = launch_scan(SCAN_VERIFY, k2r, vnarrow, ts, VDL2_SURV_VERIFY + rr, 1, 0, K2A_VRUN * ((vgrid.x + nv - 1) / nv));
+				}
 			} else {
 				/* a further round resolves the channels that still fail again from their input state, with everything listed so far */
 				scan_drain(k2r, vdrain);
@@ -1896,6 +1915,7 @@ static int push_impl(vdl2gpu_t *h, const void *iq, size_t nsamples, size_t strea
 		k2.win = h->d_win[par];
 		k2.items = h->d_items[par];
 		k2.item_cap = h->item_cap;
+		k2.item_priv = h->item_priv;
 		k2.drain_slot = -1;
 		const unsigned tiles = (unsigned)((VDL2_CARRY_FRAMES + J) / K2A_TS + 2);
 		const dim3 gch((unsigned)h->C, (unsigned)GS);

@@ -826,6 +826,11 @@ void k2c_resolve(K2Params p)
  * channel from its input state as before (k2s_merge + k2c_resolve), or K2f redoes it serially.
  * Match: d8psk.c:292-313 (what a trigger changes), 97-107 (a rejected header), 317-319 (the sub-phase sticks). */
 #define K2P_NT K2_NT
+#ifdef K2P_TRACE
+#define K2P_TR(...) do { if (tid == 0 && sc == K2P_TRACE) printf(__VA_ARGS__); } while (0)
+#else
+#define K2P_TR(...) do { } while (0)
+#endif
 struct K2pShared {
 	MachSharedT<K2P_NT> m;
 	unsigned long long knew[K2S_MERGE];	/* the new candidates by time: (nrel * 4 + r) << 16 | index */
@@ -921,7 +926,11 @@ void k2p_patch(K2Params p)
 			atomicOr(p.fmask + (sc >> 5), 1u << (sc & 31));
 	}
 	/* what cannot be repaired locally stays failed (fail[] keeps its value): the next round, or K2f, takes the channel from its input state */
-	if (ncand > VDL2_CAND_CAP || ovf_in != 0 || nnew <= 0 || nnew > K2S_MERGE || nslog_in > VDL2_SLOG_CAP)
+	/* fail_in <= 0 is not an event's instant: the verify pass could not vouch for the channel (items refused by a full list, more stretches than
+	 * the lists hold): stretches it was to look at have not been looked at, and a local repair verifies only what IT changes
+	 * [found by scripts/soak.py on handles whose item lists are small: seeds 6064, 6068, 6077] */
+	K2P_TR("k2p sc %d: fail_in %d ncand %d nold %d nslog %u ovf %u dec_base %lld\n", sc, fail_in, ncand, nold, nslog_in, ovf_in, (long long)p.dec_base);
+	if (ncand > VDL2_CAND_CAP || ovf_in != 0 || nnew <= 0 || nnew > K2S_MERGE || nslog_in > VDL2_SLOG_CAP || fail_in <= 0)
 		return;
 	__syncthreads();
 	if (tid == 0)
@@ -966,7 +975,7 @@ void k2p_patch(K2Params p)
 	int add_trig = 0, add_rej = 0, add_burst = 0;	/* what the table clusters on the new chain count */
 	int add_defer = 0;
 	int nwin = 0, nsegs = 0;
-	int rk = 0;		/* a rank of the sorted table at or below the first entry at the current time */
+	int rk = 0;		/* rank of the old candidate the walk is looking at */
 	int ev = 0;		/* next new candidate to look at */
 	int t_cur = -0x7fffffff;	/* events before this lie inside a window already handled */
 	bool to_end = false, steady_end = false, failed = false;
@@ -985,11 +994,11 @@ void k2p_patch(K2Params p)
 			const int key = (int)(ps.knew[ev] >> 16);
 			++ev;
 			win_lo = key >> 2;
+			K2P_TR("  event %d r %d (t_cur %d)\n", key >> 2, key & 3, t_cur);
 			in_window = true;
 			st.pos = cx.dec_base + win_lo;
 			st.r = key & 3;
 			st.fresh = VDL2_STEADY;
-			rk = k2p_lower_bound(skey, nold, key & ~3);
 			go = GO_REPLAY;
 		}
 		if (go != GO_WALK) {
@@ -998,6 +1007,7 @@ void k2p_patch(K2Params p)
 			const bool replay = go == GO_REPLAY;
 			const int rc = machine_run<K2P_NT, false>(sh, cx, st, true, replay ? out.ntrig + 1 : 0, 1 << 30, replay ? 1 : 0, out);
 			go = GO_WALK;
+			K2P_TR("  machine rc %d -> pos %lld r %d fresh %d ntrig %d nburst %d ndefer %d\n", rc, (long long)(st.pos - cx.dec_base), st.r, st.fresh, out.ntrig, out.nburst, out.ndefer);
 			if (rc != MR_STEADY) {	/* the data end (or a deferred burst) inside a history-dependent stretch: the channel state is the machine's */
 				to_end = true;
 				break;
@@ -1005,12 +1015,16 @@ void k2p_patch(K2Params p)
 		}
 		/* history-free at (st.pos, st.r): the next event is the first candidate of that class at or behind st.pos, old or new */
 		const int want = (int)(st.pos - cx.dec_base), cls = st.r * 2 + (want & 1);
-		rk = k2p_next_old(skey, rk, nold, want, cls);
+		/* (the search starts at the first entry at or behind `want` whatever its class: the hit of one class says nothing about where the
+		 * candidates of the class the chain is in after the NEXT burst lie -- round 6's first version went on from the hit and, once a class
+		 * had no further candidate, found none of any class: scripts/soak.py seed 6068) */
+		rk = k2p_next_old(skey, k2p_lower_bound(skey, nold, want * 4), nold, want, cls);
 		const int jn = k2p_next_new(ps.knew, nnew, want, cls);
 		const int t_old = rk < nold ? (skey[rk] >> 2) : 0x7fffffff;
 		const int t_new = jn < nnew ? (int)(ps.knew[jn] >> 18) : 0x7fffffff;
 		const int t_next = t_old < t_new ? t_old : t_new;
-		if (st.r != r_probe || (want & 1) != par_probe) {
+		K2P_TR("  walk at %d r %d cls %d: t_old %d (rk %d) t_new %d\n", want, st.r, cls, t_old, rk, t_new);
+		if (st.r != r_probe || (int)(st.pos & 1) != par_probe) {	/* (the probe's parity is one of STREAM time: a push's time base may be odd) */
 			/* the new chain idles from here to that candidate in a class the probe did not scan: the round's verify pass looks */
 			const int g_hi = t_next < t_end ? t_next : t_end;
 			if (g_hi > want) {
@@ -1042,6 +1056,7 @@ void k2p_patch(K2Params p)
 			continue;
 		}
 		const int idx = sidx[rk];
+		K2P_TR("  cand idx %d onchain %d\n", idx, (int)onchain[idx]);
 		if (onchain[idx]) {
 			/* the old chain met this candidate history-free as well: the same chain from here on */
 			if (nwin < VDL2_WIN_CAP) {
@@ -1056,7 +1071,7 @@ void k2p_patch(K2Params p)
 		}
 		const int2 hd = heads[idx];
 		const int status = hd.y & 3;
-		++rk;	/* (the search goes on behind this candidate) */
+		K2P_TR("  old cand idx %d status %d x %d\n", idx, status, hd.x);
 		if (status == CL_INVALID) {
 			st.pos = cx.dec_base + t_old;
 			go = GO_REPLAY;
@@ -1099,6 +1114,7 @@ void k2p_patch(K2Params p)
 		go = GO_SERIAL;
 	}
 	__syncthreads();
+	K2P_TR(" end: to_end %d steady_end %d failed %d nwin %d nsegs %d pos %lld r %d\n", (int)to_end, (int)steady_end, (int)failed, nwin, nsegs, (long long)(st.pos - cx.dec_base), st.r);
 	if (to_end) {	/* the last window runs to the end of the data */
 		if (nwin < VDL2_WIN_CAP) {
 			if (tid == 0)

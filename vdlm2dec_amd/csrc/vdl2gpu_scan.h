@@ -1286,60 +1286,70 @@ void k2a_verify(K2Params p)
 	if (p.round > 0 && !p.redo[sc])
 		return;
 	const long long dec_base = p.dec_base;
-	const int r_lo = (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * K2A_VRUN * 2 * K2A_TS;
 	const int t_end = (int)(VDL2_CARRY_FRAMES + p.J);
-	if (r_lo >= t_end)
-		return;
-	const int r_hi = r_lo + K2A_VRUN * 2 * K2A_TS < t_end ? r_lo + K2A_VRUN * 2 * K2A_TS : t_end;
 	const int nseg = (int)p.ctl[CTL_NSEG0 + sc];
 	const Seg *segs = p.segs + (size_t)sc * VDL2_SEG_CAP;
-	k2a_tables(sh);
-	if (tid == 0)
-		s_nl = 0;
-	__syncthreads();
-	for (int k = tid; k < nseg && k < VDL2_SEG_CAP; k += K2A_THREADS) {
-		const Seg g = segs[k];
-		if (g.lo < r_hi && g.hi > r_lo && g.hi > g.lo) {
-			const int q = atomicAdd(&s_nl, 1);
-			if (q < 64)
-				s_list[q] = k;
-		}
-	}
-	__syncthreads();
-	const int nl = s_nl;
-	if (tid == 0) {
-		int ni = 0;
-		for (int q = 0; q < nl && q < 64; ++q) {
-			const Seg g = segs[s_list[q]];
-			for (int t_lo = r_lo; t_lo < r_hi; t_lo += 2 * K2A_TS) {
-				const int t_hi = t_lo + 2 * K2A_TS < r_hi ? t_lo + 2 * K2A_TS : r_hi;
-				int lo = g.lo > t_lo ? g.lo : t_lo;
-				const int hi = g.hi < t_hi ? g.hi : t_hi;
-				lo += (lo ^ g.lo) & 1;		/* keep the segment's parity */
-				if (lo >= hi)
-					continue;
-				if (ni < K2A_VITEMS)
-					s_item[ni] = make_int4(lo, hi, g.r, 0);
-				++ni;
-			}
-		}
-		s_ni = ni;
-	}
-	__syncthreads();
-	const int ni = s_ni;
-	if (nl > 64 || ni > K2A_VITEMS) {	/* absurdly fragmented stretch: give up on the tables for this channel */
-		if (tid == 0)
-			atomicMin(p.fail + sc, 0);
+	if (nseg == 0 || (int)(p.cs[sc].pos - dec_base) + (int)blockIdx.x * K2A_VRUN * 2 * K2A_TS >= t_end)	/* (block-uniform) nothing to look at: not even the tables */
 		return;
-	}
+	k2a_tables(sh);
 	K2aPre<2> pre;
 	pre.loaded = false;
 	pre.tiles = 0;
-	for (int q = 0; q < ni; ++q) {
-		const int4 it = s_item[q];
-		const int4 nx = (q + 1 < ni) ? s_item[q + 1] : make_int4(0, 0, 0, 0);
-		k2a_tile<2>(sh, p, sc, dec_base, dec_base + it.x, (it.y - it.x + 1) / 2, 1u << it.z, 1, dec_base + it.x, dec_base + it.y,
-			    p.fail + sc, pre, dec_base + nx.x, (nx.y - nx.x + 1) / 2);
+	/* a workgroup's runs of K2A_VRUN tiles: blockIdx.x, blockIdx.x + gridDim.x, ... -- the first pass's grid has a workgroup per run;
+	 * a repair round's pass, which looks at the few stretches a local repair changed, is launched with a handful of workgroups per
+	 * channel (enqueue_back: 2 800 workgroups that find nothing each wait for a slot beside the other pushes' wide kernels) */
+	for (int run = (int)blockIdx.x;; run += (int)gridDim.x) {
+		const int r_lo = (int)(p.cs[sc].pos - dec_base) + run * K2A_VRUN * 2 * K2A_TS;
+		if (r_lo >= t_end)
+			break;
+		const int r_hi = r_lo + K2A_VRUN * 2 * K2A_TS < t_end ? r_lo + K2A_VRUN * 2 * K2A_TS : t_end;
+		__syncthreads();	/* (the lists of the run before have been read) */
+		if (tid == 0)
+			s_nl = 0;
+		__syncthreads();
+		for (int k = tid; k < nseg && k < VDL2_SEG_CAP; k += K2A_THREADS) {
+			const Seg g = segs[k];
+			if (g.lo < r_hi && g.hi > r_lo && g.hi > g.lo) {
+				const int q = atomicAdd(&s_nl, 1);
+				if (q < 64)
+					s_list[q] = k;
+			}
+		}
+		__syncthreads();
+		const int nl = s_nl;
+		if (nl == 0)	/* (block-uniform) */
+			continue;
+		if (tid == 0) {
+			int ni = 0;
+			for (int q = 0; q < nl && q < 64; ++q) {
+				const Seg g = segs[s_list[q]];
+				for (int t_lo = r_lo; t_lo < r_hi; t_lo += 2 * K2A_TS) {
+					const int t_hi = t_lo + 2 * K2A_TS < r_hi ? t_lo + 2 * K2A_TS : r_hi;
+					int lo = g.lo > t_lo ? g.lo : t_lo;
+					const int hi = g.hi < t_hi ? g.hi : t_hi;
+					lo += (lo ^ g.lo) & 1;		/* keep the segment's parity */
+					if (lo >= hi)
+						continue;
+					if (ni < K2A_VITEMS)
+						s_item[ni] = make_int4(lo, hi, g.r, 0);
+					++ni;
+				}
+			}
+			s_ni = ni;
+		}
+		__syncthreads();
+		const int ni = s_ni;
+		if (nl > 64 || ni > K2A_VITEMS) {	/* absurdly fragmented stretch: give up on the tables for this channel */
+			if (tid == 0)
+				atomicMin(p.fail + sc, 0);
+			break;
+		}
+		for (int q = 0; q < ni; ++q) {
+			const int4 it = s_item[q];
+			const int4 nx = (q + 1 < ni) ? s_item[q + 1] : make_int4(0, 0, 0, 0);
+			k2a_tile<2>(sh, p, sc, dec_base, dec_base + it.x, (it.y - it.x + 1) / 2, 1u << it.z, 1, dec_base + it.x, dec_base + it.y,
+				    p.fail + sc, pre, dec_base + nx.x, (nx.y - nx.x + 1) / 2);
+		}
 	}
 	k2a_tail(sh, sc);
 }

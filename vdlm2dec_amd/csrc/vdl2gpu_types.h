@@ -202,6 +202,7 @@ struct K2Params {
 	struct K2aItem *items;	/* [S*8][ITEM_CAP] what passed a scan's first screen: a private area per scan workgroup (worked off by that workgroup behind
 				 * its last tile), a common area behind them (worked off by the next kernel on the stream) */
 	unsigned item_cap;	/* items per channel of the list (private areas + common area): sized by the longest part the handle can be given */
+	unsigned item_priv;	/* ... of which private areas at most (host side: launch_scan) */
 	int surv_pch, surv_nwg;	/* items a private area holds (a multiple of 256), scan workgroups per channel (= private areas) */
 	int surv_common_cap;	/* test hook: the common area holds only so many items (0: all that is left of the list) */
 	int surv_slot;		/* which of the push's scans this is: its item counters are ctl[CTL_NSURV0 + slot * S*8 ...] (VDL2_SURV_*) */
